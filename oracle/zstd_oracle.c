@@ -1,0 +1,1073 @@
+/*
+ * zstd_oracle.c — CPU restatement of the reference's zstd decode path.
+ *
+ * >>> TEST INFRASTRUCTURE, NOT PRODUCT CODE. <<<
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load this library.  The product path (cairo_zstd_amd/csrc) never links,
+ * imports or calls anything in oracle/.
+ *
+ * What it restates: NethermindEth/cairo_zstd (pure Cairo 1), the path
+ *   frame_decoder -> block_decoder -> {literals, sequences, execution}.
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference tree root).  The reference cannot be compiled here (Cairo 1 /
+ * scarb 2.3.1, toolchain absent), so this restatement is
+ * PINNED against the reference's own vectors instead (tests/test_oracle_*.py):
+ *   - data/decode_corpus: 100 (original, .zst) pairs, every frame also
+ *     self-checking through its XXH64 content checksum;
+ *   - src/tests/bit_reader.cairo:14-16,56-58 (16-byte constant, both readers);
+ *   - src/decoding/sequence_section_decoder.cairo:707-737 (5 LL-table entries);
+ *   - src/tests/utils.cairo:134-150 (14 XXH64 known answers).
+ *
+ * Deliberate resolution of a reference defect: direct Huffman
+ * weights use the zstd-format nibble order (even index = high nibble); the
+ * reference line huff0_decoder.cairo:302 (`idx | 1 == 1`) is a latent bug the
+ * corpus cannot observe (all 422 direct headers carry 15 equal weights).
+ * czo_set_d1_reference_nibbles(1) switches to the literal reference behaviour.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -shared -fPIC -pthread).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "../include/cairo_zstd_amd_status.h"
+
+#define CZO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ utils */
+
+/* src/utils/math.cairo:266-271: BITS - leading_zeros, i.e. 1-based index of the top set bit */
+static inline unsigned highest_bit_set(uint32_t v) { return v ? 32u - (unsigned)__builtin_clz(v) : 0u; }
+/* src/utils/math.cairo:281-283 */
+static inline int is_power_of_two(uint32_t v) { return v != 0 && (v & (v - 1)) == 0; }
+
+static int g_d1_reference_nibbles = 0;
+CZO_API void czo_set_d1_reference_nibbles(int on) { g_d1_reference_nibbles = on; }
+
+/* ------------------------------------------------------------ XXH64 (seed) */
+/* src/utils/xxhash64.cairo:20-163 — streaming XXH64; this is the one-shot form
+   plus a streaming state so that drain()-wise hashing can be mirrored. */
+#define P1 0x9E3779B185EBCA87ULL
+#define P2 0xC2B2AE3D27D4EB4FULL
+#define P3 0x165667B19E3779F9ULL
+#define P4 0x85EBCA77C2B2AE63ULL
+#define P5 0x27D4EB2F165667C5ULL
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline uint64_t xxh_round(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
+static inline uint64_t xxh_merge(uint64_t h, uint64_t v) { v = xxh_round(0, v); h ^= v; return h * P1 + P4; }
+
+typedef struct {
+    uint64_t total_len, v1, v2, v3, v4, seed;
+    uint8_t mem[32];
+    uint32_t memsize;
+} xxh64_state;
+
+static void xxh64_reset(xxh64_state* s, uint64_t seed) {
+    memset(s, 0, sizeof *s);
+    s->seed = seed; s->v1 = seed + P1 + P2; s->v2 = seed + P2; s->v3 = seed; s->v4 = seed - P1;
+}
+static void xxh64_update(xxh64_state* s, const uint8_t* p, size_t len) {
+    s->total_len += len;
+    if (s->memsize + len < 32) { memcpy(s->mem + s->memsize, p, len); s->memsize += (uint32_t)len; return; }
+    const uint8_t* end = p + len;
+    if (s->memsize) {
+        size_t fill = 32 - s->memsize; memcpy(s->mem + s->memsize, p, fill);
+        s->v1 = xxh_round(s->v1, rd64(s->mem)); s->v2 = xxh_round(s->v2, rd64(s->mem + 8));
+        s->v3 = xxh_round(s->v3, rd64(s->mem + 16)); s->v4 = xxh_round(s->v4, rd64(s->mem + 24));
+        p += fill; s->memsize = 0;
+    }
+    while (p + 32 <= end) {
+        s->v1 = xxh_round(s->v1, rd64(p)); s->v2 = xxh_round(s->v2, rd64(p + 8));
+        s->v3 = xxh_round(s->v3, rd64(p + 16)); s->v4 = xxh_round(s->v4, rd64(p + 24)); p += 32;
+    }
+    if (p < end) { memcpy(s->mem, p, (size_t)(end - p)); s->memsize = (uint32_t)(end - p); }
+}
+static uint64_t xxh64_digest(const xxh64_state* s) {
+    uint64_t h;
+    if (s->total_len >= 32) {
+        h = rotl64(s->v1, 1) + rotl64(s->v2, 7) + rotl64(s->v3, 12) + rotl64(s->v4, 18);
+        h = xxh_merge(h, s->v1); h = xxh_merge(h, s->v2); h = xxh_merge(h, s->v3); h = xxh_merge(h, s->v4);
+    } else h = s->seed + P5;
+    h += s->total_len;
+    const uint8_t* p = s->mem; const uint8_t* end = p + s->memsize;
+    while (p + 8 <= end) { h ^= xxh_round(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl64(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+CZO_API uint64_t czo_xxh64(const uint8_t* p, size_t len, uint64_t seed) {
+    xxh64_state s; xxh64_reset(&s, seed); xxh64_update(&s, p, len); return xxh64_digest(&s);
+}
+
+/* ------------------------------------------------- forward (LSB-first) reader */
+/* src/decoding/bit_reader.cairo:18-110.  Bit i of the stream is bit i%8 of byte i/8. */
+typedef struct { const uint8_t* src; size_t len; size_t idx; } fbr;
+static void fbr_init(fbr* r, const uint8_t* src, size_t len) { r->src = src; r->len = len; r->idx = 0; }
+/* bit_reader.cairo:38-104.  Returns 0 on success, CZ_E_FSE_GETBITS-style nonzero when the
+   stream is too short (NotEnoughRemainingBits, :42-44). */
+static int fbr_get(fbr* r, unsigned n, uint64_t* out) {
+    if (n > 64) return 1;                                   /* :39-41 TooManyBits */
+    if (r->len * 8 - r->idx < n) return 2;                  /* :42-44 */
+    uint64_t v = 0;
+    for (unsigned i = 0; i < n; i++) {                      /* :46-99, restated bit by bit */
+        size_t b = r->idx + i;
+        v |= (uint64_t)((r->src[b >> 3] >> (b & 7)) & 1u) << i;
+    }
+    r->idx += n; *out = v; return 0;
+}
+static void fbr_return(fbr* r, unsigned n) { r->idx -= n; } /* :31-36 */
+
+/* ------------------------------------------------- reverse (MSB-first) reader */
+/* src/decoding/bit_reader_reverse.cairo:44-275.  The reference keeps a 64-bit
+   container plus `idx`; the only observable state is
+       bits_remaining = idx + bits_in_container          (:45-50)
+   which may go NEGATIVE: past the start, reads yield zero bits and keep
+   decrementing (:147-150); a read straddling the start returns the real bits
+   shifted left by the deficit (:152-159).  That is exactly "the bit string,
+   zero-extended below bit 0", which is what `pos` models here. */
+typedef struct { const uint8_t* src; size_t len; int64_t pos; } rbr;
+static void rbr_init(rbr* r, const uint8_t* src, size_t len) { r->src = src; r->len = len; r->pos = (int64_t)len * 8; }
+static inline int64_t rbr_bits_remaining(const rbr* r) { return r->pos; }
+/* get_bits :129-172.  n>56 only errors on the cold path (:141-143); every call site
+   that can pass n>56 passes 255 (out-of-range LL/ML code), which can never be
+   served from a <=64-bit container, so n>56 is always TooManyBits. */
+static inline int rbr_get(rbr* r, unsigned n, uint64_t* out) {
+    if (n == 0) { *out = 0; return 0; }                     /* :130-132 */
+    if (n > 56) { *out = 0; return 1; }                     /* :141-143 */
+    int64_t hi = r->pos;                                    /* bits [hi-n, hi) */
+    int64_t lo = hi - (int64_t)n;
+    r->pos = lo;
+    if (hi <= 0) { *out = 0; return 0; }                    /* :147-150 */
+    uint64_t v;
+    if (lo >= 0) {
+        size_t byte = (size_t)(lo >> 3);
+        if (byte + 8 <= r->len) {
+            v = rd64(r->src + byte) >> (lo & 7);
+        } else {
+            v = 0;
+            for (size_t i = byte, k = 0; i < r->len; i++, k++) v |= (uint64_t)r->src[i] << (8 * k);
+            v >>= (lo & 7);
+        }
+        *out = v & ((1ULL << n) - 1);
+    } else {                                                /* :152-159 partial read */
+        unsigned have = (unsigned)hi;                       /* real bits [0, hi) */
+        v = 0;
+        for (size_t i = 0, k = 0; i < r->len && k < 8; i++, k++) v |= (uint64_t)r->src[i] << (8 * k);
+        v &= (have >= 64) ? ~0ULL : ((1ULL << have) - 1);
+        *out = v << (unsigned)(-lo);
+    }
+    return 0;
+}
+/* Shared prologue of every reversed stream: skip zero padding up to and including the
+   first 1 bit; more than 8 reads => ExtraPadding.
+   literals_section_decoder.cairo:190-207, sequence_section_decoder.cairo:46-64,
+   huff0_decoder.cairo:206-225. */
+static int rbr_skip_padding(rbr* r) {
+    int skipped = 0; uint64_t v;
+    for (;;) {
+        rbr_get(r, 1, &v); skipped++;
+        if (v == 1 || skipped > 8) break;
+    }
+    return skipped > 8;
+}
+
+/* ----------------------------------------------------------------- FSE table */
+/* src/fse/fse_decoder.cairo:15-20,49-53 */
+typedef struct { uint32_t base_line; uint8_t num_bits; uint8_t symbol; } fse_entry;
+#define FSE_MAX_STORED_PROBS 260
+typedef struct {
+    fse_entry* decode; size_t decode_cap;   /* 2^accuracy_log entries */
+    uint8_t accuracy_log;
+    int32_t probs[FSE_MAX_STORED_PROBS]; uint32_t nprobs;
+} fse_table;
+
+static void fse_reset(fse_table* t) { t->accuracy_log = 0; t->nprobs = 0; }       /* :125-130 */
+static void fse_free(fse_table* t) { free(t->decode); t->decode = NULL; t->decode_cap = 0; }
+static int fse_reserve(fse_table* t, size_t n) {
+    if (t->decode_cap >= n) return 0;
+    fse_entry* p = (fse_entry*)realloc(t->decode, n * sizeof(fse_entry));
+    if (!p) return 1;
+    t->decode = p; t->decode_cap = n; return 0;
+}
+/* :371-375 */
+static inline uint32_t fse_next_position(uint32_t p, uint32_t table_size) {
+    p += (table_size >> 1) + (table_size >> 3) + 3; return p & (table_size - 1);
+}
+/* :377-400 */
+static void fse_baseline_numbits(uint32_t total, uint32_t nsym, uint32_t state_number, uint32_t* bl, uint8_t* nb) {
+    uint32_t mask = 1u << (highest_bit_set(nsym) - 1);
+    uint32_t slices = (mask == nsym) ? nsym : mask * 2;
+    uint32_t dbl = slices - nsym, single = nsym - dbl, width = total / slices;
+    uint32_t num_bits = highest_bit_set(width) - 1;
+    if (state_number < dbl) { *bl = single * width + state_number * width * 2; *nb = (uint8_t)(num_bits + 1); }
+    else { *bl = (state_number - dbl) * width; *nb = (uint8_t)num_bits; }
+}
+/* :156-256 */
+static int fse_build_decoding_table(fse_table* t) {
+    uint32_t size = 1u << t->accuracy_log;
+    if (fse_reserve(t, size)) return 1;
+    memset(t->decode, 0, size * sizeof(fse_entry));
+    uint32_t negative_idx = size;
+    for (uint32_t i = 0; i < t->nprobs; i++)                /* :169-188 */
+        if (t->probs[i] == -1) {
+            negative_idx--;
+            t->decode[negative_idx].symbol = (uint8_t)i;
+            t->decode[negative_idx].base_line = 0;
+            t->decode[negative_idx].num_bits = t->accuracy_log;
+        }
+    uint32_t position = 0;
+    for (uint32_t i = 0; i < t->nprobs; i++) {              /* :190-226 */
+        int32_t prob = t->probs[i];
+        for (int32_t j = 0; j < prob; j++) {
+            t->decode[position].symbol = (uint8_t)i;
+            position = fse_next_position(position, size);
+            while (position >= negative_idx) position = fse_next_position(position, size);
+        }
+    }
+    uint32_t counter[FSE_MAX_STORED_PROBS]; memset(counter, 0, sizeof counter);
+    for (uint32_t i = 0; i < negative_idx; i++) {           /* :231-255 */
+        uint8_t sym = t->decode[i].symbol;
+        fse_baseline_numbits(size, (uint32_t)t->probs[sym], counter[sym], &t->decode[i].base_line, &t->decode[i].num_bits);
+        counter[sym]++;
+    }
+    return 0;
+}
+/* :143-154 */
+static int fse_build_from_probabilities(fse_table* t, uint8_t acc_log, const int32_t* probs, uint32_t n) {
+    memcpy(t->probs, probs, n * sizeof(int32_t)); t->nprobs = n; t->accuracy_log = acc_log;
+    return fse_build_decoding_table(t);
+}
+/* :258-368.  *bytes_read receives ceil(bits/8). */
+static int fse_read_probabilities(fse_table* t, const uint8_t* src, size_t len, uint8_t max_log, size_t* bytes_read) {
+    fbr br; fbr_init(&br, src, len);
+    uint64_t v;
+    t->nprobs = 0;
+    if (fbr_get(&br, 4, &v)) return CZ_E_FSE_GETBITS;       /* :265-268 */
+    t->accuracy_log = (uint8_t)(5 + v);                     /* :270 */
+    if (t->accuracy_log > max_log) return CZ_E_FSE_ACC_LOG_TOO_BIG; /* :271 */
+    uint32_t sum = 1u << t->accuracy_log, counter = 0;
+    size_t nsyms = 0;                                       /* true length of symbol_probabilities */
+    while (counter < sum) {                                 /* :281-346 */
+        uint32_t max_remaining = sum - counter + 1;
+        unsigned bits_to_read = highest_bit_set(max_remaining);
+        if (fbr_get(&br, bits_to_read, &v)) return CZ_E_FSE_GETBITS;
+        uint64_t low_threshold = ((1ULL << bits_to_read) - 1) - max_remaining;
+        uint64_t mask = (1ULL << (bits_to_read - 1)) - 1;
+        uint64_t small = v & mask, value;
+        if (small < low_threshold) { fbr_return(&br, 1); value = small; }
+        else if (v > mask) value = v - low_threshold;
+        else value = v;
+        int32_t prob = (int32_t)value - 1;
+        if (nsyms < FSE_MAX_STORED_PROBS) t->probs[nsyms] = prob;
+        nsyms++;
+        if (prob != 0) counter += (prob > 0) ? (uint32_t)prob : 1u;
+        else {
+            for (;;) {                                      /* :322-340 */
+                if (fbr_get(&br, 2, &v)) return CZ_E_FSE_GETBITS;
+                for (uint64_t k = 0; k < v; k++) { if (nsyms < FSE_MAX_STORED_PROBS) t->probs[nsyms] = 0; nsyms++; }
+                if (v != 3) break;
+            }
+        }
+    }
+    if (counter != sum) return CZ_E_FSE_PROB_MISMATCH;      /* :352 */
+    if (nsyms > 256) return CZ_E_FSE_TOO_MANY_SYMBOLS;      /* :357 */
+    t->nprobs = (uint32_t)nsyms;
+    *bytes_read = (br.idx + 7) / 8;                         /* :361-365 */
+    return 0;
+}
+/* :132-141 */
+static int fse_build_decoder(fse_table* t, const uint8_t* src, size_t len, uint8_t max_log, size_t* bytes_read) {
+    t->accuracy_log = 0;
+    int e = fse_read_probabilities(t, src, len, max_log, bytes_read);
+    if (e) return e;
+    return fse_build_decoding_table(t) ? CZ_E_INVALID_ARG : 0;
+}
+
+/* ------------------------------------------------------------- Huffman table */
+/* src/huff0/huff0_decoder.cairo:17-25,56-59 */
+typedef struct { uint8_t symbol, num_bits; } huf_entry;
+typedef struct {
+    huf_entry decode[1 << 11];
+    uint8_t weights[260]; uint32_t nweights;
+    uint8_t max_num_bits;
+    fse_table fse;
+} huf_table;
+
+static void huf_reset(huf_table* h) { h->max_num_bits = 0; h->nweights = 0; fse_reset(&h->fse); } /* :139-147 */
+
+/* :159-319.  Returns bytes consumed through *bytes_used. */
+static int huf_read_weights(huf_table* h, const uint8_t* src, size_t len, uint32_t* bytes_used) {
+    if (len == 0) return CZ_E_HUF_SOURCE_EMPTY;             /* :162 */
+    uint8_t header = src[0];
+    uint32_t bits_read = 8;
+    if (header <= 127) {                                    /* :168-277 FSE-compressed weights */
+        const uint8_t* fs = src + 1; size_t fl = len - 1;
+        if (header > fl) return CZ_E_HUF_NOT_ENOUGH_BYTES_FOR_WEIGHTS;           /* :171 */
+        size_t fse_bytes;
+        int e = fse_build_decoder(&h->fse, fs, fl, 100, &fse_bytes);             /* :176 (max_log 100) */
+        if (e) return e;
+        if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES;         /* :181 */
+        size_t clen = header - fse_bytes;                                        /* :191 */
+        rbr br; rbr_init(&br, fs + fse_bytes, clen);                             /* :193-202 */
+        bits_read += (uint32_t)(fse_bytes + clen) * 8;                           /* :204 */
+        if (rbr_skip_padding(&br)) return CZ_E_HUF_EXTRA_PADDING;                /* :206-225 */
+        uint64_t v;
+        fse_entry d1, d2;
+        const fse_table* t = &h->fse;
+        rbr_get(&br, t->accuracy_log, &v); d1 = t->decode[v];                    /* :227 init_state */
+        rbr_get(&br, t->accuracy_log, &v); d2 = t->decode[v];                    /* :233 */
+        h->nweights = 0;
+        for (;;) {                                                               /* :242-274 */
+            if (h->nweights < 260) h->weights[h->nweights] = d1.symbol; h->nweights++;
+            rbr_get(&br, d1.num_bits, &v); d1 = t->decode[d1.base_line + v];
+            if (rbr_bits_remaining(&br) <= -1) {
+                if (h->nweights < 260) h->weights[h->nweights] = d2.symbol; h->nweights++;
+                break;
+            }
+            if (h->nweights < 260) h->weights[h->nweights] = d2.symbol; h->nweights++;
+            rbr_get(&br, d2.num_bits, &v); d2 = t->decode[d2.base_line + v];
+            if (rbr_bits_remaining(&br) <= -1) {
+                if (h->nweights < 260) h->weights[h->nweights] = d1.symbol; h->nweights++;
+                break;
+            }
+            if (h->nweights > 255) return CZ_E_HUF_TOO_MANY_WEIGHTS;             /* :271 */
+        }
+        /* 256 or 257 weights escape the :271 check but panic at :458 (u8 overflow of the
+           implied last symbol) — reported as the same error. */
+        if (h->nweights > 255) return CZ_E_HUF_TOO_MANY_WEIGHTS;
+    } else {                                                /* :278-311 direct 4-bit weights */
+        const uint8_t* wr = src + 1; size_t wl = len - 1;
+        uint32_t n = (uint32_t)header - 127;
+        size_t need = (n + 1) / 2;
+        if (wl < need) return CZ_E_HUF_NOT_ENOUGH_BYTES_IN_SOURCE;               /* :289 */
+        for (uint32_t idx = 0; idx < n; idx++) {
+            int low;
+            if (g_d1_reference_nibbles) low = ((idx | 1) == 1);                  /* literal :302 */
+            else low = (idx & 1);                                               /* zstd format (D1) */
+            h->weights[idx] = low ? (wr[idx / 2] & 0xF) : (wr[idx / 2] >> 4);
+            bits_read += 4;
+        }
+        h->nweights = n;
+    }
+    *bytes_used = (bits_read + 7) / 8;                      /* :313-318 */
+    return 0;
+}
+/* :321-470 */
+static int huf_build_table_from_weights(huf_table* h) {
+    uint8_t bits[260];
+    uint32_t n = h->nweights, weight_sum = 0;
+    for (uint32_t i = 0; i < n; i++) {                      /* :328-346 */
+        uint8_t w = h->weights[i];
+        if (w > 11) return CZ_E_HUF_WEIGHT_TOO_BIG;
+        weight_sum += w ? (1u << (w - 1)) : 0;
+    }
+    if (weight_sum == 0) return CZ_E_HUF_MISSING_WEIGHTS;   /* :351 */
+    uint32_t max_bits = highest_bit_set(weight_sum);        /* :355 */
+    uint32_t left_over = (1u << max_bits) - weight_sum;     /* :357 */
+    if (!is_power_of_two(left_over)) return CZ_E_HUF_LEFTOVER_NOT_POW2; /* :359 */
+    uint32_t last_weight = highest_bit_set(left_over);      /* :363 */
+    for (uint32_t s = 0; s < n; s++) bits[s] = h->weights[s] ? (uint8_t)(max_bits + 1 - h->weights[s]) : 0; /* :365-380 */
+    bits[n] = (uint8_t)(max_bits + 1 - last_weight);        /* :382 */
+    h->max_num_bits = (uint8_t)max_bits;                    /* :383 */
+    if (max_bits > 11) return CZ_E_HUF_MAX_BITS_TOO_HIGH;   /* :385 */
+    uint32_t bit_ranks[13]; memset(bit_ranks, 0, sizeof bit_ranks);
+    for (uint32_t i = 0; i <= n; i++) bit_ranks[bits[i]]++; /* :389-402 */
+    uint32_t rank_idx[13]; memset(rank_idx, 0, sizeof rank_idx);
+    rank_idx[max_bits] = 0;                                 /* :413 */
+    for (uint32_t b = max_bits; b > 0; b--)                 /* :414-429 */
+        rank_idx[b - 1] = rank_idx[b] + bit_ranks[b] * (1u << (max_bits - b));
+    /* :431 assert(rank_indexes[0] == decode.len()) holds by construction */
+    for (uint32_t s = 0; s <= n; s++) {                     /* :433-467 */
+        uint8_t b = bits[s];
+        if (!b) continue;
+        uint32_t base = rank_idx[b], len = 1u << (max_bits - b);
+        rank_idx[b] += len;
+        for (uint32_t k = 0; k < len; k++) { h->decode[base + k].symbol = (uint8_t)s; h->decode[base + k].num_bits = b; }
+    }
+    return 0;
+}
+/* :149-157 */
+static int huf_build_decoder(huf_table* h, const uint8_t* src, size_t len, uint32_t* bytes_used) {
+    int e = huf_read_weights(h, src, len, bytes_used);
+    if (e) return e;
+    return huf_build_table_from_weights(h);
+}
+
+/* ----------------------------------------------------- section header parsers */
+typedef struct { uint8_t type; uint32_t regenerated_size, compressed_size; uint8_t num_streams, has_compressed; } lit_section;
+/* src/blocks/literals_section.cairo:81-175.  Returns header length through *hdr. */
+static int lit_parse_header(lit_section* s, const uint8_t* raw, size_t len, uint8_t* hdr) {
+    if (len == 0) return CZ_E_LS_GETBITS;                   /* :84-90 get_bits(2) on empty */
+    uint8_t b0 = raw[0];
+    s->type = b0 & 3;                                       /* :91, :177-191 */
+    uint8_t fmt = (b0 >> 2) & 3;                            /* :92 */
+    uint8_t need;                                           /* :47-79 header_bytes_needed */
+    if (s->type <= 1) need = (fmt == 0 || fmt == 2) ? 1 : (fmt == 1 ? 2 : 3);
+    else need = (fmt <= 1) ? 3 : (fmt == 2 ? 4 : 5);
+    if (len < need) return CZ_E_LS_NOT_ENOUGH_BYTES;        /* :100 */
+    s->has_compressed = 0; s->compressed_size = 0; s->num_streams = 0;
+    if (s->type <= 1) {                                     /* :104-121 Raw / RLE */
+        if (fmt == 0 || fmt == 2) s->regenerated_size = b0 >> 3;
+        else if (fmt == 1) s->regenerated_size = (b0 >> 4) + ((uint32_t)raw[1] << 4);
+        else s->regenerated_size = (b0 >> 4) + ((uint32_t)raw[1] << 4) + ((uint32_t)raw[2] << 12);
+    } else {                                                /* :122-171 Compressed / Treeless */
+        s->num_streams = fmt == 0 ? 1 : 4; s->has_compressed = 1;
+        if (fmt <= 1) {
+            s->regenerated_size = (b0 >> 4) + (((uint32_t)raw[1] & 0x3f) << 4);
+            s->compressed_size = (raw[1] >> 6) + ((uint32_t)raw[2] << 2);
+        } else if (fmt == 2) {
+            s->regenerated_size = (b0 >> 4) + ((uint32_t)raw[1] << 4) + (((uint32_t)raw[2] & 3) << 12);
+            s->compressed_size = (raw[2] >> 2) + ((uint32_t)raw[3] << 6);
+        } else {
+            s->regenerated_size = (b0 >> 4) + ((uint32_t)raw[1] << 4) + (((uint32_t)raw[2] & 0x3f) << 12);
+            s->compressed_size = (raw[2] >> 6) + ((uint32_t)raw[3] << 2) + ((uint32_t)raw[4] << 10);
+        }
+    }
+    *hdr = need; return 0;
+}
+typedef struct { uint32_t num_sequences; uint8_t modes, has_modes; } seq_header;
+/* src/blocks/sequence_section.cairo:77-114 */
+static int seq_parse_header(seq_header* h, const uint8_t* src, size_t len, uint8_t* hdr) {
+    h->num_sequences = 0; h->has_modes = 0; h->modes = 0;
+    if (len == 0) return CZ_E_SH_NOT_ENOUGH_BYTES;          /* :81 */
+    uint8_t b0 = src[0], n = 0;
+    if (b0 == 0) { *hdr = 1; return 0; }                    /* :85-87 */
+    if (b0 <= 127) { if (len < 2) return CZ_E_SH_NOT_ENOUGH_BYTES; h->num_sequences = b0; n = 1; }
+    else if (b0 <= 254) { if (len < 3) return CZ_E_SH_NOT_ENOUGH_BYTES; h->num_sequences = ((uint32_t)(b0 - 128) << 8) + src[1]; n = 2; }
+    else { if (len < 4) return CZ_E_SH_NOT_ENOUGH_BYTES; h->num_sequences = src[1] + ((uint32_t)src[2] << 8) + 0x7F00; n = 3; }
+    h->modes = src[n]; h->has_modes = 1;                    /* :110 */
+    *hdr = (uint8_t)(n + 1); return 0;
+}
+
+/* ------------------------------------------------------------------- scratch */
+typedef struct { uint32_t ll, ml, of; } sequence;           /* sequence_section.cairo:12-16 */
+
+/* src/decoding/scratch.cairo:11-19 + decode_buffer.cairo:9-15 */
+typedef struct {
+    huf_table huf;
+    fse_table ll, ml, of; int ll_rle, ml_rle, of_rle;       /* scratch.cairo:87-94; -1 = None */
+    uint32_t offset_hist[3];
+    /* DecodeBuffer: bytes [buf_head, buf_len) of `buf` are the live ring content */
+    uint8_t* buf; size_t buf_cap; size_t buf_len; size_t buf_head; int buf_owned;
+    uint64_t total_output_counter; size_t window_size;
+    xxh64_state hash;
+    /* literals + sequences of the current block */
+    uint8_t* lit; size_t lit_cap; size_t lit_len;
+    sequence* seqs; size_t seq_cap; size_t nseq;
+} scratch;
+
+static void scratch_init(scratch* s) { memset(s, 0, sizeof *s); s->buf_owned = 1; }
+static void scratch_free(scratch* s) {
+    fse_free(&s->huf.fse); fse_free(&s->ll); fse_free(&s->ml); fse_free(&s->of);
+    if (s->buf_owned) free(s->buf); free(s->lit); free(s->seqs);
+}
+/* scratch.cairo:23-40 (new) and :42-58 (reset) */
+static void scratch_reset(scratch* s, size_t window_size) {
+    s->offset_hist[0] = 1; s->offset_hist[1] = 4; s->offset_hist[2] = 8;
+    s->lit_len = 0; s->nseq = 0;
+    s->buf_len = 0; s->buf_head = 0; s->total_output_counter = 0; s->window_size = window_size;
+    xxh64_reset(&s->hash, 0);                               /* decode_buffer.cairo:31,41 */
+    fse_reset(&s->ll); fse_reset(&s->ml); fse_reset(&s->of);
+    s->ll_rle = s->ml_rle = s->of_rle = -1;
+    huf_reset(&s->huf);
+}
+static inline size_t buffer_len(const scratch* s) { return s->buf_len - s->buf_head; } /* decode_buffer.cairo:44 */
+static int buffer_reserve(scratch* s, size_t extra) {
+    if (s->buf_len + extra <= s->buf_cap) return 0;
+    if (!s->buf_owned) return CZ_E_OUTPUT_TOO_SMALL;
+    size_t nc = s->buf_cap ? s->buf_cap : 4096;
+    while (nc < s->buf_len + extra) nc *= 2;
+    uint8_t* p = (uint8_t*)realloc(s->buf, nc);
+    if (!p) return CZ_E_INVALID_ARG;
+    s->buf = p; s->buf_cap = nc; return 0;
+}
+/* decode_buffer.cairo:57-60 */
+static int buffer_push(scratch* s, const uint8_t* p, size_t n) {
+    int e = buffer_reserve(s, n); if (e) return e;
+    memcpy(s->buf + s->buf_len, p, n); s->buf_len += n; s->total_output_counter += n; return 0;
+}
+static int buffer_fill(scratch* s, uint8_t byte, size_t n) {            /* block_decoder.cairo:110-120 */
+    int e = buffer_reserve(s, n); if (e) return e;
+    memset(s->buf + s->buf_len, byte, n); s->buf_len += n; s->total_output_counter += n; return 0;
+}
+/* decode_buffer.cairo:62-133 (dictionary is always empty: SURVEY.md §2 row 13) */
+static int buffer_repeat(scratch* s, size_t offset, size_t match_length) {
+    if (offset > buffer_len(s)) {                           /* :65 */
+        if (s->total_output_counter <= (uint64_t)s->window_size) return CZ_E_EXEC_NOT_ENOUGH_DICT; /* :66-75: bytes_from_dict>0 > dict len 0 */
+        return CZ_E_EXEC_OFFSET_TOO_BIG;                    /* :92 */
+    }
+    int e = buffer_reserve(s, match_length); if (e) return e;
+    uint8_t* d = s->buf + s->buf_len; const uint8_t* src = d - offset;
+    if (offset >= match_length) memcpy(d, src, match_length);           /* :121-127 */
+    else for (size_t i = 0; i < match_length; i++) d[i] = src[i];       /* :101-120 == forward byte copy */
+    s->buf_len += match_length; s->total_output_counter += match_length;             /* :129 */
+    return 0;
+}
+
+/* -------------------------------------------------------------------- literals */
+static int lit_reserve(scratch* s, size_t n) {
+    if (s->lit_cap >= n) return 0;
+    uint8_t* p = (uint8_t*)realloc(s->lit, n + 8); if (!p) return 1;
+    s->lit = p; s->lit_cap = n; return 0;
+}
+/* literals_section_decoder.cairo:183-243 (_process_stream) and :120-167 (single stream;
+   `check_end` = 0 there: the 1-stream arm has no BitstreamReadMismatch test). */
+static int huf_process_stream(scratch* s, const uint8_t* src, size_t len, int check_end, size_t cap_total) {
+    const huf_table* h = &s->huf;
+    rbr br; rbr_init(&br, src, len);
+    if (rbr_skip_padding(&br)) return CZ_E_LIT_EXTRA_PADDING;           /* :190-207 */
+    const int64_t mb = h->max_num_bits;
+    uint64_t state, v;
+    rbr_get(&br, (unsigned)mb, &state);                                 /* :209 init_state, huff0:81-91 */
+    const uint64_t mask = ((uint64_t)1 << mb) - 1;
+    while (rbr_bits_remaining(&br) > -mb) {                             /* :216-228 */
+        if (s->lit_len >= cap_total) { if (lit_reserve(s, cap_total * 2 + 64)) return CZ_E_INVALID_ARG; cap_total = s->lit_cap; }
+        huf_entry e = h->decode[state];
+        s->lit[s->lit_len++] = e.symbol;                                /* huff0:75-79 */
+        rbr_get(&br, e.num_bits, &v);                                   /* huff0:93-106 */
+        state = ((state << e.num_bits) & mask) | v;
+    }
+    if (check_end && rbr_bits_remaining(&br) != -mb) return CZ_E_LIT_BITSTREAM_MISMATCH; /* :234-241 */
+    return 0;
+}
+/* literals_section_decoder.cairo:58-181 */
+static int decompress_literals(scratch* s, const lit_section* sec, const uint8_t* src, size_t len, uint32_t* bytes_read) {
+    /* :64-68: source = source.slice(0, compressed_size); caller guarantees len >= compressed_size */
+    len = sec->compressed_size;
+    uint32_t br_ = 0;
+    if (sec->type == 2) {                                   /* Compressed :74-81 */
+        int e = huf_build_decoder(&s->huf, src, len, &br_); if (e) return e;
+    } else {                                                /* Treeless :82-86 */
+        if (s->huf.max_num_bits == 0) return CZ_E_LIT_UNINIT_HUF_TABLE;
+    }
+    if (br_ > len) return CZ_E_BLOCK_TRUNCATED;             /* (panic) source.slice(bytes_read, len) :89 */
+    src += br_; len -= br_;
+    s->lit_len = 0;
+    if (lit_reserve(s, (size_t)sec->regenerated_size + 64)) return CZ_E_INVALID_ARG;
+    if (sec->num_streams == 4) {                            /* :91-117 */
+        if (len < 6) return CZ_E_LIT_MISSING_JUMP_HEADER;
+        size_t j1 = src[0] + ((size_t)src[1] << 8);
+        size_t j2 = j1 + src[2] + ((size_t)src[3] << 8);
+        size_t j3 = j2 + src[4] + ((size_t)src[5] << 8);
+        br_ += 6; src += 6; len -= 6;
+        if (len < j3) return CZ_E_LIT_MISSING_BYTES;        /* :101 */
+        int e;
+        if ((e = huf_process_stream(s, src, j1, 1, s->lit_cap))) return e;           /* :112-115 */
+        if ((e = huf_process_stream(s, src + j1, j2 - j1, 1, s->lit_cap))) return e;
+        if ((e = huf_process_stream(s, src + j2, j3 - j2, 1, s->lit_cap))) return e;
+        if ((e = huf_process_stream(s, src + j3, len - j3, 1, s->lit_cap))) return e;
+        br_ += (uint32_t)len;
+    } else {                                                /* :118-170 */
+        int e = huf_process_stream(s, src, len, 0, s->lit_cap); if (e) return e;
+        br_ += (uint32_t)len;
+    }
+    if (s->lit_len != sec->regenerated_size) return CZ_E_LIT_COUNT_MISMATCH;         /* :172 */
+    *bytes_read = br_; return 0;
+}
+/* literals_section_decoder.cairo:32-56 */
+static int decode_literals(scratch* s, const lit_section* sec, const uint8_t* src, size_t len, uint32_t* bytes_read) {
+    switch (sec->type) {
+    case 0:                                                 /* Raw :39-42 */
+        if (lit_reserve(s, sec->regenerated_size + 8)) return CZ_E_INVALID_ARG;
+        memcpy(s->lit, src, sec->regenerated_size); s->lit_len = sec->regenerated_size;
+        *bytes_read = sec->regenerated_size; return 0;
+    case 1:                                                 /* RLE :43-46 */
+        if (lit_reserve(s, sec->regenerated_size + 8)) return CZ_E_INVALID_ARG;
+        memset(s->lit, src[0], sec->regenerated_size); s->lit_len = sec->regenerated_size;
+        *bytes_read = 1; return 0;
+    default:
+        return decompress_literals(s, sec, src, len, bytes_read);
+    }
+}
+
+/* ------------------------------------------------------------------- sequences */
+/* sequence_section_decoder.cairo:299-345 / :347-395 */
+static const uint32_t LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+static const uint8_t LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+static const uint32_t ML_BASE[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+static const uint8_t ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+static inline void lookup_ll_code(uint8_t c, uint32_t* v, unsigned* nb) { if (c < 36) { *v = LL_BASE[c]; *nb = LL_BITS[c]; } else { *v = 0; *nb = 255; } }
+static inline void lookup_ml_code(uint8_t c, uint32_t* v, unsigned* nb) { if (c < 53) { *v = ML_BASE[c]; *nb = ML_BITS[c]; } else { *v = 0; *nb = 255; } }
+
+/* predefined distributions: sequence_section_decoder.cairo:418-455, :494-524, :562-616 */
+static const int32_t LL_DEFAULT[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+static const int32_t OF_DEFAULT[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+static const int32_t ML_DEFAULT[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+
+/* one arm of maybe_update_fse_tables, sequence_section_decoder.cairo:405-647 */
+static int update_one_table(fse_table* t, int* rle, unsigned mode, const uint8_t* src, size_t len, size_t* used,
+                            uint8_t def_log, const int32_t* def_probs, uint32_t def_n, uint8_t max_log, int missing_err) {
+    *used = 0;
+    switch (mode) {
+    case 0: if (fse_build_from_probabilities(t, def_log, def_probs, def_n)) return CZ_E_INVALID_ARG; *rle = -1; return 0;
+    case 1: if (len == 0) return missing_err; *used = 1; *rle = src[0]; return 0;
+    case 2: { int e = fse_build_decoder(t, src, len, max_log, used); if (e) return e; *rle = -1; return 0; }
+    default: return 0;                                      /* Repeat: keep table or RLE symbol */
+    }
+}
+/* fse_decoder.cairo:78-91 / :93-103 */
+static inline int fse_init_state(const fse_table* t, rbr* br, fse_entry* st) {
+    if (t->accuracy_log == 0) return CZ_E_SEQ_TABLE_UNINIT;
+    uint64_t v; rbr_get(br, t->accuracy_log, &v); *st = t->decode[v]; return 0;
+}
+static inline void fse_update_state(const fse_table* t, rbr* br, fse_entry* st) {
+    uint64_t v; rbr_get(br, st->num_bits, &v); *st = t->decode[st->base_line + v];
+}
+/* sequence_section_decoder.cairo:35-71, :73-195, :197-297 (the RLE and non-RLE loops
+   differ only in skipping init/update for RLE'd tables, so they are one loop here). */
+static int decode_sequences(scratch* s, const seq_header* h, const uint8_t* src, size_t len) {
+    size_t used, off = 0; int e;
+    unsigned m = h->modes;                                  /* sequence_section.cairo:47-57 */
+    if ((e = update_one_table(&s->ll, &s->ll_rle, (m >> 6) & 3, src, len, &used, 6, LL_DEFAULT, 36, 9, CZ_E_SEQ_MISSING_RLE_BYTE_LL))) return e;
+    off += used; if (off > len) return CZ_E_BLOCK_TRUNCATED;
+    if ((e = update_one_table(&s->of, &s->of_rle, (m >> 4) & 3, src + off, len - off, &used, 5, OF_DEFAULT, 29, 8, CZ_E_SEQ_MISSING_RLE_BYTE_OF))) return e;
+    off += used; if (off > len) return CZ_E_BLOCK_TRUNCATED;
+    if ((e = update_one_table(&s->ml, &s->ml_rle, (m >> 2) & 3, src + off, len - off, &used, 6, ML_DEFAULT, 53, 9, CZ_E_SEQ_MISSING_RLE_BYTE_ML))) return e;
+    off += used; if (off > len) return CZ_E_BLOCK_TRUNCATED;
+
+    rbr br; rbr_init(&br, src + off, len - off);            /* :42-44 */
+    if (rbr_skip_padding(&br)) return CZ_E_SEQ_EXTRA_PADDING; /* :46-64 */
+
+    fse_entry ll = {0,0,0}, ml = {0,0,0}, of = {0,0,0};     /* FSEDecoderTrait::new, fse_decoder.cairo:65-72 */
+    if (s->ll.accuracy_log && s->ll.decode) ll = s->ll.decode[0];
+    if (s->ml.accuracy_log && s->ml.decode) ml = s->ml.decode[0];
+    if (s->of.accuracy_log && s->of.decode) of = s->of.decode[0];
+    /* init order LL, OF, ML (:207-218 / :83-100) */
+    if (s->ll_rle < 0 && (e = fse_init_state(&s->ll, &br, &ll))) return e;
+    if (s->of_rle < 0 && (e = fse_init_state(&s->of, &br, &of))) return e;
+    if (s->ml_rle < 0 && (e = fse_init_state(&s->ml, &br, &ml))) return e;
+
+    uint32_t n = h->num_sequences;
+    if (s->seq_cap < n) { sequence* p = (sequence*)realloc(s->seqs, (size_t)n * sizeof(sequence)); if (!p) return CZ_E_INVALID_ARG; s->seqs = p; s->seq_cap = n; }
+    s->nseq = 0;
+    for (uint32_t i = 0; i < n; i++) {                      /* :223-286 */
+        uint8_t ll_code = s->ll_rle >= 0 ? (uint8_t)s->ll_rle : ll.symbol;
+        uint8_t ml_code = s->ml_rle >= 0 ? (uint8_t)s->ml_rle : ml.symbol;
+        uint8_t of_code = s->of_rle >= 0 ? (uint8_t)s->of_rle : of.symbol;
+        uint32_t ll_v, ml_v; unsigned ll_nb, ml_nb;
+        lookup_ll_code(ll_code, &ll_v, &ll_nb); lookup_ml_code(ml_code, &ml_v, &ml_nb);
+        if (of_code >= 32) return CZ_E_SEQ_UNSUPPORTED_OFFSET;          /* :235 */
+        uint64_t ob, mb, lb;                                /* get_bits_triple(of, ml, ll) :239; bit_reader_reverse:175-253 */
+        if (rbr_get(&br, of_code, &ob) || rbr_get(&br, ml_nb, &mb) || rbr_get(&br, ll_nb, &lb)) return CZ_E_SEQ_TOO_MANY_BITS;
+        uint32_t offset = (uint32_t)ob + (1u << of_code);   /* :243 */
+        s->seqs[s->nseq].ll = ll_v + (uint32_t)lb; s->seqs[s->nseq].ml = ml_v + (uint32_t)mb; s->seqs[s->nseq].of = offset; s->nseq++;
+        if (s->nseq < n) {                                  /* :258-277 update order LL, ML, OF */
+            if (s->ll_rle < 0) fse_update_state(&s->ll, &br, &ll);
+            if (s->ml_rle < 0) fse_update_state(&s->ml, &br, &ml);
+            if (s->of_rle < 0) fse_update_state(&s->of, &br, &of);
+        }
+        if (rbr_bits_remaining(&br) < 0) return CZ_E_SEQ_NOT_ENOUGH_BYTES;          /* :281 */
+    }
+    if (rbr_bits_remaining(&br) > 0) return CZ_E_SEQ_EXTRA_BITS;        /* :292 */
+    return 0;
+}
+
+/* sequence_execution.cairo:85-129 */
+static inline uint32_t do_offset_history(uint32_t ov, uint32_t ll, uint32_t* h) {
+    uint32_t actual;
+    if (ll > 0) actual = ov == 1 ? h[0] : ov == 2 ? h[1] : ov == 3 ? h[2] : ov - 3;
+    else        actual = ov == 1 ? h[1] : ov == 2 ? h[2] : ov == 3 ? h[0] - 1 : ov - 3;
+    if (ll > 0) {
+        if (ov == 1) { /* unchanged */ }
+        else if (ov == 2) { h[1] = h[0]; h[0] = actual; }
+        else { h[2] = h[1]; h[1] = h[0]; h[0] = actual; }
+    } else {
+        if (ov == 1) { h[1] = h[0]; h[0] = actual; }
+        else { h[2] = h[1]; h[1] = h[0]; h[0] = actual; }
+    }
+    return actual;
+}
+/* sequence_execution.cairo:12-83.  NB: the reference computes the new history BEFORE the
+   ZeroOffset test but only stores it after (:43-51); on error the frame is dead either way. */
+static int execute_sequences(scratch* s) {
+    size_t lit_counter = 0;
+    for (size_t i = 0; i < s->nseq; i++) {
+        sequence q = s->seqs[i];
+        if (q.ll > 0) {                                     /* :28-41 */
+            size_t high = lit_counter + q.ll;
+            if (high > s->lit_len) return CZ_E_EXEC_NOT_ENOUGH_LITERALS;
+            int e = buffer_push(s, s->lit + lit_counter, q.ll); if (e) return e;
+            lit_counter = high;
+        }
+        uint32_t hist[3] = { s->offset_hist[0], s->offset_hist[1], s->offset_hist[2] };
+        uint32_t actual = do_offset_history(q.of, q.ll, hist);
+        if (actual == 0) return CZ_E_EXEC_ZERO_OFFSET;      /* :47 */
+        memcpy(s->offset_hist, hist, sizeof hist);
+        if (q.ml > 0) { int e = buffer_repeat(s, actual, q.ml); if (e) return e; }   /* :53-60 */
+    }
+    if (lit_counter < s->lit_len) {                         /* :72-78 */
+        int e = buffer_push(s, s->lit + lit_counter, s->lit_len - lit_counter); if (e) return e;
+    }
+    return 0;
+}
+
+/* ----------------------------------------------------------------------- blocks */
+typedef struct { uint8_t last_block, block_type; uint32_t decompressed_size, content_size; } block_header; /* blocks/block.cairo:10-15 */
+/* block_decoder.cairo:237-321 */
+static int read_block_header(const uint8_t* p, size_t len, block_header* h) {
+    if (len < 3) return CZ_E_BH_TRUNCATED;                  /* (panic) :240 */
+    uint32_t a = p[0], b = p[1], c = p[2];
+    uint8_t t = (a >> 1) & 3;                               /* :289-304 */
+    if (t == 3) return CZ_E_BH_RESERVED;                    /* :248 */
+    uint32_t size = (a >> 3) | (b << 5) | (c << 13);        /* :315-321 */
+    if (size > 128 * 1024) return CZ_E_BH_SIZE_TOO_LARGE;   /* :306-313 */
+    h->block_type = t; h->last_block = a & 1;               /* :284-287 */
+    h->decompressed_size = (t == 2) ? 0 : size;             /* :256-261 */
+    h->content_size = (t == 1) ? 1 : size;                  /* :262-267 */
+    return 0;
+}
+/* block_decoder.cairo:139-235 */
+static int decompress_block(scratch* s, const uint8_t* raw, size_t len) {
+    lit_section sec; uint8_t lh; int e;
+    if ((e = lit_parse_header(&sec, raw, len, &lh))) return e;          /* :150-156 */
+    raw += lh; len -= lh;
+    size_t upper = sec.has_compressed ? sec.compressed_size : (sec.type == 1 ? 1 : sec.regenerated_size); /* :160-172 */
+    if (len < upper) return CZ_E_MALFORMED_SECTION_HEADER;  /* :174 */
+    uint32_t used;
+    if ((e = decode_literals(s, &sec, raw, upper, &used))) return e;    /* :184-190 */
+    raw += upper; len -= upper;                             /* :196 (assert :194 holds by construction) */
+    seq_header sh; uint8_t shl;
+    if ((e = seq_parse_header(&sh, raw, len, &shl))) return e;          /* :198-204 */
+    if (sh.has_modes == 0 && sh.num_sequences == 0) { /* b0==0 */ }
+    raw += shl; len -= shl;
+    if (sh.num_sequences != 0) {                            /* :216-228 */
+        if ((e = decode_sequences(s, &sh, raw, len))) return e;
+        return execute_sequences(s);
+    }
+    s->nseq = 0;
+    return buffer_push(s, s->lit, s->lit_len);              /* :229-232 */
+}
+/* block_decoder.cairo:77-137.  *consumed = body bytes taken from source. */
+static int decode_block_content(scratch* s, const block_header* h, const uint8_t* src, size_t len, uint64_t* consumed) {
+    switch (h->block_type) {
+    case 0:                                                 /* Raw :97-103 */
+        if (len < h->decompressed_size) return CZ_E_BLOCK_TRUNCATED;
+        *consumed = h->decompressed_size; return buffer_push(s, src, h->decompressed_size);
+    case 1:                                                 /* RLE :104-123 */
+        if (len < 1) return CZ_E_BLOCK_TRUNCATED;
+        *consumed = 1; return buffer_fill(s, src[0], h->decompressed_size);
+    case 2:                                                 /* Compressed :124-134 */
+        if (len < h->content_size) return CZ_E_BLOCK_TRUNCATED;         /* (panic) :145 */
+        *consumed = h->content_size; return decompress_block(s, src, h->content_size);
+    default: return CZ_E_BH_RESERVED;
+    }
+}
+
+/* ------------------------------------------------------------------ frame header */
+typedef struct { uint8_t descriptor, window_descriptor; uint32_t dict_id; uint8_t has_dict_id; uint64_t frame_content_size; } frame_header;
+/* frame.cairo:152-284.  detail[0..1] receive (magic, skip_size) for SkipFrame / BadMagic. */
+static int read_frame_header(const uint8_t* p, size_t len, frame_header* fh, uint8_t* hdr_len, uint64_t* detail) {
+    size_t i = 0;
+    if (len < 4) return CZ_E_FH_MAGIC_READ;                 /* :155-158 */
+    uint32_t magic = rd32(p); i = 4;
+    if (magic >= 0x184D2A50 && magic <= 0x184D2A5F) {       /* :160-166 */
+        if (len < 8) return CZ_E_FH_DESCRIPTOR_READ;
+        if (detail) { detail[0] = magic; detail[1] = rd32(p + 4); }
+        return CZ_E_FH_SKIP_FRAME;
+    }
+    if (magic != 0xFD2FB528u) { if (detail) detail[0] = magic; return CZ_E_FH_BAD_MAGIC; } /* :168 */
+    if (len < i + 1) return CZ_E_FH_DESCRIPTOR_READ;        /* :172-175 */
+    uint8_t d = p[i++];
+    memset(fh, 0, sizeof *fh); fh->descriptor = d;
+    int single = (d >> 5) & 1;                              /* :44-46 */
+    if (!single) { if (len < i + 1) return CZ_E_FH_WINDOW_DESC_READ; fh->window_descriptor = p[i++]; } /* :186-193 */
+    static const uint8_t did_bytes[4] = {0, 1, 2, 4};       /* :76-90 */
+    unsigned dl = did_bytes[d & 3];
+    if (dl) {                                               /* :202-231 */
+        if (len < i + dl) return CZ_E_FH_DICT_ID_READ;
+        uint32_t id = 0; for (unsigned k = 0; k < dl; k++) id |= (uint32_t)p[i + k] << (8 * k);
+        i += dl; if (id) { fh->dict_id = id; fh->has_dict_id = 1; }
+    }
+    unsigned flag = d >> 6, fl = flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8; /* :56-74 */
+    if (fl) {                                               /* :240-278; truncated FCS reports DictionaryIdReadError */
+        if (len < i + fl) return CZ_E_FH_DICT_ID_READ;
+        uint64_t f = 0; for (unsigned k = 0; k < fl; k++) f |= (uint64_t)p[i + k] << (8 * k);
+        i += fl; if (fl == 2) f += 256;
+        fh->frame_content_size = f;
+    }
+    *hdr_len = (uint8_t)i; return 0;
+}
+/* frame.cairo:106-129 */
+static int frame_window_size(const frame_header* fh, uint64_t* ws) {
+    if ((fh->descriptor >> 5) & 1) { *ws = fh->frame_content_size; return 0; }
+    uint64_t exp = fh->window_descriptor >> 3, mant = fh->window_descriptor & 7;
+    uint64_t base = 1ULL << (10 + exp), w = base + (base / 8) * mant;
+    if (w < 1024) return CZ_E_WINDOW_TOO_SMALL;
+    if (w >= 4123168604160ULL) return CZ_E_WINDOW_TOO_BIG;
+    *ws = w; return 0;
+}
+
+/* ----------------------------------------------------------------- frame decoder */
+/* frame_decoder.cairo:17-30 */
+typedef struct czo_frame_decoder {
+    frame_header fh; scratch sc;
+    int frame_finished; size_t block_counter; uint64_t bytes_read_counter;
+    uint32_t check_sum; int has_check_sum;
+    int initialised;
+} czo_frame_decoder;
+
+CZO_API czo_frame_decoder* czo_fd_create(void) {
+    czo_frame_decoder* d = (czo_frame_decoder*)calloc(1, sizeof *d);
+    if (d) scratch_init(&d->sc);
+    return d;
+}
+CZO_API void czo_fd_destroy(czo_frame_decoder* d) { if (d) { scratch_free(&d->sc); free(d); } }
+
+/* FrameDecoderStateTrait::new (:54-76) when is_reset==0, ::reset (:78-104) when 1 (adds the
+   100 MiB window cap, D4).  *consumed = header bytes. */
+static int fd_init_common(czo_frame_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail, int is_reset) {
+    uint8_t hl; int e;
+    if ((e = read_frame_header(src, len, &d->fh, &hl, detail))) return e;
+    uint64_t ws;
+    if ((e = frame_window_size(&d->fh, &ws))) return e;
+    if (is_reset && ws > 1024ULL * 1024 * 100) return CZ_E_WINDOW_SIZE_TOO_BIG;      /* :92 */
+    scratch_reset(&d->sc, (size_t)ws);
+    d->frame_finished = 0; d->block_counter = 0; d->bytes_read_counter = hl;
+    d->has_check_sum = 0; d->check_sum = 0; d->initialised = 1;
+    if (consumed) *consumed = hl;
+    return 0;
+}
+CZO_API int czo_fd_new(czo_frame_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init_common(d, src, len, consumed, detail, 0); }
+CZO_API int czo_fd_reset(czo_frame_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init_common(d, src, len, consumed, detail, 1); }
+
+CZO_API uint64_t czo_fd_content_size(const czo_frame_decoder* d) { return d->fh.frame_content_size; }          /* :125 */
+CZO_API int czo_fd_checksum_from_data(const czo_frame_decoder* d, uint32_t* v) { if (d->has_check_sum) *v = d->check_sum; return d->has_check_sum; } /* :129 */
+CZO_API uint32_t czo_fd_calculated_checksum(const czo_frame_decoder* d) { return (uint32_t)xxh64_digest(&d->sc.hash); } /* :133-138 */
+CZO_API uint64_t czo_fd_bytes_read_from_source(const czo_frame_decoder* d) { return d->bytes_read_counter; }    /* :140 */
+CZO_API int czo_fd_is_finished(const czo_frame_decoder* d) {                                                    /* :144-150 */
+    if ((d->fh.descriptor >> 2) & 1) return d->frame_finished && d->has_check_sum;
+    return d->frame_finished;
+}
+CZO_API size_t czo_fd_blocks_decoded(const czo_frame_decoder* d) { return d->block_counter; }                    /* :152 */
+
+/* strategy: 0 = All, 1 = UptoBlocks(n), 2 = UptoBytes(n)   (:33-37)
+   decode_blocks :156-222.  *consumed = source bytes taken by this call. */
+CZO_API int czo_fd_decode_blocks(czo_frame_decoder* d, const uint8_t* src, size_t len, int strategy, size_t n,
+                                 size_t* consumed, int* finished) {
+    size_t pos = 0; int e = 0;
+    size_t buffer_before = buffer_len(&d->sc), blocks_before = d->block_counter;
+    for (;;) {
+        block_header bh;
+        if ((e = read_block_header(src + pos, len - pos, &bh))) break;              /* :166-171 */
+        pos += 3; d->bytes_read_counter += 3;
+        uint64_t body;
+        if ((e = decode_block_content(&d->sc, &bh, src + pos, len - pos, &body))) break; /* :175-184 */
+        pos += (size_t)body; d->bytes_read_counter += body; d->block_counter++;
+        if (bh.last_block) {                                /* :189-200 */
+            d->frame_finished = 1;
+            if ((d->fh.descriptor >> 2) & 1) {
+                if (len - pos < 4) { e = CZ_E_CHECKSUM_TRUNCATED; break; }
+                d->check_sum = rd32(src + pos); d->has_check_sum = 1; pos += 4; d->bytes_read_counter += 4;
+            }
+            break;
+        }
+        if (strategy == 1 && d->block_counter - blocks_before >= n) break;          /* :204-208 */
+        if (strategy == 2 && buffer_len(&d->sc) - buffer_before >= n) break;        /* :209-213 */
+    }
+    if (consumed) *consumed = pos;
+    if (finished) *finished = d->frame_finished;
+    return e;
+}
+/* decode_buffer.cairo:168-186 drain_to + hash update */
+static size_t buffer_drain_to(scratch* s, size_t amount, uint8_t* dst, size_t cap) {
+    size_t n = buffer_len(s) < amount ? buffer_len(s) : amount;
+    if (n > cap) n = cap;
+    if (n == 0) return 0;
+    memcpy(dst, s->buf + s->buf_head, n);
+    xxh64_update(&s->hash, s->buf + s->buf_head, n);
+    s->buf_head += n;
+    return n;
+}
+/* can_collect :233-243 */
+CZO_API size_t czo_fd_can_collect(const czo_frame_decoder* d) {
+    size_t bl = buffer_len(&d->sc);
+    if (czo_fd_is_finished(d)) return bl;
+    return bl > d->sc.window_size ? bl - d->sc.window_size : 0;
+}
+/* collect :224-231 -> drain (:157-166) / drain_to_window_size (:147-155).
+   Returns 1 (Some) / 0 (None); *written = bytes moved. */
+CZO_API int czo_fd_collect(czo_frame_decoder* d, uint8_t* dst, size_t cap, size_t* written) {
+    *written = 0;
+    if (czo_fd_is_finished(d)) {
+        size_t bl = buffer_len(&d->sc);
+        if (bl > cap) return -1;
+        *written = buffer_drain_to(&d->sc, bl, dst, cap);
+        /* drain() clears the ring (:164) */
+        d->sc.buf_head = d->sc.buf_len;
+        return 1;
+    }
+    size_t bl = buffer_len(&d->sc);
+    if (bl > d->sc.window_size) {
+        size_t can = bl - d->sc.window_size;
+        if (can > cap) return -1;
+        *written = buffer_drain_to(&d->sc, can, dst, cap); return 1;
+    }
+    return 0;
+}
+/* read :328-334 -> decode_buffer read_all (:198-203) / read (:188-196) */
+CZO_API size_t czo_fd_read(czo_frame_decoder* d, uint8_t* dst, size_t cap) {
+    size_t bl = buffer_len(&d->sc), amount;
+    if (d->frame_finished) amount = bl;
+    else amount = bl > d->sc.window_size ? bl - d->sc.window_size : 0;
+    return buffer_drain_to(&d->sc, amount, dst, cap);
+}
+/* decode_from_to :245-326.  Returns status; (*read_len, *written) = (source bytes consumed,
+   target bytes produced). */
+CZO_API int czo_fd_decode_from_to(czo_frame_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap,
+                                  size_t* read_len, size_t* written) {
+    uint64_t start = d->bytes_read_counter; size_t pos = 0; int e = 0;
+    *read_len = 0; *written = 0;
+    if (!czo_fd_is_finished(d)) {
+        int cks = (d->fh.descriptor >> 2) & 1;
+        if (cks && d->frame_finished && !d->has_check_sum) {                        /* :255-267 */
+            if (len >= 4) { d->check_sum = rd32(src); d->has_check_sum = 1; d->bytes_read_counter += 4; }
+            *read_len = 4; return 0;                                                /* returns (4,0) even when <4 bytes (:266) */
+        }
+        for (;;) {                                                                  /* :269-314 */
+            if (len - pos < 3) break;
+            block_header bh;
+            if ((e = read_block_header(src + pos, len - pos, &bh))) break;
+            if (len - pos - 3 < bh.content_size) break;                             /* :282 (header bytes NOT counted) */
+            pos += 3; d->bytes_read_counter += 3;
+            uint64_t body;
+            if ((e = decode_block_content(&d->sc, &bh, src + pos, len - pos, &body))) break;
+            pos += (size_t)body; d->bytes_read_counter += body; d->block_counter++;
+            if (bh.last_block) {
+                d->frame_finished = 1;
+                if (cks && len - pos >= 4) { d->check_sum = rd32(src + pos); d->has_check_sum = 1; pos += 4; d->bytes_read_counter += 4; }
+                break;
+            }
+        }
+        if (e) return e;
+    }
+    *written = czo_fd_read(d, dst, cap);
+    *read_len = (size_t)(d->bytes_read_counter - start);
+    return 0;
+}
+
+/* ------------------------------------------------------------ one-shot helpers */
+/* The reference's end-to-end entry, src/tests/decoding.cairo:4-21 (_test_decode):
+   new -> decode_blocks(All) -> is_finished -> collect -> checksum getters.
+   Decodes straight into the caller's buffer (no intermediate ring copy) so that it can
+   serve as the timed CPU baseline.  info[0]=written, info[1]=consumed,
+   info[2]=checksum_from_data (or 0), info[3]=has_checksum, info[4]=blocks decoded,
+   info[5]=window_size, info[6]=frame_content_size. */
+static int decode_frame_with(czo_frame_decoder* d, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, uint64_t* info) {
+    size_t hl = 0, used = 0; int fin = 0; uint64_t detail[2] = {0, 0};
+    scratch* s = &d->sc;
+    uint8_t* saved_buf = s->buf; size_t saved_cap = s->buf_cap; int saved_owned = s->buf_owned;
+    int e = czo_fd_new(d, src, len, &hl, detail);
+    if (!e) {
+        s->buf = dst; s->buf_cap = cap; s->buf_owned = 0;
+        e = czo_fd_decode_blocks(d, src + hl, len - hl, 0, 0, &used, &fin);
+        if (!e && !czo_fd_is_finished(d)) e = CZ_E_NOT_FINISHED;
+    }
+    if (info) {
+        info[0] = s->buf_len; info[1] = hl + used; info[2] = d->check_sum; info[3] = (uint64_t)d->has_check_sum;
+        info[4] = d->block_counter; info[5] = s->window_size; info[6] = d->fh.frame_content_size;
+        if (e == CZ_E_FH_SKIP_FRAME || e == CZ_E_FH_BAD_MAGIC) { info[5] = detail[0]; info[6] = detail[1]; }
+    }
+    s->buf = saved_buf; s->buf_cap = saved_cap; s->buf_owned = saved_owned; s->buf_len = 0; s->buf_head = 0;
+    return e;
+}
+CZO_API int czo_decode_frame(const uint8_t* src, size_t len, uint8_t* dst, size_t cap, uint64_t* info) {
+    czo_frame_decoder* d = czo_fd_create(); if (!d) return CZ_E_INVALID_ARG;
+    int e = decode_frame_with(d, src, len, dst, cap, info);
+    czo_fd_destroy(d); return e;
+}
+
+/* Batch of independent frames (frames share nothing: frame_decoder.cairo:78-104), decoded
+   by `nthreads` host threads, one frame per task.  Mirrors the device batch entry
+   cz_decode_batch() argument for argument so tests can diff the two. */
+typedef struct {
+    const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
+    uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
+    uint64_t* out_len; int32_t* status; size_t n; volatile size_t* next;
+} batch_job;
+static void* batch_worker(void* arg) {
+    batch_job* j = (batch_job*)arg;
+    czo_frame_decoder* d = czo_fd_create();
+    for (;;) {
+        size_t i = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (i >= j->n) break;
+        uint64_t info[7];
+        int e = decode_frame_with(d, j->in_base + j->in_off[i], (size_t)j->in_len[i], j->out_base + j->out_off[i], (size_t)j->out_cap[i], info);
+        j->status[i] = e; j->out_len[i] = info[0];
+    }
+    czo_fd_destroy(d); return NULL;
+}
+CZO_API int czo_decode_batch(const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len, size_t n,
+                             uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap,
+                             uint64_t* out_len, int32_t* status, int nthreads) {
+    volatile size_t next = 0;
+    batch_job j = { in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status, n, &next };
+    if (nthreads <= 1) { batch_worker(&j); return 0; }
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, batch_worker, &j);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    return 0;
+}
+
+/* ------------------------------------------------------ hooks for the KAT tests */
+/* src/tests/bit_reader.cairo:12-50 / :54-92: read `n` bits with the reversed / forward reader */
+CZO_API int czo_kat_reverse_reads(const uint8_t* src, size_t len, const uint8_t* widths, size_t nreads, uint64_t* out, int64_t* remaining) {
+    rbr r; rbr_init(&r, src, len);
+    for (size_t i = 0; i < nreads; i++) if (rbr_get(&r, widths[i], &out[i])) return 1;
+    *remaining = rbr_bits_remaining(&r); return 0;
+}
+CZO_API int czo_kat_forward_reads(const uint8_t* src, size_t len, const uint8_t* widths, size_t nreads, uint64_t* out) {
+    fbr r; fbr_init(&r, src, len);
+    for (size_t i = 0; i < nreads; i++) if (fbr_get(&r, widths[i], &out[i])) return 1;
+    return 0;
+}
+/* sequence_section_decoder.cairo:649-739: build a predefined table (which: 0 LL, 1 OF, 2 ML)
+   or one from explicit probabilities, and dump (symbol, num_bits, base_line) triples. */
+CZO_API int czo_kat_fse_table(int which, uint8_t acc_log, const int32_t* probs, uint32_t nprobs,
+                              uint8_t* sym, uint8_t* nb, uint32_t* bl, uint32_t* size) {
+    fse_table t; memset(&t, 0, sizeof t); int e;
+    if (which == 0) e = fse_build_from_probabilities(&t, 6, LL_DEFAULT, 36);
+    else if (which == 1) e = fse_build_from_probabilities(&t, 5, OF_DEFAULT, 29);
+    else if (which == 2) e = fse_build_from_probabilities(&t, 6, ML_DEFAULT, 53);
+    else e = fse_build_from_probabilities(&t, acc_log, probs, nprobs);
+    if (e) { fse_free(&t); return e; }
+    *size = 1u << t.accuracy_log;
+    for (uint32_t i = 0; i < *size; i++) { sym[i] = t.decode[i].symbol; nb[i] = t.decode[i].num_bits; bl[i] = t.decode[i].base_line; }
+    fse_free(&t); return 0;
+}
+/* read an FSE table description (fse_decoder.cairo:258-368) and dump probabilities */
+CZO_API int czo_kat_fse_read(const uint8_t* src, size_t len, uint8_t max_log, int32_t* probs, uint32_t* nprobs, uint8_t* acc_log, size_t* bytes) {
+    fse_table t; memset(&t, 0, sizeof t);
+    int e = fse_read_probabilities(&t, src, len, max_log, bytes);
+    if (!e) { *nprobs = t.nprobs; *acc_log = t.accuracy_log; memcpy(probs, t.probs, t.nprobs * sizeof(int32_t)); }
+    return e;
+}
+/* build a Huffman table from a tree description (huff0_decoder.cairo:149-157), dump it */
+CZO_API int czo_kat_huf_table(const uint8_t* src, size_t len, uint8_t* sym, uint8_t* nb, uint32_t* max_bits, uint32_t* bytes_used,
+                              uint8_t* weights, uint32_t* nweights) {
+    huf_table* h = (huf_table*)calloc(1, sizeof *h);
+    int e = huf_build_decoder(h, src, len, bytes_used);
+    if (!e) {
+        *max_bits = h->max_num_bits;
+        for (uint32_t i = 0; i < (1u << h->max_num_bits); i++) { sym[i] = h->decode[i].symbol; nb[i] = h->decode[i].num_bits; }
+        *nweights = h->nweights; memcpy(weights, h->weights, h->nweights);
+    }
+    fse_free(&h->fse); free(h); return e;
+}
+/* block-level hook: decode ONE block body given its 3-byte header, fresh scratch
+   (block_decoder.cairo:237 + :77) */
+CZO_API int czo_decode_single_block(const uint8_t* src, size_t len, uint8_t* dst, size_t cap, uint64_t* written, uint64_t* consumed, size_t window) {
+    scratch s; scratch_init(&s); scratch_reset(&s, window);
+    s.buf = dst; s.buf_cap = cap; s.buf_owned = 0;
+    block_header bh; int e = read_block_header(src, len, &bh);
+    uint64_t body = 0;
+    if (!e) e = decode_block_content(&s, &bh, src + 3, len - 3, &body);
+    *written = s.buf_len; *consumed = 3 + body;
+    s.buf = NULL; scratch_free(&s); return e;
+}
+CZO_API int czo_abi_version(void) { return 1; }
