@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — zstd block-decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload full_4a|huf_literals|raw_rle|full_4b|mix]
+
+A "step" is one pass of the hot path (cz_decode_batch_device: one persistent-grid launch of
+cz_decode_frames_kernel) over one batch of synthetic frames that already sits in HBM.
+Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full
+compressed 128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
+Frames shard by rank with no data-path collective (weak scaling: 10 000 frames per GPU).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
+  roofline      achieved = algorithmic bytes / mean kernel duration (hipEvents around the kernel
+                on the stream it runs on), against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference algorithm) timed on a bounded sample of
+                the same frames on this host's cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "raw_rle": "config2: single-block frames, 50% Raw 131072 B random / 50% RLE 131072 B",
+    "huf_literals": "config3: literals-only compressed blocks, 131072 literals, 4-stream Huffman, fresh table per block",
+    "full_4a": "config4a: full compressed blocks, 32768 literals (Huffman 4-stream) + 32768 sequences (ll~1, ml=3), FSE-compressed LL/OF/ML tables, 131072 B out",
+    "full_4b": "config4b: reference-shape blocks, 65536 sequences, ~224 KiB out (beyond the zstd block limit)",
+    "mix": "config5: corpus-like mix of Raw/RLE/Compressed multi-block frames",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="full_4a", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
+    ap.add_argument("--gather", action="store_true", help="include an RCCL gather of the decoded arenas to rank 0 in the step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=16, help="frames per rank checked against the oracle after the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import cairo_zstd_amd as cz
+    from cairo_zstd_amd import synth
+
+    # ---- synthetic batch for this rank (frames rank*F .. rank*F+F-1 of the global batch)
+    F = args.frames
+    ncpu = os.cpu_count() or 1
+    t0 = time.time()
+    batch = synth.generate(args.workload, F, first_index=rank * F, nthreads=max(1, min(32, ncpu // max(1, min(world, 8)))))
+    gen_s = time.time() - t0
+    out_off, out_cap, out_total = batch.out_layout(256)
+    alg_bytes = int(batch.length.sum() + batch.regen.sum())       # compressed bytes read once + decoded bytes written once
+    regen_bytes = int(batch.regen.sum())
+
+    t_in = torch.from_numpy(batch.base).to(dev)
+    t_off = torch.from_numpy(batch.off.astype(np.int64)).to(dev)
+    t_len = torch.from_numpy(batch.length.astype(np.int64)).to(dev)
+    t_ooff = torch.from_numpy(out_off.astype(np.int64)).to(dev)
+    t_ocap = torch.from_numpy(out_cap.astype(np.int64)).to(dev)
+    t_out = torch.empty(out_total, dtype=torch.uint8, device=dev)
+    t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    ctx = cz.Context(local_rank, stream.cuda_stream)
+
+    gather_bufs = None
+    if args.gather and world > 1:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([out_total], dtype=torch.int64, device=dev))
+        if rank == 0:
+            gather_bufs = [torch.empty(int(s.item()), dtype=torch.uint8, device=dev) for s in sizes]
+
+    def step():
+        ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
+                                t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
+        if args.gather and world > 1:
+            # final gather of the decoded arenas: direct peer sends to the root so that all of its
+            # xGMI links are used concurrently (a ring would be bound by one link)
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, gather_bufs[r], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, t_out, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # Per-launch kernel durations for the roofline: K more launches of the same step, each read
+    # from the hipEvent pair the library records around the kernel on the stream it runs on
+    # (reading a pair needs a sync, which must stay out of the timed region above).
+    kernel_ms = []
+    for _ in range(args.steps):
+        ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
+                                t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
+        kernel_ms.append(ctx.last_kernel_ms())
+    torch.cuda.synchronize()
+
+    # ---- correctness gate: every frame OK + sizes; a sample bit-exact against the oracle
+    res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+    ok = bool((res["status"] == 0).all() and (res["bytes_produced"] == batch.regen).all())
+    verified = 0
+    if args.verify:
+        import oracle
+        out_host = t_out.cpu().numpy()
+        for i in np.linspace(0, F - 1, num=min(args.verify, F), dtype=np.int64):
+            st, ref, _ = oracle.decode_frame(batch.frame(int(i)), cap=int(batch.regen[i]) + 16)
+            got = out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])].tobytes()
+            ok = ok and st == 0 and got == ref
+            verified += 1
+        del out_host
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(regen_bytes), float(alg_bytes), 1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        regen_all, alg_all, ok_all = float(tot[0].item()), float(tot[1].item()), int(tot[2].item()) == world
+    else:
+        regen_all, alg_all, ok_all = float(regen_bytes), float(alg_bytes), ok
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
+            "value": regen_all * args.steps / elapsed / 1e6,
+            "unit": "MB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}", "frames_per_gpu": F,
+                       "frames_total": F * world, "compressed_bytes_per_gpu": int(batch.length.sum()),
+                       "decoded_bytes_per_gpu": regen_bytes, "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
+                       "gather_in_step": bool(args.gather and world > 1)},
+            "bit_exact": bool(ok_all), "frames_verified_vs_oracle": verified,
+            "algorithmic_GBps_whole_job": alg_all * args.steps / elapsed / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "cz_decode_frames_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_mean": k_ms,
+                         "kernel_ms_all": [round(float(x), 4) for x in kernel_ms], **ctx.launch_info()},
+            "synth_seconds": round(gen_s, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            threads = ncpu
+            # bounded sample: grow the frame count until the budget is used
+            n_s = min(F, max(threads * 2, 64))
+            sample_s, done = 0.0, 0
+            t_begin = time.perf_counter()
+            while True:
+                idx = np.arange(done, min(F, done + n_s))
+                if idx.size == 0:
+                    break
+                t1 = time.perf_counter()
+                _, olen, ost = oracle.decode_batch(batch.base, batch.off[idx], batch.length[idx], out_off[idx] - out_off[idx[0]],
+                                                   out_cap[idx], int(out_off[idx[-1]] + out_cap[idx[-1]] - out_off[idx[0]]) + 256,
+                                                   nthreads=threads)
+                sample_s += time.perf_counter() - t1
+                assert (ost == 0).all()
+                done += idx.size
+                if time.perf_counter() - t_begin > args.cpu_seconds or done >= F:
+                    break
+                n_s = min(F - done, n_s * 2)
+            cpu_regen = float(batch.regen[:done].sum())
+            line["cpu_baseline"] = {"value": cpu_regen / sample_s / 1e6, "unit": "MB/s", "cores": threads, "kind": "port",
+                                    "sample": f"first {done} frames of the same batch, oracle/zstd_oracle.c (C restatement of the reference), {threads} pthreads, one frame per task, {sample_s:.2f} s"}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

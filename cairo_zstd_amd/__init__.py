@@ -1,0 +1,218 @@
+"""cairo_zstd_amd — MI355X-native zstd frame/block decoder with the frame_decoder API surface of
+NethermindEth/cairo_zstd.
+
+Python here is a thin mirror over the C ABI (include/cairo_zstd_amd.h, libcairo_zstd_amd.so):
+  * Context / decode_batch* : many independent frames per launch (the GPU hot path)
+  * FrameDecoder            : FrameDecoderTrait call for call (src/frame_decoder.cairo:107-335)
+  * read_frame_header / read_block_header : stateless parsers
+All decoding runs in the HIP kernels; nothing here decodes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import status
+from ._lib import RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM, BlockHeader, FrameHeader, build, lib
+from .status import CzError
+
+__all__ = ["Context", "FrameDecoder", "BlockDecodingStrategy", "decode_batch_host", "read_frame_header",
+           "read_block_header", "RESULT_DTYPE", "status", "CzError", "build", "lib"]
+
+
+def _as_u8(b) -> np.ndarray:
+    if isinstance(b, np.ndarray):
+        return np.ascontiguousarray(b, dtype=np.uint8)
+    return np.frombuffer(bytes(b), dtype=np.uint8)
+
+
+class Context:
+    """Device context (cz_context_*).  `stream` is a raw hipStream_t (e.g.
+    torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        st = lib().cz_context_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None)
+        if st:
+            self._h = None
+            raise CzError(st, "cz_context_create")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cz_context_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def synchronize(self):
+        st = lib().cz_context_synchronize(self._h)
+        if st:
+            raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+
+    def launch_info(self):
+        wg, th, cu = C.c_int(), C.c_int(), C.c_int()
+        lib().cz_context_launch_info(self._h, C.byref(wg), C.byref(th), C.byref(cu))
+        return dict(workgroups=wg.value, threads_per_workgroup=th.value, compute_units=cu.value)
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        st = lib().cz_context_last_kernel_ms(self._h, C.byref(ms))
+        if st:
+            raise CzError(st, "cz_context_last_kernel_ms")
+        return ms.value
+
+    def decode_batch_device(self, in_base: int, in_off: int, in_len: int, n: int, out_base: int, out_off: int,
+                            out_cap: int, results: int):
+        """All arguments are raw DEVICE pointers (tensor.data_ptr()).  Asynchronous."""
+        st = lib().cz_decode_batch_device(self._h, in_base, in_off, in_len, n, out_base, out_off, out_cap, results)
+        if st:
+            raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+
+    def decode_batch_host(self, in_base, in_off, in_len, out_off, out_cap, out_total: int):
+        """Host buffers in, host buffers out (PCIe-inclusive).  Returns (out_base, results)."""
+        in_base = _as_u8(in_base)
+        in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        in_len = np.ascontiguousarray(in_len, dtype=np.uint64)
+        out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+        out_cap = np.ascontiguousarray(out_cap, dtype=np.uint64)
+        n = int(in_off.size)
+        out = np.zeros(max(out_total, 1), dtype=np.uint8)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        st = lib().cz_decode_batch_host(self._h, in_base.ctypes.data, in_base.size, in_off.ctypes.data, in_len.ctypes.data,
+                                        n, out.ctypes.data, out_total, out_off.ctypes.data, out_cap.ctypes.data,
+                                        res.ctypes.data)
+        if st:
+            raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+        return out, res
+
+
+def decode_batch_host(frames, caps, ctx: Context | None = None):
+    """Convenience: list of frame byte strings -> list of (result record, decoded bytes)."""
+    own = ctx is None
+    ctx = ctx or Context()
+    try:
+        lens = np.array([len(f) for f in frames], dtype=np.uint64)
+        in_off = np.zeros(len(frames), dtype=np.uint64)
+        if len(frames) > 1:
+            in_off[1:] = np.cumsum(lens[:-1])
+        in_base = np.frombuffer(b"".join(frames) + b"\0" * 16, dtype=np.uint8)
+        caps = np.array(caps, dtype=np.uint64)
+        pad = (caps + np.uint64(255)) // np.uint64(256) * np.uint64(256)
+        out_off = np.zeros(len(frames), dtype=np.uint64)
+        if len(frames) > 1:
+            out_off[1:] = np.cumsum(pad[:-1])
+        total = int(pad.sum())
+        out, res = ctx.decode_batch_host(in_base, in_off, lens, out_off, caps, total)
+        return [(res[i], out[int(out_off[i]): int(out_off[i]) + min(int(res[i]["bytes_produced"]), int(caps[i]))].tobytes())
+                for i in range(len(frames))]
+    finally:
+        if own:
+            ctx.close()
+
+
+def read_frame_header(src):
+    """read_frame_header (src/frame.cairo:152-284).  Returns (status, FrameHeader, detail)."""
+    a = _as_u8(src)
+    fh = FrameHeader()
+    detail = (C.c_uint64 * 2)()
+    st = lib().cz_read_frame_header(a.ctypes.data if a.size else None, a.size, C.byref(fh), detail)
+    return st, fh, (detail[0], detail[1])
+
+
+def read_block_header(src):
+    """BlockDecoderTrait::read_block_header (src/decoding/block_decoder.cairo:237-278)."""
+    a = _as_u8(src)
+    bh = BlockHeader()
+    st = lib().cz_read_block_header(a.ctypes.data if a.size else None, a.size, C.byref(bh))
+    return st, bh
+
+
+class BlockDecodingStrategy:
+    """src/frame_decoder.cairo:33-37"""
+    ALL, UPTO_BLOCKS, UPTO_BYTES = 0, 1, 2
+
+
+class FrameDecoder:
+    """Mirror of FrameDecoder / FrameDecoderTrait (src/frame_decoder.cairo:17-335).  Methods
+    return the status code where the reference returns Result<_, FrameDecoderError>."""
+
+    def __init__(self, ctx: Context):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        st = lib().cz_frame_decoder_create(ctx._h, C.byref(self._h))
+        if st:
+            self._h = None
+            raise CzError(st, "cz_frame_decoder_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cz_frame_decoder_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _init(self, fn, src):
+        a = _as_u8(src)
+        consumed = C.c_size_t()
+        detail = (C.c_uint64 * 2)()
+        st = fn(self._h, a.ctypes.data if a.size else None, a.size, C.byref(consumed), detail)
+        return st, consumed.value, (detail[0], detail[1])
+
+    def new(self, src):
+        return self._init(lib().cz_frame_decoder_new, src)
+
+    def reset(self, src):
+        return self._init(lib().cz_frame_decoder_reset, src)
+
+    def content_size(self):
+        return lib().cz_frame_decoder_content_size(self._h)
+
+    def get_checksum_from_data(self):
+        v = C.c_uint32()
+        return v.value if lib().cz_frame_decoder_checksum_from_data(self._h, C.byref(v)) else None
+
+    def get_calculated_checksum(self):
+        return lib().cz_frame_decoder_calculated_checksum(self._h)
+
+    def bytes_read_from_source(self):
+        return lib().cz_frame_decoder_bytes_read_from_source(self._h)
+
+    def is_finished(self):
+        return bool(lib().cz_frame_decoder_is_finished(self._h))
+
+    def blocks_decoded(self):
+        return lib().cz_frame_decoder_blocks_decoded(self._h)
+
+    def decode_blocks(self, src, strategy=BlockDecodingStrategy.ALL, n=0):
+        a = _as_u8(src)
+        consumed = C.c_size_t()
+        fin = C.c_int()
+        st = lib().cz_frame_decoder_decode_blocks(self._h, a.ctypes.data if a.size else None, a.size, strategy, n,
+                                                  C.byref(consumed), C.byref(fin))
+        return st, consumed.value, bool(fin.value)
+
+    def can_collect(self):
+        return lib().cz_frame_decoder_can_collect(self._h)
+
+    def collect(self, cap: int = 1 << 24):
+        out = np.empty(cap, dtype=np.uint8)
+        w = C.c_size_t()
+        r = lib().cz_frame_decoder_collect(self._h, out.ctypes.data, cap, C.byref(w))
+        if r < 0:
+            raise CzError(-r, "collect")
+        return out[: w.value].tobytes() if r == 1 else None
+
+    def read(self, cap: int = 1 << 24):
+        out = np.empty(cap, dtype=np.uint8)
+        n = lib().cz_frame_decoder_read(self._h, out.ctypes.data, cap)
+        return out[:n].tobytes()
+
+    def decode_from_to(self, src, cap: int = 1 << 24):
+        a = _as_u8(src)
+        out = np.empty(cap, dtype=np.uint8)
+        r, w = C.c_size_t(), C.c_size_t()
+        st = lib().cz_frame_decoder_decode_from_to(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap,
+                                                   C.byref(r), C.byref(w))
+        return st, r.value, out[: w.value].tobytes()

@@ -1,0 +1,114 @@
+"""Loader of libcairo_zstd_amd.so (the C ABI of include/cairo_zstd_amd.h).
+
+Fails loudly when the library is missing: there is no CPU decode path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcairo_zstd_amd.so")
+
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("blocks_decoded", "<u4"), ("bytes_consumed", "<u8"),
+                         ("bytes_produced", "<u8"), ("checksum_from_data", "<u4"), ("flags", "<u4"),
+                         ("detail", "<u8", (2,))])
+RESULT_FINISHED, RESULT_HAS_CHECKSUM = 1, 2
+
+
+class FrameHeader(C.Structure):
+    _fields_ = [("descriptor", C.c_uint8), ("window_descriptor", C.c_uint8), ("has_dict_id", C.c_uint8),
+                ("header_len", C.c_uint8), ("dict_id", C.c_uint32), ("frame_content_size", C.c_uint64),
+                ("window_size", C.c_uint64)]
+
+
+class BlockHeader(C.Structure):
+    _fields_ = [("last_block", C.c_uint8), ("block_type", C.c_uint8), ("decompressed_size", C.c_uint32),
+                ("content_size", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the library in-tree with hipcc for gfx950 (csrc/Makefile)."""
+    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_types.h")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("cairo_zstd_amd.h", "cairo_zstd_amd_status.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "libcairo_zstd_amd.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded C ABI.  Import torch first when it is used in the same process, so that both
+    share one HIP runtime (the library's DT_NEEDED libamdhip64.so.7 then resolves to the copy
+    torch already mapped)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  cairo_zstd_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (maps torch's HIP runtime first)
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)
+    L.cz_abi_version.restype = C.c_int
+    L.cz_context_create.restype = C.c_int
+    L.cz_context_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.cz_context_destroy.argtypes = [vp]
+    L.cz_context_synchronize.restype = C.c_int
+    L.cz_context_synchronize.argtypes = [vp]
+    L.cz_context_last_hip_error.restype = C.c_int
+    L.cz_context_last_hip_error.argtypes = [vp]
+    L.cz_context_launch_info.restype = C.c_int
+    L.cz_context_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.cz_context_last_kernel_ms.restype = C.c_int
+    L.cz_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cz_decode_batch_device.restype = C.c_int
+    L.cz_decode_batch_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    L.cz_decode_batch_host.restype = C.c_int
+    L.cz_decode_batch_host.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.cz_read_frame_header.restype = C.c_int
+    L.cz_read_frame_header.argtypes = [vp, sz, C.POINTER(FrameHeader), u64p]
+    L.cz_read_block_header.restype = C.c_int
+    L.cz_read_block_header.argtypes = [vp, sz, C.POINTER(BlockHeader)]
+    L.cz_frame_decoder_create.restype = C.c_int
+    L.cz_frame_decoder_create.argtypes = [vp, C.POINTER(vp)]
+    L.cz_frame_decoder_destroy.argtypes = [vp]
+    for name in ("cz_frame_decoder_new", "cz_frame_decoder_reset"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, vp, sz, C.POINTER(sz), u64p]
+    L.cz_frame_decoder_content_size.restype = C.c_uint64
+    L.cz_frame_decoder_content_size.argtypes = [vp]
+    L.cz_frame_decoder_checksum_from_data.restype = C.c_int
+    L.cz_frame_decoder_checksum_from_data.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.cz_frame_decoder_calculated_checksum.restype = C.c_uint32
+    L.cz_frame_decoder_calculated_checksum.argtypes = [vp]
+    L.cz_frame_decoder_bytes_read_from_source.restype = C.c_uint64
+    L.cz_frame_decoder_bytes_read_from_source.argtypes = [vp]
+    L.cz_frame_decoder_is_finished.restype = C.c_int
+    L.cz_frame_decoder_is_finished.argtypes = [vp]
+    L.cz_frame_decoder_blocks_decoded.restype = sz
+    L.cz_frame_decoder_blocks_decoded.argtypes = [vp]
+    L.cz_frame_decoder_decode_blocks.restype = C.c_int
+    L.cz_frame_decoder_decode_blocks.argtypes = [vp, vp, sz, C.c_int, sz, C.POINTER(sz), C.POINTER(C.c_int)]
+    L.cz_frame_decoder_can_collect.restype = sz
+    L.cz_frame_decoder_can_collect.argtypes = [vp]
+    L.cz_frame_decoder_collect.restype = C.c_int
+    L.cz_frame_decoder_collect.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.cz_frame_decoder_read.restype = sz
+    L.cz_frame_decoder_read.argtypes = [vp, vp, sz]
+    L.cz_frame_decoder_decode_from_to.restype = C.c_int
+    L.cz_frame_decoder_decode_from_to.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    _lib = L
+    return L

@@ -1,0 +1,473 @@
+/*
+ * czstd_host.hip — host side of libcairo_zstd_amd.so: the C ABI of include/cairo_zstd_amd.h.
+ *
+ *   cz_context_*          device context: stream, per-workgroup literal scratch, work counter
+ *   cz_decode_batch_*     batch planner + launch of cz_decode_frames_kernel
+ *   cz_frame_decoder_*    C++ mirror of the reference's FrameDecoder state machine
+ *                         (src/frame_decoder.cairo:107-335); block decoding itself is always
+ *                         done by the device kernel — there is no CPU decode path here.
+ *   cz_read_frame_header / cz_read_block_header   stateless parsers (frame.cairo:152-284,
+ *                         block_decoder.cairo:237-278)
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "czstd_types.h"
+
+#include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
+
+#define CZ_EXPORT extern "C" __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ context */
+struct cz_context {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int num_cu = 0, occupancy = 0, grid_max = 0;
+    uint8_t* lit_scratch = nullptr; uint32_t* work_counter = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr; bool timed = false;
+    int last_grid = 0;
+    int last_hip_error = 0;
+    /* staging for cz_decode_batch_host */
+    void* d_stage = nullptr; size_t d_stage_bytes = 0;
+};
+
+#define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
+
+CZ_EXPORT int cz_abi_version(void) { return CZ_ABI_VERSION; }
+
+CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
+    if (!out) return CZ_E_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CZ_E_NO_DEVICE;
+    cz_context* c = new (std::nothrow) cz_context();
+    if (!c) return CZ_E_INVALID_ARG;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return CZ_E_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return CZ_E_NO_DEVICE; }
+    if (!strstr(prop.gcnArchName, "gfx950")) { delete c; return CZ_E_NO_DEVICE; }   /* kernels are built for gfx950 only */
+    c->num_cu = prop.multiProcessorCount;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
+    c->occupancy = occ; c->grid_max = c->num_cu * occ;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CZ_E_HIP; } c->own_stream = true; }
+    if (hipMalloc((void**)&c->lit_scratch, (size_t)c->grid_max * CZ_LIT_SCRATCH_BYTES) != hipSuccess ||
+        hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
+        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        if (c->lit_scratch) (void)hipFree(c->lit_scratch);
+        if (c->work_counter) (void)hipFree(c->work_counter);
+        delete c; return CZ_E_HIP;
+    }
+    *out = c;
+    return CZ_OK;
+}
+
+CZ_EXPORT void cz_context_destroy(cz_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->lit_scratch) (void)hipFree(c->lit_scratch);
+    if (c->work_counter) (void)hipFree(c->work_counter);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+CZ_EXPORT int cz_context_synchronize(cz_context* c) {
+    if (!c) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+CZ_EXPORT int cz_context_last_hip_error(const cz_context* c) { return c ? c->last_hip_error : 0; }
+CZ_EXPORT int cz_context_launch_info(const cz_context* c, int* workgroups, int* threads_per_wg, int* compute_units) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (workgroups) *workgroups = c->last_grid ? c->last_grid : c->grid_max;
+    if (threads_per_wg) *threads_per_wg = CZ_WG_THREADS;
+    if (compute_units) *compute_units = c->num_cu;
+    return CZ_OK;
+}
+CZ_EXPORT int cz_context_last_kernel_ms(cz_context* c, float* ms) {
+    if (!c || !ms || !c->timed) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return CZ_OK;
+}
+
+/* ------------------------------------------------------------------ launch */
+static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
+    if (n == 0) return CZ_OK;
+    if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
+    cz_batch_args a = proto;
+    a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_LIT_SCRATCH_BYTES;
+    const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
+    CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
+    CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+    CZ_HIP(c, hipGetLastError());
+    CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true; c->last_grid = grid;
+    return CZ_OK;
+}
+
+CZ_EXPORT int cz_decode_batch_device(cz_context* c, const void* d_in_base, const uint64_t* d_in_off, const uint64_t* d_in_len, size_t n,
+                                     void* d_out_base, const uint64_t* d_out_off, const uint64_t* d_out_cap, cz_frame_result* d_results) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (n && (!d_in_base || !d_in_off || !d_in_len || !d_out_base || !d_out_off || !d_out_cap || !d_results)) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    cz_batch_args a; memset(&a, 0, sizeof a);
+    a.in_base = (const uint8_t*)d_in_base; a.in_off = d_in_off; a.in_len = d_in_len;
+    a.out_base = (uint8_t*)d_out_base; a.out_off = d_out_off; a.out_cap = d_out_cap; a.results = d_results; a.tasks = nullptr;
+    return cz_launch(c, a, n);
+}
+
+static int cz_stage_reserve(cz_context* c, size_t bytes) {
+    if (c->d_stage_bytes >= bytes) return CZ_OK;
+    if (c->d_stage) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_stage); c->d_stage = nullptr; c->d_stage_bytes = 0; }
+    CZ_HIP(c, hipMalloc(&c->d_stage, bytes));
+    c->d_stage_bytes = bytes;
+    return CZ_OK;
+}
+
+CZ_EXPORT int cz_decode_batch_host(cz_context* c, const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
+                                   void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap, cz_frame_result* results) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (n == 0) return CZ_OK;
+    if (!in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !results) return CZ_E_INVALID_ARG;
+    for (size_t i = 0; i < n; i++) {
+        if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i]) return CZ_E_INVALID_ARG;
+        if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i]) return CZ_E_INVALID_ARG;
+    }
+    CZ_HIP(c, hipSetDevice(c->device));
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_in = 0, o_out = o_in + up(in_bytes + 16), o_desc = o_out + up(out_bytes + 16), o_res = o_desc + up(4 * n * 8);
+    const size_t total = o_res + up(n * sizeof(cz_frame_result));
+    int st = cz_stage_reserve(c, total); if (st) return st;
+    uint8_t* d = (uint8_t*)c->d_stage;
+    uint64_t* d_desc = (uint64_t*)(d + o_desc);
+    CZ_HIP(c, hipMemcpyAsync(d + o_in, in_base, in_bytes, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipMemcpyAsync(d_desc, in_off, n * 8, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipMemcpyAsync(d_desc + n, in_len, n * 8, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipMemcpyAsync(d_desc + 2 * n, out_off, n * 8, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipMemcpyAsync(d_desc + 3 * n, out_cap, n * 8, hipMemcpyHostToDevice, c->stream));
+    st = cz_decode_batch_device(c, d + o_in, d_desc, d_desc + n, n, d + o_out, d_desc + 2 * n, d_desc + 3 * n, (cz_frame_result*)(d + o_res));
+    if (st) return st;
+    CZ_HIP(c, hipMemcpyAsync(out_base, d + o_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(c, hipMemcpyAsync(results, d + o_res, n * sizeof(cz_frame_result), hipMemcpyDeviceToHost, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+
+/* ------------------------------------------------------------------ stateless parsers */
+static inline uint32_t rd32le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+CZ_EXPORT int cz_read_frame_header(const uint8_t* p, size_t len, cz_frame_header* out, uint64_t* detail) {
+    if (!out || (!p && len)) return CZ_E_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    if (len < 4) return CZ_E_FH_MAGIC_READ;                             /* frame.cairo:155-158 */
+    const uint32_t magic = rd32le(p); size_t i = 4;
+    if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {                 /* :160-166 */
+        if (len < 8) return CZ_E_FH_DESCRIPTOR_READ;
+        if (detail) { detail[0] = magic; detail[1] = rd32le(p + 4); }
+        return CZ_E_FH_SKIP_FRAME;
+    }
+    if (magic != 0xFD2FB528u) { if (detail) detail[0] = magic; return CZ_E_FH_BAD_MAGIC; }   /* :168 */
+    if (len < i + 1) return CZ_E_FH_DESCRIPTOR_READ;                    /* :172-175 */
+    const uint8_t d = p[i++]; out->descriptor = d;
+    const int single = (d >> 5) & 1;
+    if (!single) { if (len < i + 1) return CZ_E_FH_WINDOW_DESC_READ; out->window_descriptor = p[i++]; }   /* :186-193 */
+    const unsigned didf = d & 3, dl = didf == 3 ? 4 : didf;             /* :76-90 */
+    if (dl) {                                                           /* :202-231 */
+        if (len < i + dl) return CZ_E_FH_DICT_ID_READ;
+        uint32_t id = 0; for (unsigned k = 0; k < dl; k++) id |= (uint32_t)p[i + k] << (8 * k);
+        i += dl; if (id) { out->dict_id = id; out->has_dict_id = 1; }
+    }
+    const unsigned flag = d >> 6, fl = flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8;  /* :56-74 */
+    if (fl) {                                                           /* :240-278; truncation reports DictionaryIdReadError */
+        if (len < i + fl) return CZ_E_FH_DICT_ID_READ;
+        uint64_t f = 0; for (unsigned k = 0; k < fl; k++) f |= (uint64_t)p[i + k] << (8 * k);
+        i += fl; if (fl == 2) f += 256;
+        out->frame_content_size = f;
+    }
+    out->header_len = (uint8_t)i;
+    if (single) out->window_size = out->frame_content_size;             /* :106-129 */
+    else {
+        const uint64_t base = 1ull << (10 + (out->window_descriptor >> 3)), w = base + (base / 8) * (out->window_descriptor & 7);
+        if (w < 1024) return CZ_E_WINDOW_TOO_SMALL;
+        if (w >= 4123168604160ull) return CZ_E_WINDOW_TOO_BIG;
+        out->window_size = w;
+    }
+    return CZ_OK;
+}
+
+CZ_EXPORT int cz_read_block_header(const uint8_t* p, size_t len, cz_block_header* h) {
+    if (!h || (!p && len)) return CZ_E_INVALID_ARG;
+    memset(h, 0, sizeof *h);
+    if (len < 3) return CZ_E_BH_TRUNCATED;                              /* (panic) block_decoder.cairo:240 */
+    const uint32_t a = p[0], b = p[1], c = p[2], t = (a >> 1) & 3;      /* :289-304 */
+    if (t == 3) return CZ_E_BH_RESERVED;                                /* :248 */
+    const uint32_t size = (a >> 3) | (b << 5) | (c << 13);              /* :315-321 */
+    if (size > 128u * 1024u) return CZ_E_BH_SIZE_TOO_LARGE;             /* :306-313 */
+    h->block_type = (uint8_t)t; h->last_block = (uint8_t)(a & 1);
+    h->decompressed_size = t == 2 ? 0 : size;                           /* :256-261 */
+    h->content_size = t == 1 ? 1 : size;                                /* :262-267 */
+    return CZ_OK;
+}
+
+/* ------------------------------------------------------------------ XXH64 (frame content checksum) */
+/* src/utils/xxhash64.cairo:20-163.  The reference hashes what DecodeBuffer drains
+ * (decode_buffer.cairo:162,181), seed 0; the low 32 bits are compared (frame_decoder.cairo:133-138). */
+namespace {
+const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full, P3 = 0x165667B19E3779F9ull, P4 = 0x85EBCA77C2B2AE63ull, P5 = 0x27D4EB2F165667C5ull;
+inline uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint64_t rnd(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; }
+inline uint64_t mrg(uint64_t h, uint64_t v) { v = rnd(0, v); h ^= v; return h * P1 + P4; }
+struct Xxh64 {
+    uint64_t total = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0; uint8_t mem[32]; uint32_t memsize = 0;
+    void reset() { total = 0; memsize = 0; v1 = P1 + P2; v2 = P2; v3 = 0; v4 = 0 - P1; }
+    void update(const uint8_t* p, size_t len) {
+        total += len;
+        if (memsize + len < 32) { memcpy(mem + memsize, p, len); memsize += (uint32_t)len; return; }
+        const uint8_t* end = p + len;
+        if (memsize) {
+            size_t fill = 32 - memsize; memcpy(mem + memsize, p, fill);
+            v1 = rnd(v1, rd64(mem)); v2 = rnd(v2, rd64(mem + 8)); v3 = rnd(v3, rd64(mem + 16)); v4 = rnd(v4, rd64(mem + 24));
+            p += fill; memsize = 0;
+        }
+        while (p + 32 <= end) { v1 = rnd(v1, rd64(p)); v2 = rnd(v2, rd64(p + 8)); v3 = rnd(v3, rd64(p + 16)); v4 = rnd(v4, rd64(p + 24)); p += 32; }
+        if (p < end) { memcpy(mem, p, (size_t)(end - p)); memsize = (uint32_t)(end - p); }
+    }
+    uint64_t digest() const {
+        uint64_t h;
+        if (total >= 32) { h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18); h = mrg(h, v1); h = mrg(h, v2); h = mrg(h, v3); h = mrg(h, v4); }
+        else h = P5;
+        h += total;
+        const uint8_t* p = mem; const uint8_t* end = p + memsize;
+        while (p + 8 <= end) { h ^= rnd(0, rd64(p)); h = rotl(h, 27) * P1 + P4; p += 8; }
+        if (p + 4 <= end) { h ^= (uint64_t)rd32le(p) * P1; h = rotl(h, 23) * P2 + P3; p += 4; }
+        while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl(h, 11) * P1; p++; }
+        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+        return h;
+    }
+};
+}  // namespace
+
+/* ------------------------------------------------------------------ frame decoder */
+struct cz_frame_decoder {
+    cz_context* ctx = nullptr;
+    cz_frame_header fh{}; bool initialised = false;
+    bool frame_finished = false; size_t block_counter = 0; uint64_t bytes_read_counter = 0;    /* frame_decoder.cairo:22-30 */
+    uint32_t check_sum = 0; bool has_check_sum = false;
+    uint64_t window_size = 0;
+    /* DecodeBuffer (decode_buffer.cairo:9-15): the decoded frame stays in HBM; `drained`
+       marks how much the host already collected, so buffer.len() == produced - drained */
+    uint8_t* d_out = nullptr; size_t d_out_cap = 0; uint64_t produced = 0, drained = 0;
+    Xxh64 hash;
+    /* device-side bookkeeping */
+    uint8_t* d_src = nullptr; size_t d_src_cap = 0;
+    uint8_t* d_ctl = nullptr;   /* [state | state backup | task | result] */
+    std::vector<uint8_t> bounce;
+};
+static const size_t CTL_STATE = 0, CTL_BACKUP = (sizeof(cz_device_frame_state) + 255) & ~(size_t)255,
+                    CTL_TASK = 2 * CTL_BACKUP, CTL_RES = CTL_TASK + 256, CTL_BYTES = CTL_RES + 256;
+
+CZ_EXPORT int cz_frame_decoder_create(cz_context* ctx, cz_frame_decoder** out) {
+    if (!ctx || !out) return CZ_E_INVALID_ARG;
+    *out = nullptr;
+    cz_frame_decoder* fd = new (std::nothrow) cz_frame_decoder();
+    if (!fd) return CZ_E_INVALID_ARG;
+    fd->ctx = ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&fd->d_ctl, CTL_BYTES) != hipSuccess) { delete fd; return CZ_E_HIP; }
+    *out = fd; return CZ_OK;
+}
+CZ_EXPORT void cz_frame_decoder_destroy(cz_frame_decoder* fd) {
+    if (!fd) return;
+    (void)hipSetDevice(fd->ctx->device);
+    (void)hipStreamSynchronize(fd->ctx->stream);
+    if (fd->d_out) (void)hipFree(fd->d_out);
+    if (fd->d_src) (void)hipFree(fd->d_src);
+    if (fd->d_ctl) (void)hipFree(fd->d_ctl);
+    delete fd;
+}
+
+static int fd_init(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail, bool is_reset) {
+    if (!fd) return CZ_E_INVALID_ARG;
+    cz_frame_header fh;
+    int e = cz_read_frame_header(src, len, &fh, detail);                /* frame_decoder.cairo:55-64 / :81-90 */
+    if (e) return e;
+    if (is_reset && fh.window_size > 1024ull * 1024 * 100) return CZ_E_WINDOW_SIZE_TOO_BIG;     /* :92 (D4: new() has no cap) */
+    cz_context* c = fd->ctx;
+    CZ_HIP(c, hipSetDevice(c->device));
+    /* DecoderScratch::new / reset (scratch.cairo:23-58) */
+    cz_device_frame_state init; memset(&init, 0, sizeof init);
+    init.hist[0] = 1; init.hist[1] = 4; init.hist[2] = 8; init.fse_rle[0] = init.fse_rle[1] = init.fse_rle[2] = -1;
+    CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_STATE, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    fd->fh = fh; fd->window_size = fh.window_size; fd->initialised = true;
+    fd->frame_finished = false; fd->block_counter = 0; fd->bytes_read_counter = fh.header_len;
+    fd->check_sum = 0; fd->has_check_sum = false; fd->produced = 0; fd->drained = 0; fd->hash.reset();
+    if (consumed) *consumed = fh.header_len;
+    return CZ_OK;
+}
+CZ_EXPORT int cz_frame_decoder_new(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init(fd, src, len, consumed, detail, false); }
+CZ_EXPORT int cz_frame_decoder_reset(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init(fd, src, len, consumed, detail, true); }
+
+CZ_EXPORT uint64_t cz_frame_decoder_content_size(const cz_frame_decoder* fd) { return fd ? fd->fh.frame_content_size : 0; }
+CZ_EXPORT int cz_frame_decoder_checksum_from_data(const cz_frame_decoder* fd, uint32_t* v) { if (fd && fd->has_check_sum && v) *v = fd->check_sum; return fd && fd->has_check_sum; }
+CZ_EXPORT uint32_t cz_frame_decoder_calculated_checksum(const cz_frame_decoder* fd) { return fd ? (uint32_t)fd->hash.digest() : 0; }
+CZ_EXPORT uint64_t cz_frame_decoder_bytes_read_from_source(const cz_frame_decoder* fd) { return fd ? fd->bytes_read_counter : 0; }
+CZ_EXPORT int cz_frame_decoder_is_finished(const cz_frame_decoder* fd) {
+    if (!fd) return 0;
+    if ((fd->fh.descriptor >> 2) & 1) return fd->frame_finished && fd->has_check_sum;           /* frame_decoder.cairo:144-150 */
+    return fd->frame_finished;
+}
+CZ_EXPORT size_t cz_frame_decoder_blocks_decoded(const cz_frame_decoder* fd) { return fd ? fd->block_counter : 0; }
+
+static inline size_t fd_buffer_len(const cz_frame_decoder* fd) { return (size_t)(fd->produced - fd->drained); }
+
+/* grows the resident frame buffer, keeping what is already decoded (window reach-back) */
+static int fd_reserve_out(cz_frame_decoder* fd, size_t need) {
+    if (fd->d_out_cap >= need) return CZ_OK;
+    cz_context* c = fd->ctx;
+    size_t nc = fd->d_out_cap ? fd->d_out_cap : (size_t)1 << 20;
+    while (nc < need) nc *= 2;
+    uint8_t* p = nullptr;
+    CZ_HIP(c, hipMalloc((void**)&p, nc));
+    if (fd->d_out && fd->produced) CZ_HIP(c, hipMemcpyAsync(p, fd->d_out, fd->produced, hipMemcpyDeviceToDevice, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (fd->d_out) (void)hipFree(fd->d_out);
+    fd->d_out = p; fd->d_out_cap = nc;
+    return CZ_OK;
+}
+
+/* Uploads `src`, runs the kernel on ONE frame task, folds the result into the counters. */
+static int fd_run(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint32_t strategy, uint64_t n, uint32_t streaming, cz_frame_result* res) {
+    cz_context* c = fd->ctx;
+    CZ_HIP(c, hipSetDevice(c->device));
+    if (fd->d_src_cap < len + 16) {
+        if (fd->d_src) (void)hipFree(fd->d_src);
+        fd->d_src = nullptr; fd->d_src_cap = 0;
+        size_t nc = (len + 16 + 65535) & ~(size_t)65535;
+        CZ_HIP(c, hipMalloc((void**)&fd->d_src, nc)); fd->d_src_cap = nc;
+    }
+    if (len) CZ_HIP(c, hipMemcpyAsync(fd->d_src, src, len, hipMemcpyHostToDevice, c->stream));
+    /* output bound: every block regenerates at most 128 KiB in valid data; the reference does
+       not enforce that, so grow and retry on CZ_E_OUTPUT_TOO_SMALL */
+    size_t blocks = 0, pos = 0;
+    while (len - pos >= 3) {
+        cz_block_header bh; if (cz_read_block_header(src + pos, len - pos, &bh)) break;
+        blocks++; pos += 3 + bh.content_size;
+        if (bh.last_block || pos > len) break;
+        if (strategy == CZ_STRATEGY_UPTO_BLOCKS && blocks >= n) break;
+    }
+    size_t want = (size_t)fd->produced + (blocks ? blocks : 1) * (128u * 1024u) + 4096;
+    CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_BACKUP, fd->d_ctl + CTL_STATE, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        int st = fd_reserve_out(fd, want); if (st) return st;
+        cz_device_task t; memset(&t, 0, sizeof t);
+        t.src = fd->d_src; t.src_len = len; t.dst = fd->d_out; t.dst_cap = fd->d_out_cap; t.produced = fd->produced; t.drained = fd->drained;
+        t.window_size = fd->window_size; t.strategy = strategy; t.strategy_n = n; t.has_checksum = (fd->fh.descriptor >> 2) & 1; t.streaming = streaming;
+        t.state = (cz_device_frame_state*)(fd->d_ctl + CTL_STATE);
+        CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_TASK, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+        cz_batch_args a; memset(&a, 0, sizeof a);
+        a.tasks = (const cz_device_task*)(fd->d_ctl + CTL_TASK); a.results = (cz_frame_result*)(fd->d_ctl + CTL_RES);
+        st = cz_launch(c, a, 1); if (st) return st;
+        CZ_HIP(c, hipMemcpyAsync(res, fd->d_ctl + CTL_RES, sizeof *res, hipMemcpyDeviceToHost, c->stream));
+        CZ_HIP(c, hipStreamSynchronize(c->stream));
+        if (res->status != CZ_E_OUTPUT_TOO_SMALL) return CZ_OK;
+        /* roll the carried state back and retry with a larger resident buffer */
+        CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_STATE, fd->d_ctl + CTL_BACKUP, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
+        want = fd->d_out_cap * 4;
+    }
+    return CZ_OK;
+}
+
+CZ_EXPORT int cz_frame_decoder_decode_blocks(cz_frame_decoder* fd, const uint8_t* src, size_t len, cz_strategy strategy, size_t n,
+                                             size_t* consumed, int* finished) {
+    if (!fd || !fd->initialised || (!src && len)) return CZ_E_INVALID_ARG;
+    cz_frame_result r; memset(&r, 0, sizeof r);
+    int st = fd_run(fd, src, len, (uint32_t)strategy, n, 0, &r);       /* frame_decoder.cairo:156-222 */
+    if (st) return st;
+    fd->bytes_read_counter += r.bytes_consumed; fd->block_counter += r.blocks_decoded; fd->produced = r.bytes_produced;
+    if (r.flags & CZ_RESULT_FINISHED) fd->frame_finished = true;
+    if (r.flags & CZ_RESULT_HAS_CHECKSUM) { fd->check_sum = r.checksum_from_data; fd->has_check_sum = true; }
+    if (consumed) *consumed = (size_t)r.bytes_consumed;
+    if (finished) *finished = fd->frame_finished;
+    return r.status;
+}
+
+CZ_EXPORT size_t cz_frame_decoder_can_collect(const cz_frame_decoder* fd) {                    /* frame_decoder.cairo:233-243 */
+    if (!fd) return 0;
+    const size_t bl = fd_buffer_len(fd);
+    if (cz_frame_decoder_is_finished(fd)) return bl;
+    return bl > fd->window_size ? (size_t)(bl - fd->window_size) : 0;
+}
+/* drain_to (decode_buffer.cairo:168-186): device -> host, hash update, advance */
+static size_t fd_drain(cz_frame_decoder* fd, size_t amount, uint8_t* dst, size_t cap) {
+    size_t n = fd_buffer_len(fd) < amount ? fd_buffer_len(fd) : amount;
+    if (n > cap) n = cap;
+    if (!n) return 0;
+    cz_context* c = fd->ctx;
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    if (hipMemcpyAsync(dst, fd->d_out + fd->drained, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    fd->hash.update(dst, n);
+    fd->drained += n;
+    return n;
+}
+CZ_EXPORT int cz_frame_decoder_collect(cz_frame_decoder* fd, uint8_t* dst, size_t cap, size_t* written) {     /* :224-231 */
+    if (!fd || !written) return -CZ_E_INVALID_ARG;
+    *written = 0;
+    const size_t bl = fd_buffer_len(fd);
+    if (cz_frame_decoder_is_finished(fd)) {
+        if (bl > cap) return -CZ_E_TARGET_TOO_SMALL;
+        *written = fd_drain(fd, bl, dst, cap); return 1;
+    }
+    if (bl > fd->window_size) {
+        const size_t can = (size_t)(bl - fd->window_size);
+        if (can > cap) return -CZ_E_TARGET_TOO_SMALL;
+        *written = fd_drain(fd, can, dst, cap); return 1;
+    }
+    return 0;
+}
+CZ_EXPORT size_t cz_frame_decoder_read(cz_frame_decoder* fd, uint8_t* dst, size_t cap) {                     /* :328-334 */
+    if (!fd) return 0;
+    const size_t bl = fd_buffer_len(fd);
+    const size_t amount = fd->frame_finished ? bl : (bl > fd->window_size ? (size_t)(bl - fd->window_size) : 0);
+    return fd_drain(fd, amount, dst, cap);
+}
+CZ_EXPORT int cz_frame_decoder_decode_from_to(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint8_t* dst, size_t cap,
+                                              size_t* read_len, size_t* written) {                           /* :245-326 */
+    if (!fd || !fd->initialised || !read_len || !written || (!src && len)) return CZ_E_INVALID_ARG;
+    const uint64_t start = fd->bytes_read_counter;
+    *read_len = 0; *written = 0;
+    if (!cz_frame_decoder_is_finished(fd)) {
+        const bool cks = (fd->fh.descriptor >> 2) & 1;
+        if (cks && fd->frame_finished && !fd->has_check_sum) {          /* :255-267 */
+            if (len >= 4) { fd->check_sum = rd32le(src); fd->has_check_sum = true; fd->bytes_read_counter += 4; }
+            *read_len = 4; return CZ_OK;                                /* (4, 0) even when fewer than 4 bytes were there */
+        }
+        cz_frame_result r; memset(&r, 0, sizeof r);
+        int st = fd_run(fd, src, len, CZ_STRATEGY_ALL, 0, 1, &r);
+        if (st) return st;
+        fd->bytes_read_counter += r.bytes_consumed; fd->block_counter += r.blocks_decoded; fd->produced = r.bytes_produced;
+        if (r.flags & CZ_RESULT_FINISHED) fd->frame_finished = true;
+        if (r.flags & CZ_RESULT_HAS_CHECKSUM) { fd->check_sum = r.checksum_from_data; fd->has_check_sum = true; }
+        if (r.status) return r.status;
+    }
+    *written = cz_frame_decoder_read(fd, dst, cap);
+    *read_len = (size_t)(fd->bytes_read_counter - start);
+    return CZ_OK;
+}

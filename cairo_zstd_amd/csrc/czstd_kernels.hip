@@ -1,0 +1,888 @@
+/*
+ * czstd_kernels.hip — CDNA4 (gfx950) kernels of the zstd frame/block decoder.
+ *
+ * Mapping: ONE 64-lane wavefront (= one workgroup) per frame, a
+ * persistent grid that pulls frames from an atomic work counter.  Blocks of one frame are
+ * chained (Treeless literals, Repeat FSE modes, offset history, window reach-back:
+ * src/decoding/scratch.cairo:11-19), so the frame is the unit of parallelism and all carried
+ * state lives in the workgroup's LDS: Huffman table (4 KiB), LL/OF/ML FSE tables (6 KiB),
+ * offset history.  Per block:
+ *     lane 0      parses headers / table descriptions from an LDS-staged copy of the bytes
+ *     lanes 0..2  build the three FSE decoding tables side by side
+ *     all lanes   fill the Huffman table; copy / fill Raw and RLE payloads (16 B per lane)
+ *     lanes 0..3  decode the four huff0 streams (one backward bit reader per lane)
+ *     lane 0      runs the interleaved LL/OF/ML FSE state machines, 64 sequences at a time,
+ *                 then all 64 lanes execute those sequences: wave prefix sums give every
+ *                 sequence its literal and output offsets, literals are scattered in
+ *                 parallel, matches are resolved in dependency rounds (ballot + first-undone
+ *                 watermark), long copies are done cooperatively.
+ *
+ * Semantics follow the reference (NethermindEth/cairo_zstd) line by line where it matters;
+ * each device function cites the reference file:line it restates.  Error codes mirror the
+ * reference's enum leaves (cairo_zstd_amd_status.h) in the reference's order of detection.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "czstd_types.h"
+
+#define LANE ((int)threadIdx.x)
+
+
+/* ------------------------------------------------------------------ LDS layout */
+struct CzBroadcast {
+    int32_t  err; uint32_t detail;
+    /* frame header */
+    uint32_t hdr_len, has_checksum; uint64_t window_size; uint64_t d0, d1;
+    /* block header */
+    uint32_t btype, bsize, blast;
+    /* literals section */
+    uint32_t lit_type, regen, nstreams, lit_total;      /* lit_total = header + body bytes */
+    uint32_t stream_off[4], stream_len[4];              /* relative to the block start */
+    uint32_t huf_fill, huf_nsym;
+    uint32_t st_count[4], st_flags[4];
+    /* sequences section */
+    int32_t  seq_hdr_err; uint32_t nseq, seq_modes, seq_body_off;
+    uint32_t build_mask, nprobs[3], acc_log[3], bitstream_off;
+    /* per chunk */
+    uint32_t chunk_cnt; int32_t chunk_err;
+};
+
+struct CzShared {
+    cz_device_frame_state st;          /* carried across blocks (scratch.cairo:11-19) */
+    int16_t  probs[3][256];
+    uint16_t counters[3][256];
+    uint8_t  stage[512];
+    union { uint32_t wtab[512]; struct { uint32_t ll[64], ml[64], off[64]; } seq; } u;
+    uint8_t  hbits[264];
+    uint16_t sym_base[264];
+    uint32_t llml[96];                 /* [0..35] LL base | bits<<24, [40..92] ML */
+    CzBroadcast bc;
+    uint32_t frame_idx;
+};
+
+/* sequence_section_decoder.cairo:299-345 / :347-395 */
+__device__ static const uint32_t CZ_LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+__device__ static const uint8_t  CZ_LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__device__ static const uint32_t CZ_ML_BASE[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+__device__ static const uint8_t  CZ_ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+/* predefined distributions, sequence_section_decoder.cairo:418-455, :494-524, :562-616 */
+__device__ static const int8_t CZ_LL_DEFAULT[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__device__ static const int8_t CZ_OF_DEFAULT[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+__device__ static const int8_t CZ_ML_DEFAULT[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+
+/* math.cairo:266-271: 1-based index of the highest set bit */
+__device__ static inline uint32_t cz_hbs(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
+
+/* ------------------------------------------------------------------ wave helpers */
+__device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, (unsigned)d); if (LANE >= d) v += t; }
+    return v;
+}
+
+/* all-lane copy, 16 B per lane per step once dst is 16-byte aligned */
+__device__ static void cz_coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > n) head = (uint32_t)n;
+    if ((uint32_t)LANE < head) dst[LANE] = src[LANE];
+    dst += head; src += head; n -= head;
+    const uint64_t nvec = n >> 4;
+    for (uint64_t i = (uint64_t)LANE; i < nvec; i += 64) {
+        uint4 v; __builtin_memcpy(&v, src + 16 * i, 16);          /* source may be unaligned */
+        *(uint4*)(dst + 16 * i) = v;
+    }
+    for (uint64_t i = (nvec << 4) + (uint64_t)LANE; i < n; i += 64) dst[i] = src[i];
+}
+__device__ static void cz_coop_fill(uint8_t* dst, uint8_t byte, uint64_t n) {
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > n) head = (uint32_t)n;
+    if ((uint32_t)LANE < head) dst[LANE] = byte;
+    dst += head; n -= head;
+    const uint32_t w = 0x01010101u * byte;
+    uint4 v; v.x = w; v.y = w; v.z = w; v.w = w;
+    const uint64_t nvec = n >> 4;
+    for (uint64_t i = (uint64_t)LANE; i < nvec; i += 64) *(uint4*)(dst + 16 * i) = v;
+    for (uint64_t i = (nvec << 4) + (uint64_t)LANE; i < n; i += 64) dst[i] = byte;
+}
+
+/* ------------------------------------------------------------------ bit readers */
+/* Reversed reader (bit_reader_reverse.cairo:44-275), one per lane, over global memory.
+ * `remaining` is the reference's bits_remaining and may go negative; reads past the start
+ * return zero bits (:147-159).  buf holds unread bits MSB-aligned. */
+struct CzRBits { const uint8_t* base; int32_t bytes_left; uint64_t buf; int32_t avail; int32_t remaining; };
+
+__device__ static inline void cz_rb_init(CzRBits& r, const uint8_t* base, uint32_t len) {
+    r.base = base; r.bytes_left = (int32_t)len; r.buf = 0; r.avail = 0; r.remaining = (int32_t)len * 8;
+}
+__device__ static inline void cz_rb_refill(CzRBits& r) {
+    if (r.avail <= 32 && r.bytes_left > 0) {
+        if (r.bytes_left >= 4) {
+            const uint8_t* p = r.base + r.bytes_left - 4;
+            uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            r.bytes_left -= 4;
+            r.buf |= (uint64_t)w << (32 - r.avail); r.avail += 32;
+        } else {
+            while (r.bytes_left > 0) { uint8_t b = r.base[--r.bytes_left]; r.buf |= (uint64_t)b << (56 - r.avail); r.avail += 8; }
+        }
+    }
+}
+/* get_bits(n), n <= 32 (bit_reader_reverse.cairo:129-172) */
+__device__ static inline uint32_t cz_rb_get(CzRBits& r, uint32_t n) {
+    if (n == 0) return 0;
+    cz_rb_refill(r);
+    uint32_t v = (uint32_t)(r.buf >> (64 - n));
+    r.buf <<= n; r.avail -= (int32_t)n; r.remaining -= (int32_t)n;
+    return v;
+}
+/* zero padding up to and including the first 1 bit; > 8 reads = ExtraPadding
+ * (literals_section_decoder.cairo:190-207, sequence_section_decoder.cairo:46-64,
+ *  huff0_decoder.cairo:206-225).  Returns 1 on ExtraPadding. */
+__device__ static inline int cz_rb_skip_padding(CzRBits& r) {
+    int skipped = 0;
+    for (;;) { uint32_t v = cz_rb_get(r, 1); skipped++; if (v == 1 || skipped > 8) break; }
+    return skipped > 8;
+}
+
+/* Forward LSB-first reader (bit_reader.cairo:18-110) used by ONE lane for table
+ * descriptions.  Bytes come from the LDS stage when inside it, else from global memory. */
+struct CzFBits { const uint8_t* g; uint32_t len; const uint8_t* stage; uint32_t stage_lo, stage_hi; uint32_t idx; };
+__device__ static inline uint32_t cz_fb_byte(const CzFBits& f, uint32_t i) {
+    return (i >= f.stage_lo && i < f.stage_hi) ? f.stage[i - f.stage_lo] : f.g[i];
+}
+/* returns 0 ok / 1 not enough bits (bit_reader.cairo:42-44).  n <= 24 */
+__device__ static inline int cz_fb_get(CzFBits& f, uint32_t n, uint32_t* out) {
+    if (f.len * 8u - f.idx < n) return 1;
+    uint32_t b = f.idx >> 3, sh = f.idx & 7, v = 0;
+    for (uint32_t k = 0; k * 8 < sh + n; k++) v |= cz_fb_byte(f, b + k) << (8 * k);
+    *out = (v >> sh) & ((1u << n) - 1u);
+    f.idx += n; return 0;
+}
+
+/* ------------------------------------------------------------------ FSE tables */
+/* packed entry: symbol | num_bits << 8 | base_line << 16  (fse_decoder.cairo:49-53) */
+#define CZ_FSE_SYM(e) ((e) & 0xFFu)
+#define CZ_FSE_NB(e) (((e) >> 8) & 0xFFu)
+#define CZ_FSE_BASE(e) ((e) >> 16)
+
+/* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
+__device__ static int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
+                                        uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above) {
+    uint32_t v;
+    if (cz_fb_get(br, 4, &v)) return CZ_E_FSE_GETBITS;                  /* :265-268 */
+    uint32_t log = 5 + v;                                               /* :270 */
+    if (log > max_log) return CZ_E_FSE_ACC_LOG_TOO_BIG;                 /* :271 */
+    if ((int)log > unsupported_above) return CZ_E_UNSUPPORTED;          /* DESIGN.md divergence D2 */
+    uint32_t sum = 1u << log, counter = 0, n = 0;
+    while (counter < sum) {                                             /* :281-346 */
+        uint32_t max_rem = sum - counter + 1, bits = cz_hbs(max_rem);
+        if (cz_fb_get(br, bits, &v)) return CZ_E_FSE_GETBITS;
+        uint32_t low = ((1u << bits) - 1u) - max_rem, mask = (1u << (bits - 1)) - 1u, small = v & mask, value;
+        if (small < low) { br.idx -= 1; value = small; }                /* return_bits(1) :303 */
+        else if (v > mask) value = v - low;
+        else value = v;
+        int32_t prob = (int32_t)value - 1;
+        if (n < 256) probs[n] = (int16_t)prob;
+        n++;
+        if (prob != 0) counter += prob > 0 ? (uint32_t)prob : 1u;
+        else for (;;) {                                                 /* :322-340 */
+            if (cz_fb_get(br, 2, &v)) return CZ_E_FSE_GETBITS;
+            for (uint32_t k = 0; k < v; k++) { if (n < 256) probs[n] = 0; n++; }
+            if (v != 3) break;
+        }
+    }
+    if (counter != sum) return CZ_E_FSE_PROB_MISMATCH;                  /* :352 */
+    if (n > 256) return CZ_E_FSE_TOO_MANY_SYMBOLS;                      /* :357 */
+    *nprobs = n; *acc_log = log; *bytes_read = (br.idx + 7) >> 3;       /* :361-365 */
+    return 0;
+}
+/* build_decoding_table (fse_decoder.cairo:156-256).  One lane per table; lanes 0..2 run it
+ * side by side on different tables. */
+__device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters) {
+    const uint32_t size = 1u << log;
+    uint32_t neg = size;
+    for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
+        counters[s] = 0;
+        if (probs[s] == -1) { neg--; table[neg] = s | (log << 8); }
+    }
+    uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    for (uint32_t s = 0; s < nprobs; s++) {                             /* :190-226 */
+        int32_t p = probs[s];
+        for (int32_t j = 0; j < p; j++) {
+            table[pos] = s;
+            do { pos = (pos + step) & mask; } while (pos >= neg);
+        }
+    }
+    for (uint32_t i = 0; i < neg; i++) {                                /* :231-255, :377-400 */
+        uint32_t s = table[i] & 0xFFu, n = (uint32_t)probs[s], k = counters[s];
+        counters[s] = (uint16_t)(k + 1);
+        uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
+        uint32_t dbl = slices - n, single = n - dbl, width = size / slices, nb = cz_hbs(width) - 1, bl;
+        if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
+        else bl = (k - dbl) * width;
+        table[i] = s | (nb << 8) | (bl << 16);
+    }
+}
+
+/* ------------------------------------------------------------------ Huffman table */
+/* read_weights + the serial half of build_table_from_weights
+ * (huff0_decoder.cairo:159-319, :321-431).  Lane 0.  Leaves per-symbol code lengths in
+ * sh.hbits[0..nsym) and first-cell indices in sh.sym_base[]; the table itself is filled by
+ * all lanes afterwards (cz_huf_fill).  *bytes_used per :313-318. */
+__device__ static int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
+                                           uint32_t goff, uint32_t* bytes_used, uint32_t* nsym_out) {
+    /* g = block start, the tree description begins at block offset goff, len bytes available */
+    if (len == 0) return CZ_E_HUF_SOURCE_EMPTY;                         /* :162 */
+    CzFBits fb; fb.g = g; fb.stage = sh.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = 0;
+    const uint32_t header = cz_fb_byte(fb, goff);
+    uint8_t* w = sh.hbits; uint32_t nw = 0;
+    if (header < 128) {                                                 /* :168-277 */
+        const uint32_t fl = len - 1;
+        if (header > fl) return CZ_E_HUF_NOT_ENOUGH_BYTES_FOR_WEIGHTS;  /* :171 */
+        /* FSE description: reader positioned at block offset goff+1 */
+        CzFBits br; br.g = g + goff + 1; br.len = fl; br.stage = sh.stage; br.idx = 0;
+        br.stage_lo = 0; br.stage_hi = 0;
+        if (goff + 1 >= stage_lo && goff + 1 < stage_hi) { br.stage = sh.stage + (goff + 1 - stage_lo); br.stage_lo = 0; br.stage_hi = stage_hi - (goff + 1); }
+        uint32_t nprobs, log, fse_bytes;
+        int e = cz_fse_read_probs(br, 100, sh.probs[0], &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
+        if (e) return e;
+        if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
+        cz_fse_build(sh.u.wtab, sh.probs[0], nprobs, log, sh.counters[0]);
+        CzRBits rb; cz_rb_init(rb, g + goff + 1 + fse_bytes, header - fse_bytes);       /* :190-202 */
+        if (cz_rb_skip_padding(rb)) return CZ_E_HUF_EXTRA_PADDING;      /* :206-225 */
+        uint32_t d1 = sh.u.wtab[cz_rb_get(rb, log)];                    /* :227 */
+        uint32_t d2 = sh.u.wtab[cz_rb_get(rb, log)];                    /* :233 */
+        for (;;) {                                                      /* :242-274 */
+            if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d1); nw++;
+            d1 = sh.u.wtab[CZ_FSE_BASE(d1) + cz_rb_get(rb, CZ_FSE_NB(d1))];
+            if (rb.remaining <= -1) { if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d2); nw++; break; }
+            if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d2); nw++;
+            d2 = sh.u.wtab[CZ_FSE_BASE(d2) + cz_rb_get(rb, CZ_FSE_NB(d2))];
+            if (rb.remaining <= -1) { if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d1); nw++; break; }
+            if (nw > 255) return CZ_E_HUF_TOO_MANY_WEIGHTS;             /* :271 */
+        }
+        if (nw > 255) return CZ_E_HUF_TOO_MANY_WEIGHTS;                 /* u8 overflow panic at :458 */
+        *bytes_used = 1 + header;                                       /* :204, :313-318 */
+    } else {                                                            /* :278-311 direct weights (zstd nibble order, D1) */
+        nw = header - 127;
+        const uint32_t need = (nw + 1) >> 1;
+        if (len - 1 < need) return CZ_E_HUF_NOT_ENOUGH_BYTES_IN_SOURCE; /* :289 */
+        for (uint32_t i = 0; i < nw; i++) {
+            uint32_t b = cz_fb_byte(fb, goff + 1 + (i >> 1));
+            w[i] = (uint8_t)((i & 1) ? (b & 0xF) : (b >> 4));
+        }
+        *bytes_used = 1 + need;
+    }
+    /* build_table_from_weights :321-431 */
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < nw; i++) {
+        if (w[i] > 11) return CZ_E_HUF_WEIGHT_TOO_BIG;                  /* :335 */
+        sum += w[i] ? (1u << (w[i] - 1)) : 0u;
+    }
+    if (sum == 0) return CZ_E_HUF_MISSING_WEIGHTS;                      /* :351 */
+    const uint32_t max_bits = cz_hbs(sum), left = (1u << max_bits) - sum;
+    if (left == 0 || (left & (left - 1))) return CZ_E_HUF_LEFTOVER_NOT_POW2;            /* :359 */
+    const uint32_t last_w = cz_hbs(left);
+    sh.st.huf_max_bits = (uint8_t)max_bits;                             /* :383 (set before the check, as the reference) */
+    if (max_bits > 11) return CZ_E_HUF_MAX_BITS_TOO_HIGH;               /* :385 */
+    uint32_t rank_cnt[13], rank_idx[13];
+    for (int b = 0; b < 13; b++) { rank_cnt[b] = 0; rank_idx[b] = 0; }
+    for (uint32_t s = 0; s <= nw; s++) {
+        uint32_t wt = s < nw ? w[s] : last_w, bits = wt ? max_bits + 1 - wt : 0;
+        w[s] = (uint8_t)bits; rank_cnt[bits]++;
+    }
+    for (uint32_t b = max_bits; b > 0; b--) rank_idx[b - 1] = rank_idx[b] + rank_cnt[b] * (1u << (max_bits - b)); /* :414-429 */
+    for (uint32_t s = 0; s <= nw; s++) {                                /* :433-450 */
+        uint32_t b = w[s];
+        if (b) { sh.sym_base[s] = (uint16_t)rank_idx[b]; rank_idx[b] += 1u << (max_bits - b); }
+    }
+    *nsym_out = nw + 1;
+    return 0;
+}
+/* all lanes: the cell-filling half (huff0_decoder.cairo:451-463).  entry = symbol | bits<<8 */
+__device__ static void cz_huf_fill(CzShared& sh, uint32_t nsym) {
+    const uint32_t max_bits = sh.st.huf_max_bits;
+    for (uint32_t s = 0; s < nsym; s++) {
+        const uint32_t b = sh.hbits[s];
+        if (!b) continue;
+        const uint32_t base = sh.sym_base[s], len = 1u << (max_bits - b);
+        const uint16_t e = (uint16_t)(s | (b << 8));
+        for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.st.huf[base + k] = e;
+    }
+}
+/* One huff0 stream, one lane (literals_section_decoder.cairo:183-243).  Writes at most `cap`
+ * bytes to out but keeps counting.  flags: 1 ExtraPadding, 2 stream did not end exactly. */
+__device__ static void cz_huf_stream(const CzShared& sh, const uint8_t* src, uint32_t len, uint8_t* out, uint32_t cap,
+                                     uint32_t* count, uint32_t* flags) {
+    CzRBits rb; cz_rb_init(rb, src, len);
+    if (cz_rb_skip_padding(rb)) { *count = 0; *flags = 1; return; }    /* :190-207 */
+    const uint32_t mb = sh.st.huf_max_bits;
+    uint32_t n = 0;
+    /* peek form of init_state/next_state (huff0_decoder.cairo:81-106): state = next mb bits.
+       bits_remaining(ref) = rb.remaining - mb; loop while it is > -mb (:216-228). */
+    while (rb.remaining > 0) {
+        cz_rb_refill(rb);
+        const uint32_t e = sh.st.huf[(uint32_t)(rb.buf >> (64 - mb))];
+        const uint32_t nb = e >> 8;
+        if (n < cap) out[n] = (uint8_t)e;
+        n++;
+        rb.buf <<= nb; rb.avail -= (int32_t)nb; rb.remaining -= (int32_t)nb;
+    }
+    *count = n; *flags = (rb.remaining != 0) ? 2u : 0u;                 /* :234-241 */
+}
+
+/* ------------------------------------------------------------------ frame / block headers */
+/* read_frame_header + window_size (frame.cairo:152-284, :106-129).  Lane 0. */
+__device__ static int cz_parse_frame_header(const uint8_t* p, uint64_t len, CzBroadcast& bc) {
+    if (len < 4) return CZ_E_FH_MAGIC_READ;
+    const uint32_t magic = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    uint32_t i = 4;
+    if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {
+        if (len < 8) return CZ_E_FH_DESCRIPTOR_READ;
+        bc.d0 = magic; bc.d1 = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+        return CZ_E_FH_SKIP_FRAME;
+    }
+    if (magic != 0xFD2FB528u) { bc.d0 = magic; return CZ_E_FH_BAD_MAGIC; }
+    if (len < i + 1) return CZ_E_FH_DESCRIPTOR_READ;
+    const uint32_t d = p[i++];
+    const uint32_t single = (d >> 5) & 1;
+    uint32_t wd = 0;
+    if (!single) { if (len < i + 1) return CZ_E_FH_WINDOW_DESC_READ; wd = p[i++]; }
+    const uint32_t didf = d & 3, dl = didf == 3 ? 4 : didf;
+    if (dl) { if (len < i + dl) return CZ_E_FH_DICT_ID_READ; i += dl; }
+    const uint32_t flag = d >> 6, fl = flag == 0 ? (single ? 1u : 0u) : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
+    uint64_t fcs = 0;
+    if (fl) {
+        if (len < i + fl) return CZ_E_FH_DICT_ID_READ;                  /* frame.cairo:245-270 quirk */
+        for (uint32_t k = 0; k < fl; k++) fcs |= (uint64_t)p[i + k] << (8 * k);
+        i += fl; if (fl == 2) fcs += 256;
+    }
+    uint64_t ws;
+    if (single) ws = fcs;
+    else {
+        const uint64_t base = 1ull << (10 + (wd >> 3)); ws = base + (base / 8) * (wd & 7);
+        if (ws < 1024) return CZ_E_WINDOW_TOO_SMALL;
+        if (ws >= 4123168604160ull) return CZ_E_WINDOW_TOO_BIG;
+    }
+    bc.hdr_len = i; bc.window_size = ws; bc.has_checksum = (d >> 2) & 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ literals */
+struct CzLit { const uint8_t* p; uint32_t len; uint32_t rle; uint8_t byte; };   /* rle=1: `len` copies of byte */
+
+__device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, uint32_t from, uint32_t n) {
+    if (lit.rle) cz_coop_fill(dst, lit.byte, n); else cz_coop_copy(dst, lit.p + from, n);
+}
+
+/* LiteralsSection::parse_from_header (literals_section.cairo:81-175) + the serial parts of
+ * decompress_literals (literals_section_decoder.cairo:58-117) + SequencesHeader::parse_from_header
+ * (sequence_section.cairo:77-114).  Lane 0; results in sh.bc. */
+__device__ static int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_hi) {
+    CzBroadcast& bc = sh.bc;
+    CzFBits fb; fb.g = blk; fb.stage = sh.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
+    if (bsize == 0) return CZ_E_LS_GETBITS;                             /* :84-90 */
+    const uint32_t b0 = cz_fb_byte(fb, 0), type = b0 & 3, fmt = (b0 >> 2) & 3;
+    uint32_t need = type <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
+    if (bsize < need) return CZ_E_LS_NOT_ENOUGH_BYTES;                  /* :100 */
+    uint32_t b1 = need > 1 ? cz_fb_byte(fb, 1) : 0, b2 = need > 2 ? cz_fb_byte(fb, 2) : 0,
+             b3 = need > 3 ? cz_fb_byte(fb, 3) : 0, b4 = need > 4 ? cz_fb_byte(fb, 4) : 0;
+    uint32_t regen, comp = 0, streams = 0;
+    if (type <= 1) {
+        if (fmt == 0 || fmt == 2) regen = b0 >> 3; else if (fmt == 1) regen = (b0 >> 4) + (b1 << 4); else regen = (b0 >> 4) + (b1 << 4) + (b2 << 12);
+    } else {
+        streams = fmt == 0 ? 1 : 4;
+        if (fmt <= 1) { regen = (b0 >> 4) + ((b1 & 0x3f) << 4); comp = (b1 >> 6) + (b2 << 2); }
+        else if (fmt == 2) { regen = (b0 >> 4) + (b1 << 4) + ((b2 & 3) << 12); comp = (b2 >> 2) + (b3 << 6); }
+        else { regen = (b0 >> 4) + (b1 << 4) + ((b2 & 0x3f) << 12); comp = (b2 >> 6) + (b3 << 2) + (b4 << 10); }
+    }
+    const uint32_t upper = type >= 2 ? comp : (type == 1 ? 1u : regen); /* block_decoder.cairo:160-172 */
+    if (bsize - need < upper) return CZ_E_MALFORMED_SECTION_HEADER;     /* block_decoder.cairo:174 */
+    bc.lit_type = type; bc.regen = regen; bc.nstreams = streams; bc.lit_total = need + upper; bc.huf_fill = 0;
+    if (type >= 2) {                                                    /* literals_section_decoder.cairo:64-117 */
+        uint32_t off = need, left = comp;
+        if (type == 2) {
+            uint32_t used, nsym;
+            int e = cz_huf_read_and_rank(sh, blk, left, 0, stage_hi, off, &used, &nsym);
+            if (e) return e;
+            bc.huf_fill = 1; bc.huf_nsym = nsym;
+            if (used > left) return CZ_E_BLOCK_TRUNCATED;               /* (panic) slice(bytes_read, len) :89 */
+            off += used; left -= used;
+        } else if (sh.st.huf_max_bits == 0) return CZ_E_LIT_UNINIT_HUF_TABLE;           /* :82-86 */
+        if (streams == 4) {
+            if (left < 6) return CZ_E_LIT_MISSING_JUMP_HEADER;          /* :92 */
+            const uint32_t j1 = cz_fb_byte(fb, off) + (cz_fb_byte(fb, off + 1) << 8);
+            const uint32_t j2 = j1 + cz_fb_byte(fb, off + 2) + (cz_fb_byte(fb, off + 3) << 8);
+            const uint32_t j3 = j2 + cz_fb_byte(fb, off + 4) + (cz_fb_byte(fb, off + 5) << 8);
+            off += 6; left -= 6;
+            if (left < j3) return CZ_E_LIT_MISSING_BYTES;               /* :101 */
+            bc.stream_off[0] = off;      bc.stream_len[0] = j1;
+            bc.stream_off[1] = off + j1; bc.stream_len[1] = j2 - j1;
+            bc.stream_off[2] = off + j2; bc.stream_len[2] = j3 - j2;
+            bc.stream_off[3] = off + j3; bc.stream_len[3] = left - j3;
+        } else { bc.stream_off[0] = off; bc.stream_len[0] = left; }
+    }
+    /* sequences header (read early; its error is only reported after the literals decoded) */
+    const uint32_t so = need + upper, sl = bsize - so;
+    bc.seq_hdr_err = 0; bc.nseq = 0; bc.seq_modes = 0; bc.seq_body_off = so;
+    if (sl == 0) bc.seq_hdr_err = CZ_E_SH_NOT_ENOUGH_BYTES;             /* sequence_section.cairo:81 */
+    else {
+        const uint32_t s0 = cz_fb_byte(fb, so);
+        if (s0 == 0) bc.seq_body_off = so + 1;                          /* :85-87 */
+        else {
+            uint32_t n = 0, hb = 0;
+            if (s0 <= 127) { if (sl < 2) bc.seq_hdr_err = CZ_E_SH_NOT_ENOUGH_BYTES; else { n = s0; hb = 1; } }
+            else if (s0 <= 254) { if (sl < 3) bc.seq_hdr_err = CZ_E_SH_NOT_ENOUGH_BYTES; else { n = ((s0 - 128) << 8) + cz_fb_byte(fb, so + 1); hb = 2; } }
+            else { if (sl < 4) bc.seq_hdr_err = CZ_E_SH_NOT_ENOUGH_BYTES; else { n = cz_fb_byte(fb, so + 1) + (cz_fb_byte(fb, so + 2) << 8) + 0x7F00u; hb = 3; } }
+            if (!bc.seq_hdr_err) { bc.nseq = n; bc.seq_modes = cz_fb_byte(fb, so + hb); bc.seq_body_off = so + hb + 1; }
+        }
+    }
+    return 0;
+}
+
+/* Huffman literal streams -> `target` (regen bytes).  All lanes enter; returns status
+ * (uniform).  literals_section_decoder.cairo:91-178. */
+__device__ static int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, uint8_t* target) {
+    CzBroadcast& bc = sh.bc;
+    const uint32_t regen = bc.regen, streams = bc.nstreams;
+    if (streams == 4) {
+        const uint32_t seg = (regen + 3) >> 2;
+        const int fits = 3 * seg <= regen;
+        if (LANE < 4) {
+            uint32_t cap = 0, o = (uint32_t)LANE * seg;
+            if (fits) cap = LANE < 3 ? seg : regen - 3 * seg;
+            uint32_t cnt, fl;
+            cz_huf_stream(sh, blk + bc.stream_off[LANE], bc.stream_len[LANE], target + (fits ? o : 0), cap, &cnt, &fl);
+            bc.st_count[LANE] = cnt; bc.st_flags[LANE] = fl | ((cnt != cap) ? 4u : 0u);
+        }
+        __syncthreads();
+        const uint32_t f0 = bc.st_flags[0], f1 = bc.st_flags[1], f2 = bc.st_flags[2], f3 = bc.st_flags[3];
+        const uint32_t total = bc.st_count[0] + bc.st_count[1] + bc.st_count[2] + bc.st_count[3];
+        __syncthreads();
+        /* first failing stream in stream order decides (reference decodes them sequentially) */
+        const uint32_t fl[4] = { f0, f1, f2, f3 };
+        for (int k = 0; k < 4; k++) {
+            if (fl[k] & 1u) return CZ_E_LIT_EXTRA_PADDING;
+            if (fl[k] & 2u) return CZ_E_LIT_BITSTREAM_MISMATCH;
+        }
+        if (total != regen) return CZ_E_LIT_COUNT_MISMATCH;             /* :172 */
+        if ((f0 | f1 | f2 | f3) & 4u) {
+            /* Valid streams whose symbol counts are not the ceil(regen/4) split (the reference
+               concatenates whatever each stream yields, :112-115): redo them back to back. */
+            __syncthreads();
+            if (LANE == 0) {
+                uint32_t at = 0;
+                for (int k = 0; k < 4; k++) { uint32_t c, f; cz_huf_stream(sh, blk + bc.stream_off[k], bc.stream_len[k], target + at, regen - at, &c, &f); at += c; }
+            }
+            __syncthreads();
+        }
+        return 0;
+    }
+    if (LANE == 0) {                                                    /* :118-170, no end-of-stream test */
+        uint32_t cnt, fl;
+        cz_huf_stream(sh, blk + bc.stream_off[0], bc.stream_len[0], target, regen, &cnt, &fl);
+        bc.st_count[0] = cnt; bc.st_flags[0] = fl;
+    }
+    __syncthreads();
+    const uint32_t sf = bc.st_flags[0], sc = bc.st_count[0];
+    __syncthreads();
+    if (sf & 1u) return CZ_E_LIT_EXTRA_PADDING;
+    if (sc != regen) return CZ_E_LIT_COUNT_MISMATCH;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ sequences */
+/* maybe_update_fse_tables, serial part (sequence_section_decoder.cairo:405-647): modes,
+ * RLE bytes, probability descriptions.  Lane 0.  Sets build_mask / nprobs / acc_log. */
+__device__ static int cz_parse_seq_tables(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_lo, uint32_t stage_hi) {
+    CzBroadcast& bc = sh.bc;
+    uint32_t off = bc.seq_body_off;
+    bc.build_mask = 0;
+    const uint32_t modes[3] = { (bc.seq_modes >> 6) & 3, (bc.seq_modes >> 4) & 3, (bc.seq_modes >> 2) & 3 };   /* LL, OF, ML */
+    const uint32_t max_log[3] = { 9, 8, 9 };
+    const int miss[3] = { CZ_E_SEQ_MISSING_RLE_BYTE_LL, CZ_E_SEQ_MISSING_RLE_BYTE_OF, CZ_E_SEQ_MISSING_RLE_BYTE_ML };
+    for (int t = 0; t < 3; t++) {
+        const uint32_t left = bsize - off;
+        if (modes[t] == 0) {                                            /* Predefined */
+            const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
+            const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u;
+            for (uint32_t s = 0; s < n; s++) sh.probs[t][s] = d[s];
+            bc.nprobs[t] = n; bc.acc_log[t] = t == 1 ? 5u : 6u; bc.build_mask |= 1u << t;
+            sh.st.fse_rle[t] = -1;
+        } else if (modes[t] == 1) {                                     /* RLE */
+            if (left == 0) return miss[t];
+            CzFBits fb; fb.g = blk; fb.stage = sh.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
+            sh.st.fse_rle[t] = (int32_t)cz_fb_byte(fb, off); off += 1;
+        } else if (modes[t] == 2) {                                     /* FSE_Compressed */
+            CzFBits br; br.g = blk + off; br.len = left; br.idx = 0; br.stage = sh.stage; br.stage_lo = 0; br.stage_hi = 0;
+            if (off >= stage_lo && off < stage_hi) { br.stage = sh.stage + (off - stage_lo); br.stage_hi = stage_hi - off; }
+            uint32_t np, lg, used;
+            int e = cz_fse_read_probs(br, max_log[t], sh.probs[t], &np, &lg, &used, 100);
+            if (e) return e;
+            bc.nprobs[t] = np; bc.acc_log[t] = lg; bc.build_mask |= 1u << t;
+            sh.st.fse_rle[t] = -1;
+            off += used;
+            if (off > bsize) return CZ_E_BLOCK_TRUNCATED;
+        }                                                               /* Repeat: keep */
+    }
+    bc.bitstream_off = off;
+    return 0;
+}
+
+/* sequence_execution.cairo:85-129; returns the actual offset (0 = ZeroOffset) */
+__device__ static inline uint32_t cz_offset_history(uint32_t ov, uint32_t ll, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    uint32_t a;
+    if (ll > 0) a = ov == 1 ? h0 : ov == 2 ? h1 : ov == 3 ? h2 : ov - 3;
+    else        a = ov == 1 ? h1 : ov == 2 ? h2 : ov == 3 ? h0 - 1 : ov - 3;
+    if (a == 0) return 0;
+    if (ll > 0) {
+        if (ov == 1) { }
+        else if (ov == 2) { h1 = h0; h0 = a; }
+        else { h2 = h1; h1 = h0; h0 = a; }
+    } else {
+        if (ov == 1) { h1 = h0; h0 = a; }
+        else { h2 = h1; h1 = h0; h0 = a; }
+    }
+    return a;
+}
+
+struct CzExecCtx {
+    uint8_t* out;            /* frame output base */
+    uint64_t cap;            /* capacity of the frame output */
+    uint64_t produced;       /* bytes already produced in this frame (total_output_counter) */
+    uint64_t drained;        /* bytes drained by the host (buffer.len = produced - drained) */
+    uint64_t window;
+    uint32_t lit_used;
+};
+
+/* execute up to 64 decoded sequences (sh.u.seq.*), all lanes.  sequence_execution.cairo:12-66,
+ * decode_buffer.cairo:62-133.  Returns status (uniform). */
+__device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt) {
+    const int active = (uint32_t)LANE < cnt;
+    const uint32_t ll = active ? sh.u.seq.ll[LANE] : 0, ml = active ? sh.u.seq.ml[LANE] : 0, off = active ? sh.u.seq.off[LANE] : 1;
+    const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
+    const uint32_t sum_ll = __shfl(incl_ll, 63), sum_tot = __shfl(incl_tot, 63);
+    const uint32_t lit_start = x.lit_used + (incl_ll - ll);
+    const uint64_t out_start = x.produced + (uint64_t)(incl_tot - tot);
+    const uint64_t dst = out_start + ll;                                /* where the match goes */
+    int e = 0;
+    if (active) {
+        if (ll > 0 && (uint64_t)lit_start + ll > lit.len) e = CZ_E_EXEC_NOT_ENOUGH_LITERALS;        /* :28-36 */
+        else if (off == 0) e = CZ_E_EXEC_ZERO_OFFSET;                                               /* :47 */
+        else if (ml > 0 && (uint64_t)off > dst - x.drained)                                         /* decode_buffer.cairo:65 */
+            e = (dst <= x.window) ? CZ_E_EXEC_NOT_ENOUGH_DICT : CZ_E_EXEC_OFFSET_TOO_BIG;           /* :66-75 / :92 */
+        else if (dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
+    }
+    const unsigned long long emask = __ballot(e != 0);
+    if (emask) { const int first = __ffsll((long long)emask) - 1; return __shfl(e, first); }
+
+    /* literals: short runs per lane, long runs cooperatively */
+    const int long_lit = ll > 32;
+    if (active && ll > 0 && !long_lit) {
+        uint8_t* d = x.out + out_start;
+        if (lit.rle) for (uint32_t k = 0; k < ll; k++) d[k] = lit.byte;
+        else { const uint8_t* s = lit.p + lit_start; for (uint32_t k = 0; k < ll; k++) d[k] = s[k]; }
+    }
+    unsigned long long lm = __ballot(long_lit);
+    while (lm) {
+        const int j = __ffsll((long long)lm) - 1; lm &= lm - 1;
+        const uint32_t n = __shfl(ll, j), ls = __shfl(lit_start, j);
+        const uint64_t os = ((uint64_t)__shfl((uint32_t)(out_start >> 32), j) << 32) | __shfl((uint32_t)out_start, j);
+        cz_lit_coop_copy(x.out + os, lit, ls, n);
+    }
+    __syncthreads();
+
+    /* matches: dependency rounds.  W = first byte not yet guaranteed written = match
+       destination of the first undone sequence; a sequence may go once its source range
+       (clipped to its own destination for self-overlap) lies below W. */
+    int done = !(active && ml > 0);
+    const uint64_t src = dst - off;
+    const uint64_t src_end = (src + ml < dst) ? src + ml : dst;
+    for (;;) {
+        const unsigned long long pend = __ballot(!done);
+        if (!pend) break;
+        const int f = __ffsll((long long)pend) - 1;
+        const uint64_t W = ((uint64_t)__shfl((uint32_t)(dst >> 32), f) << 32) | __shfl((uint32_t)dst, f);
+        const int ready = !done && src_end <= W;
+        if (ready && ml <= 32) {
+            uint8_t* d = x.out + dst; const uint8_t* s = x.out + src;
+            for (uint32_t k = 0; k < ml; k++) d[k] = s[k];              /* forward byte copy == decode_buffer.cairo:101-120 */
+        }
+        unsigned long long big = __ballot(ready && ml > 32);
+        while (big) {
+            const int j = __ffsll((long long)big) - 1; big &= big - 1;
+            const uint32_t n = __shfl(ml, j), o = __shfl(off, j);
+            const uint64_t dj = ((uint64_t)__shfl((uint32_t)(dst >> 32), j) << 32) | __shfl((uint32_t)dst, j);
+            uint8_t* d = x.out + dj; const uint8_t* s = d - o;
+            if (o >= n) cz_coop_copy(d, s, n);
+            else if (o >= 64) {
+                /* overlapping but far enough apart: copy `o`-byte generations, each fully
+                   written before the next one reads it */
+                for (uint32_t base = 0; base < n; base += o) {
+                    const uint32_t m = (n - base < o) ? n - base : o;
+                    for (uint32_t k = (uint32_t)LANE; k < m; k += 64) d[base + k] = s[base + k];
+                    __syncthreads();
+                }
+            } else for (uint32_t k = (uint32_t)LANE; k < n; k += 64) d[k] = s[k % o];   /* period-o pattern: source [s, s+o) is complete */
+        }
+        if (ready) done = 1;
+        __syncthreads();
+    }
+    x.produced += sum_tot; x.lit_used += sum_ll;
+    return 0;
+}
+
+/* decode_sequences + execute_sequences for one block.  All lanes.
+ * sequence_section_decoder.cairo:35-297, sequence_execution.cairo:12-83. */
+__device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit) {
+    CzBroadcast& bc = sh.bc;
+    const uint32_t nseq = bc.nseq;
+    /* lane-0 private decoder state */
+    CzRBits rb; rb.base = blk; rb.bytes_left = 0; rb.buf = 0; rb.avail = 0; rb.remaining = 0;
+    uint32_t sLL = 0, sOF = 0, sML = 0, h0 = sh.st.hist[0], h1 = sh.st.hist[1], h2 = sh.st.hist[2];
+    const int32_t rLL = sh.st.fse_rle[0], rOF = sh.st.fse_rle[1], rML = sh.st.fse_rle[2];
+    if (LANE == 0) {
+        int e = 0;
+        cz_rb_init(rb, blk + bc.bitstream_off, bsize - bc.bitstream_off);               /* :42-44 */
+        if (cz_rb_skip_padding(rb)) e = CZ_E_SEQ_EXTRA_PADDING;                          /* :46-64 */
+        /* init order LL, OF, ML (:207-218); a table that was never set is TableIsUninitialized */
+        if (!e && rLL < 0) { if (!sh.st.fse_log[0]) e = CZ_E_SEQ_TABLE_UNINIT; else sLL = cz_rb_get(rb, sh.st.fse_log[0]); }
+        if (!e && rOF < 0) { if (!sh.st.fse_log[1]) e = CZ_E_SEQ_TABLE_UNINIT; else sOF = cz_rb_get(rb, sh.st.fse_log[1]); }
+        if (!e && rML < 0) { if (!sh.st.fse_log[2]) e = CZ_E_SEQ_TABLE_UNINIT; else sML = cz_rb_get(rb, sh.st.fse_log[2]); }
+        bc.chunk_err = e;
+    }
+    __syncthreads();
+    { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+    int exec_err = 0;                                                   /* first execution error, reported only if the
+                                                                           rest of the section decodes (reference order) */
+    for (uint32_t done = 0; done < nseq; done += 64) {
+        const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
+        if (LANE == 0) {
+            int e = 0;
+            for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286 */
+                const uint32_t eLL = sh.st.fse[0][sLL], eOF = sh.st.fse[1][sOF], eML = sh.st.fse[2][sML];
+                const uint32_t ll_code = rLL >= 0 ? (uint32_t)rLL : CZ_FSE_SYM(eLL);
+                const uint32_t ml_code = rML >= 0 ? (uint32_t)rML : CZ_FSE_SYM(eML);
+                const uint32_t of_code = rOF >= 0 ? (uint32_t)rOF : CZ_FSE_SYM(eOF);
+                if (of_code >= 32) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
+                if (ll_code >= 36 || ml_code >= 53) { e = CZ_E_SEQ_TOO_MANY_BITS; break; } /* num_bits 255 -> TooManyBits :239 */
+                const uint32_t tl = sh.llml[ll_code], tm = sh.llml[40 + ml_code];
+                const uint32_t ob = cz_rb_get(rb, of_code), mb = cz_rb_get(rb, tm >> 24), lb = cz_rb_get(rb, tl >> 24); /* :239 */
+                const uint32_t ov = (1u << of_code) + ob, ll = (tl & 0xFFFFFFu) + lb, ml = (tm & 0xFFFFFFu) + mb;       /* :243-256 */
+                uint32_t actual = 1;
+                if (!exec_err) actual = cz_offset_history(ov, ll, h0, h1, h2);
+                sh.u.seq.ll[i] = ll; sh.u.seq.ml[i] = ml; sh.u.seq.off[i] = actual;
+                if (done + i + 1 < nseq) {                              /* :258-277 update order LL, ML, OF */
+                    if (rLL < 0) sLL = CZ_FSE_BASE(eLL) + cz_rb_get(rb, CZ_FSE_NB(eLL));
+                    if (rML < 0) sML = CZ_FSE_BASE(eML) + cz_rb_get(rb, CZ_FSE_NB(eML));
+                    if (rOF < 0) sOF = CZ_FSE_BASE(eOF) + cz_rb_get(rb, CZ_FSE_NB(eOF));
+                }
+                if (rb.remaining < 0) { e = CZ_E_SEQ_NOT_ENOUGH_BYTES; break; }         /* :281 */
+            }
+            if (!e && done + cnt >= nseq && rb.remaining > 0) e = CZ_E_SEQ_EXTRA_BITS;  /* :292 */
+            bc.chunk_err = e;
+        }
+        __syncthreads();
+        { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+        if (!exec_err) exec_err = cz_execute_chunk(sh, x, lit, cnt);
+        __syncthreads();
+    }
+    if (exec_err) return exec_err;
+    if (LANE == 0) { sh.st.hist[0] = h0; sh.st.hist[1] = h1; sh.st.hist[2] = h2; }
+    /* remaining literals (sequence_execution.cairo:72-78) */
+    if (x.lit_used < lit.len) {
+        const uint32_t rest = lit.len - x.lit_used;
+        if (x.produced + rest > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+        cz_lit_coop_copy(x.out + x.produced, lit, x.lit_used, rest);
+        x.produced += rest;
+    }
+    __syncthreads();
+    return 0;
+}
+
+/* ------------------------------------------------------------------ one compressed block */
+/* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
+__device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch) {
+    CzBroadcast& bc = sh.bc;
+    /* stage the head of the block for the serial header / tree parsers */
+    const uint32_t stage_hi = bsize < 512 ? bsize : 512;
+    for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.stage[i] = blk[i];
+    __syncthreads();
+    if (LANE == 0) bc.err = cz_parse_sections(sh, blk, bsize, stage_hi);
+    __syncthreads();
+    { const int e = bc.err; __syncthreads(); if (e) return e; }         /* read, then fence the slot before it is rewritten */
+    if (bc.huf_fill) { cz_huf_fill(sh, bc.huf_nsym); __syncthreads(); }
+    /* literals */
+    CzLit lit; lit.rle = 0; lit.byte = 0; lit.len = bc.regen; lit.p = blk;
+    const uint32_t lt = bc.lit_type, nseq_early = bc.seq_hdr_err ? 1u : bc.nseq;
+    const uint32_t lit_hdr = bc.lit_total - (lt >= 2 ? 0 : 0);
+    (void)lit_hdr;
+    if (lt == 0) { lit.p = blk + (bc.lit_total - bc.regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
+    else if (lt == 1) { lit.rle = 1; lit.byte = blk[bc.lit_total - 1]; } /* RLE :43-46 */
+    else {
+        uint8_t* target = lit_scratch;
+        if (nseq_early == 0) {                                          /* no sequences: decode straight into the output */
+            if (x.produced + bc.regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+            target = x.out + x.produced;
+        } else if (bc.regen > CZ_LIT_SCRATCH_BYTES) return CZ_E_UNSUPPORTED;
+        const int e = cz_decode_huf_literals(sh, blk, target);
+        if (e) return e;
+        lit.p = target;
+        __syncthreads();
+    }
+    if (bc.seq_hdr_err) return bc.seq_hdr_err;                          /* block_decoder.cairo:198-204 */
+    if (bc.nseq == 0) {                                                 /* :229-232 */
+        if (lt < 2) {
+            if (x.produced + lit.len > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+            cz_lit_coop_copy(x.out + x.produced, lit, 0, lit.len);
+        }
+        x.produced += lit.len;
+        __syncthreads();
+        return 0;
+    }
+    /* sequence tables */
+    const uint32_t so = bc.seq_body_off;
+    uint32_t st_lo = 0, st_hi = stage_hi;
+    if (so + 192 > stage_hi && so < bsize) {                            /* restage around the table descriptions */
+        __syncthreads();
+        st_lo = so; st_hi = bsize - so < 512 ? bsize : so + 512;
+        for (uint32_t i = st_lo + (uint32_t)LANE; i < st_hi; i += 64) sh.stage[i - st_lo] = blk[i];
+        __syncthreads();
+    }
+    if (LANE == 0) bc.err = cz_parse_seq_tables(sh, blk, bsize, st_lo, st_hi);
+    __syncthreads();
+    { const int e = bc.err; __syncthreads(); if (e) return e; }
+    if (LANE < 3 && ((bc.build_mask >> LANE) & 1u)) {
+        cz_fse_build(sh.st.fse[LANE], sh.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.counters[LANE]);
+        sh.st.fse_log[LANE] = (uint8_t)bc.acc_log[LANE];
+    }
+    __syncthreads();
+    x.lit_used = 0;
+    return cz_sequences(sh, blk, bsize, x, lit);
+}
+
+/* ------------------------------------------------------------------ one frame */
+struct CzFrameIO {
+    const uint8_t* src; uint64_t src_len;
+    uint8_t* dst; uint64_t dst_cap;
+    uint64_t produced, drained, window;
+    uint32_t parse_header, has_checksum, strategy, streaming; uint64_t strategy_n;
+};
+
+/* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
+__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, cz_frame_result* res) {
+    CzBroadcast& bc = sh.bc;
+    uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
+    if (io.parse_header) {
+        if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(io.src, io.src_len, bc); }
+        __syncthreads();
+        err = bc.err;
+        if (!err) { pos = bc.hdr_len; io.window = bc.window_size; io.has_checksum = bc.has_checksum; }
+        __syncthreads();
+    }
+    CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
+    const uint64_t produced0 = io.produced;
+    while (!err) {
+        /* block header (block_decoder.cairo:237-321) */
+        if (io.streaming && io.src_len - pos < 3) break;                /* frame_decoder.cairo:270 */
+        if (LANE == 0) {
+            int e = 0;
+            if (io.src_len - pos < 3) e = CZ_E_BH_TRUNCATED;
+            else {
+                const uint8_t* p = io.src + pos;
+                const uint32_t a = p[0], b = p[1], c = p[2], t = (a >> 1) & 3, size = (a >> 3) | (b << 5) | (c << 13);
+                if (t == 3) e = CZ_E_BH_RESERVED;
+                else if (size > 128u * 1024u) e = CZ_E_BH_SIZE_TOO_LARGE;
+                bc.btype = t; bc.bsize = size; bc.blast = a & 1;
+            }
+            bc.err = e;
+        }
+        __syncthreads();
+        err = bc.err;
+        const uint32_t btype = bc.btype, bsize = bc.bsize, blast = bc.blast;
+        __syncthreads();
+        if (err) break;
+        const uint64_t body = pos + 3, avail = io.src_len - body;
+        const uint32_t content = btype == 1 ? 1u : bsize;
+        if (io.streaming && avail < content) break;                     /* frame_decoder.cairo:282 */
+        if (avail < content) { err = CZ_E_BLOCK_TRUNCATED; break; }
+        if (btype == 0) {                                               /* Raw, block_decoder.cairo:97-103 */
+            if (x.produced + bsize > x.cap) { err = CZ_E_OUTPUT_TOO_SMALL; break; }
+            cz_coop_copy(x.out + x.produced, io.src + body, bsize);
+            x.produced += bsize;
+        } else if (btype == 1) {                                        /* RLE :104-123 */
+            if (x.produced + bsize > x.cap) { err = CZ_E_OUTPUT_TOO_SMALL; break; }
+            cz_coop_fill(x.out + x.produced, io.src[body], bsize);
+            x.produced += bsize;
+        } else {
+            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch);
+            if (err) break;
+        }
+        __syncthreads();
+        pos = body + content; blocks++;
+        if (blast) {                                                    /* frame_decoder.cairo:189-200 / :300-312 */
+            flags |= CZ_RESULT_FINISHED;
+            if (io.has_checksum) {
+                if (io.src_len - pos >= 4) {
+                    const uint8_t* p = io.src + pos;
+                    cksum = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                    flags |= CZ_RESULT_HAS_CHECKSUM; pos += 4;
+                } else if (!io.streaming) err = CZ_E_CHECKSUM_TRUNCATED;
+            }
+            break;
+        }
+        if (io.strategy == 1 && blocks >= io.strategy_n) break;         /* :204-208 */
+        if (io.strategy == 2 && x.produced - produced0 >= io.strategy_n) break;         /* :209-213 */
+    }
+    if (LANE == 0) {
+        res->status = err; res->blocks_decoded = blocks; res->bytes_consumed = pos; res->bytes_produced = x.produced;
+        res->checksum_from_data = cksum; res->flags = flags;
+        res->detail[0] = io.parse_header && (err == CZ_E_FH_SKIP_FRAME || err == CZ_E_FH_BAD_MAGIC) ? bc.d0 : blocks;
+        res->detail[1] = io.parse_header && err == CZ_E_FH_SKIP_FRAME ? bc.d1 : pos;
+    }
+    __syncthreads();
+}
+
+__device__ static void cz_state_reset(CzShared& sh) {                   /* scratch.cairo:23-40 */
+    if (LANE == 0) {
+        sh.st.hist[0] = 1; sh.st.hist[1] = 4; sh.st.hist[2] = 8;
+        sh.st.fse_rle[0] = sh.st.fse_rle[1] = sh.st.fse_rle[2] = -1;
+        sh.st.fse_log[0] = sh.st.fse_log[1] = sh.st.fse_log[2] = 0; sh.st.huf_max_bits = 0;
+    }
+}
+
+/* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 2) cz_decode_frames_kernel(cz_batch_args a) {
+    __shared__ CzShared sh;
+    for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
+    for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+    uint8_t* lit_scratch = a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride;
+    for (;;) {
+        __syncthreads();
+        if (LANE == 0) sh.frame_idx = atomicAdd(a.work_counter, 1u);
+        __syncthreads();
+        const uint32_t f = sh.frame_idx;
+        if (f >= a.n) break;
+        CzFrameIO io;
+        if (a.tasks) {
+            const cz_device_task t = a.tasks[f];
+            io.src = t.src; io.src_len = t.src_len; io.dst = t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
+            io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
+            io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming;
+            /* restore carried state */
+            uint32_t* d = (uint32_t*)&sh.st; const uint32_t* s = (const uint32_t*)t.state;
+            for (uint32_t i = (uint32_t)LANE; i < sizeof(cz_device_frame_state) / 4; i += 64) d[i] = s[i];
+            __syncthreads();
+            cz_run_frame(sh, io, lit_scratch, &a.results[f]);
+            uint32_t* d2 = (uint32_t*)t.state; const uint32_t* s2 = (const uint32_t*)&sh.st;
+            for (uint32_t i = (uint32_t)LANE; i < sizeof(cz_device_frame_state) / 4; i += 64) d2[i] = s2[i];
+        } else {
+            io.src = a.in_base + a.in_off[f]; io.src_len = a.in_len[f]; io.dst = a.out_base + a.out_off[f]; io.dst_cap = a.out_cap[f];
+            io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
+            io.strategy = 0; io.strategy_n = 0; io.streaming = 0;
+            cz_state_reset(sh);
+            __syncthreads();
+            cz_run_frame(sh, io, lit_scratch, &a.results[f]);
+            if (LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
+        }
+    }
+}

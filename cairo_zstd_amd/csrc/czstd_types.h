@@ -1,0 +1,46 @@
+/* czstd_types.h — structures shared by the host side (czstd_host.hip) and the kernels. */
+#ifndef CZSTD_TYPES_H
+#define CZSTD_TYPES_H
+
+#include <stdint.h>
+#include "cairo_zstd_amd.h"
+
+#define CZ_WG_THREADS 64                      /* one wavefront per frame */
+#define CZ_LIT_SCRATCH_BYTES (256 * 1024 + 256) /* Huffman regenerated size < 2^18 (literals_section.cairo:156-168) */
+
+/* Carried per-frame decoder state = the reference's DecoderScratch minus the buffers
+ * (src/decoding/scratch.cairo:11-19): Huffman table, three FSE tables + RLE symbols,
+ * offset history.  Only the resumable frame decoder saves / restores it between launches. */
+typedef struct cz_device_frame_state {
+    uint16_t huf[2048];
+    uint32_t fse[3][512];
+    uint32_t hist[3];
+    int32_t  fse_rle[3];
+    uint8_t  fse_log[3];
+    uint8_t  huf_max_bits;
+} cz_device_frame_state;
+
+/* One unit of work for the resumable path (cz_frame_decoder_*): decode blocks of ONE frame
+ * starting at a block header. */
+typedef struct cz_device_task {
+    const uint8_t* src; uint64_t src_len;     /* positioned at a block header */
+    uint8_t* dst; uint64_t dst_cap;           /* whole-frame output buffer */
+    uint64_t produced;                        /* bytes already in dst (total_output_counter) */
+    uint64_t drained;                         /* bytes the host already drained (buffer.len = produced - drained) */
+    uint64_t window_size;
+    uint32_t strategy; uint32_t _pad; uint64_t strategy_n;
+    uint32_t has_checksum; uint32_t streaming;/* streaming=1: decode_from_to semantics (stop quietly when short) */
+    cz_device_frame_state* state;             /* in/out */
+} cz_device_task;
+
+typedef struct cz_batch_args {
+    const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
+    uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
+    cz_frame_result* results;
+    const cz_device_task* tasks;              /* non-NULL: resumable path, one task per entry */
+    uint32_t n;
+    uint32_t* work_counter;                   /* zeroed before every launch */
+    uint8_t* lit_scratch; uint64_t lit_scratch_stride;   /* one region per resident workgroup */
+} cz_batch_args;
+
+#endif

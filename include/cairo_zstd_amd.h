@@ -1,0 +1,163 @@
+/*
+ * cairo_zstd_amd.h — C ABI of the MI355X-native zstd decoder (libcairo_zstd_amd.so).
+ *
+ * The reference (NethermindEth/cairo_zstd, pure Cairo 1) has no FFI of its own
+ * (SURVEY.md §8b); the boundary is therefore its *trait API*, re-exposed here as plain C:
+ * opaque handles, plain pointers and sizes, int32 status codes that map 1:1 onto the
+ * reference's error-enum leaves (cairo_zstd_amd_status.h).  Every entry point cites the
+ * reference interface it replaces (file:line relative to the reference tree).
+ * INTEGRATION.md shows the Cairo-runner-hint / ctypes binding a maintainer would add.
+ *
+ * Three layers:
+ *   1. cz_context_*        device context (HIP stream, scratch arenas).     [no reference analogue]
+ *   2. cz_decode_batch*    many independent frames in one launch — the GPU hot path.
+ *                          Semantics per frame = `_test_decode` (src/tests/decoding.cairo:4-21).
+ *   3. cz_frame_decoder_*  one resumable frame, mirrors FrameDecoderTrait
+ *                          (src/frame_decoder.cairo:107-335) call for call.
+ *   plus stateless header parsers mirroring read_frame_header / read_block_header.
+ *
+ * Threading: one context / frame decoder per host thread.  Batch calls are asynchronous on
+ * the context's HIP stream unless stated otherwise.  All compute runs on the device; there
+ * is no CPU decode path in this library — without a gfx950 device every compute entry
+ * returns CZ_E_NO_DEVICE.
+ */
+#ifndef CAIRO_ZSTD_AMD_H
+#define CAIRO_ZSTD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cairo_zstd_amd_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CZ_ABI_VERSION 1
+
+/* Per-frame result record written by the device (one per batch entry).  Mirrors what the
+ * reference exposes after decode_blocks: is_finished (frame_decoder.cairo:144),
+ * blocks_decoded (:152), bytes_read_from_source (:140), get_checksum_from_data (:129). */
+typedef struct cz_frame_result {
+    int32_t  status;            /* cz_status */
+    uint32_t blocks_decoded;
+    uint64_t bytes_consumed;    /* source bytes consumed, frame header and checksum included */
+    uint64_t bytes_produced;    /* decoded bytes written at out_base + out_off[i] */
+    uint32_t checksum_from_data;/* valid when flags & CZ_RESULT_HAS_CHECKSUM */
+    uint32_t flags;
+    uint64_t detail[2];         /* error payload (e.g. magic / skip length for CZ_E_FH_SKIP_FRAME,
+                                   block index and byte position for decode errors) */
+} cz_frame_result;
+#define CZ_RESULT_FINISHED     1u   /* last block seen (frame_finished, frame_decoder.cairo:190) */
+#define CZ_RESULT_HAS_CHECKSUM 2u
+
+/* ---------------------------------------------------------------- 1. context */
+typedef struct cz_context cz_context;
+
+int  cz_abi_version(void);
+/* Creates a decoder context on HIP device `device` (ordinal).  `stream` may be NULL (the
+ * context then owns a stream) or a hipStream_t cast to void*. */
+int  cz_context_create(cz_context** out, int device, void* stream);
+void cz_context_destroy(cz_context* ctx);
+int  cz_context_synchronize(cz_context* ctx);
+/* Last HIP error seen by this context (hipError_t), for CZ_E_HIP diagnostics. */
+int  cz_context_last_hip_error(const cz_context* ctx);
+/* Kernel-launch geometry actually used (for bench / roofline reports). */
+int  cz_context_launch_info(const cz_context* ctx, int* workgroups, int* threads_per_wg, int* compute_units);
+
+/* ------------------------------------------------------- 2. batch (GPU hot path) */
+/*
+ * Decodes n independent zstd frames.  Frame i occupies in_base[in_off[i] .. +in_len[i]) and is
+ * decoded to out_base[out_off[i] .. +out_cap[i]).  Each frame is handled exactly like the
+ * reference's end-to-end entry: FrameDecoderStateTrait::new (frame_decoder.cairo:54) ->
+ * decode_blocks(All) (:156) -> is_finished (:144); results[i] carries what the getters return.
+ * A frame that fails leaves its neighbours untouched.
+ *
+ * ALL pointers are DEVICE pointers (results too).  Asynchronous on the context stream.
+ * Returns CZ_OK when the launch was enqueued; per-frame outcomes are in results[].
+ */
+int cz_decode_batch_device(cz_context* ctx,
+                           const void* d_in_base, const uint64_t* d_in_off, const uint64_t* d_in_len, size_t n,
+                           void* d_out_base, const uint64_t* d_out_off, const uint64_t* d_out_cap,
+                           cz_frame_result* d_results);
+
+/* Same, with HOST buffers: stages the inputs to the device, decodes, copies outputs and
+ * results back, and synchronizes.  (PCIe-inclusive convenience path.) */
+int cz_decode_batch_host(cz_context* ctx,
+                         const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
+                         void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,
+                         cz_frame_result* results);
+
+/* Duration in milliseconds of the most recent decode launch on this context, measured with
+ * hipEvents recorded on the context stream around the kernel (bench.py's roofline leg).
+ * Blocks until that launch has finished. */
+int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
+
+/* ------------------------------------------------- stateless header parsers */
+/* read_frame_header (src/frame.cairo:152-284) + FrameHeaderTrait::window_size (:106-129). */
+typedef struct cz_frame_header {
+    uint8_t  descriptor;          /* FrameDescriptor (frame.cairo:25-27) */
+    uint8_t  window_descriptor;
+    uint8_t  has_dict_id;
+    uint8_t  header_len;          /* bytes consumed */
+    uint32_t dict_id;
+    uint64_t frame_content_size;
+    uint64_t window_size;
+} cz_frame_header;
+/* detail[0..1] = (magic, skip_len) for CZ_E_FH_SKIP_FRAME / CZ_E_FH_BAD_MAGIC; may be NULL. */
+int cz_read_frame_header(const uint8_t* src, size_t len, cz_frame_header* out, uint64_t* detail);
+
+/* BlockDecoderTrait::read_block_header (src/decoding/block_decoder.cairo:237-278);
+ * BlockHeader (src/blocks/block.cairo:10-15).  Always consumes 3 bytes. */
+typedef struct cz_block_header {
+    uint8_t  last_block;
+    uint8_t  block_type;          /* 0 Raw, 1 RLE, 2 Compressed (3 Reserved is an error) */
+    uint32_t decompressed_size;   /* Raw/RLE: size; Compressed: 0 = unknown */
+    uint32_t content_size;        /* Raw/Compressed: size; RLE: 1 */
+} cz_block_header;
+int cz_read_block_header(const uint8_t* src, size_t len, cz_block_header* out);
+
+/* ------------------------------------------- 3. resumable single-frame decoder */
+/* FrameDecoder / FrameDecoderState (src/frame_decoder.cairo:17-30).  Source and target are
+ * HOST buffers (as the reference's ByteArraySlice / ByteArray are); decoding runs on the
+ * device, the decoded frame stays resident in HBM until collected. */
+typedef struct cz_frame_decoder cz_frame_decoder;
+
+typedef enum cz_strategy {          /* BlockDecodingStrategy, frame_decoder.cairo:33-37 */
+    CZ_STRATEGY_ALL = 0,
+    CZ_STRATEGY_UPTO_BLOCKS = 1,
+    CZ_STRATEGY_UPTO_BYTES = 2
+} cz_strategy;
+
+int  cz_frame_decoder_create(cz_context* ctx, cz_frame_decoder** out);
+void cz_frame_decoder_destroy(cz_frame_decoder* fd);
+/* FrameDecoderStateTrait::new (frame_decoder.cairo:54-76): parses the frame header.
+ * *consumed = header bytes; detail as cz_read_frame_header. */
+int  cz_frame_decoder_new(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail);
+/* FrameDecoderStateTrait::reset (:78-104): same, plus the 100 MiB window cap (:92). */
+int  cz_frame_decoder_reset(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail);
+uint64_t cz_frame_decoder_content_size(const cz_frame_decoder* fd);                 /* :125 */
+int  cz_frame_decoder_checksum_from_data(const cz_frame_decoder* fd, uint32_t* v);  /* :129; returns 1 = Some */
+uint32_t cz_frame_decoder_calculated_checksum(const cz_frame_decoder* fd);          /* :133-138 (low 32 bits of XXH64 of
+                                                                                       the bytes drained so far) */
+uint64_t cz_frame_decoder_bytes_read_from_source(const cz_frame_decoder* fd);       /* :140 */
+int  cz_frame_decoder_is_finished(const cz_frame_decoder* fd);                      /* :144-150 */
+size_t cz_frame_decoder_blocks_decoded(const cz_frame_decoder* fd);                 /* :152 */
+/* decode_blocks (:156-222).  src points just past what earlier calls consumed.  *consumed =
+ * bytes taken by this call, *finished = frame_finished. */
+int  cz_frame_decoder_decode_blocks(cz_frame_decoder* fd, const uint8_t* src, size_t len, cz_strategy strategy,
+                                    size_t n, size_t* consumed, int* finished);
+size_t cz_frame_decoder_can_collect(const cz_frame_decoder* fd);                    /* :233-243 */
+/* collect (:224-231).  Returns 1 = Some (bytes moved into dst, *written set), 0 = None,
+ * <0 = -cz_status (dst too small: CZ_E_TARGET_TOO_SMALL). */
+int  cz_frame_decoder_collect(cz_frame_decoder* fd, uint8_t* dst, size_t cap, size_t* written);
+/* read (:328-334); returns bytes moved. */
+size_t cz_frame_decoder_read(cz_frame_decoder* fd, uint8_t* dst, size_t cap);
+/* decode_from_to (:245-326): (*read_len, *written) = (source bytes consumed, target bytes produced). */
+int  cz_frame_decoder_decode_from_to(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint8_t* dst, size_t cap,
+                                     size_t* read_len, size_t* written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAIRO_ZSTD_AMD_H */

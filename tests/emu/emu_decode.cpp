@@ -1,0 +1,92 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — runs cz_decode_frames_kernel (the unmodified kernel source) on
+ * the CPU through tests/emu/hip/hip_runtime.h, normally under ASan+UBSan.
+ * usage: emu_decode <batch.bin> <result.bin>
+ *   batch.bin : u64 n, then n x { u64 in_len, u64 out_cap, in bytes }
+ *   result.bin: n x { cz_frame_result, out bytes (bytes_produced) }
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+thread_local emu_dim3 threadIdx;
+thread_local emu_dim3 blockIdx;
+pthread_barrier_t emu_barrier;
+volatile uint64_t emu_xchg[64];
+void* volatile emu_site[64];
+void* volatile emu_ring[64][64];
+volatile uint64_t emu_sync_count[64];
+static volatile int emu_lane_done[64];
+#include <execinfo.h>
+#include <unistd.h>
+/* watchdog: if no lane passes a barrier for 20 s, print where every lane waits and abort */
+static void* emu_watchdog(void*) {
+    uint64_t last = 0; int idle = 0;
+    for (;;) {
+        sleep(1);
+        uint64_t sum = 0; for (int i = 0; i < 64; i++) sum += emu_sync_count[i];
+        if (sum != last) { last = sum; idle = 0; continue; }
+        if (++idle < 20) continue;
+        fprintf(stderr, "EMU HANG: barrier sites per lane (addr2line -e emu_decode <addr>):\n");
+        for (int i = 0; i < 64; i++) fprintf(stderr, "lane %d done=%d syncs=%llu site=%p\n", i, emu_lane_done[i], (unsigned long long)emu_sync_count[i], emu_site[i]);
+        for (int l = 0; l < 2; l++) { fprintf(stderr, "ring lane %d:", l); for (int k = 0; k < 64; k++) fprintf(stderr, " %p", emu_ring[l][(emu_sync_count[l] + 1 + k) & 63]); fprintf(stderr, "\n"); }
+        _exit(3);
+    }
+    return nullptr;
+}
+
+#include "czstd_kernels.hip"
+
+struct lane_arg { cz_batch_args a; unsigned lane, block; };
+static void* lane_main(void* p) {
+    lane_arg* la = (lane_arg*)p;
+    threadIdx.x = la->lane; blockIdx.x = la->block;
+    emu_lane_done[la->lane] = 0;
+    cz_decode_frames_kernel(la->a);
+    emu_lane_done[la->lane] = 1;
+    return nullptr;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
+    uint64_t n; if (fread(&n, 8, 1, f) != 1) return 2;
+    std::vector<uint64_t> in_off(n), in_len(n), out_off(n), out_cap(n);
+    std::vector<uint8_t> in; uint64_t out_total = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t l, c; if (fread(&l, 8, 1, f) != 1 || fread(&c, 8, 1, f) != 1) return 2;
+        in_off[i] = in.size(); in_len[i] = l; out_cap[i] = c; out_off[i] = out_total; out_total += c;
+        size_t at = in.size(); in.resize(at + l);
+        if (l && fread(in.data() + at, 1, l, f) != l) return 2;
+    }
+    fclose(f);
+    /* exact-size heap blocks so that ASan sees any byte read or written out of range */
+    uint8_t* in_exact = (uint8_t*)malloc(in.size() ? in.size() : 1); if (in.size()) memcpy(in_exact, in.data(), in.size());
+    uint8_t* out = (uint8_t*)malloc(out_total ? out_total : 1); memset(out, 0xEE, out_total);
+    std::vector<cz_frame_result> res(n);
+    uint32_t counter = 0;
+    const int grid = 2;
+    uint8_t* lit = (uint8_t*)malloc((size_t)grid * CZ_LIT_SCRATCH_BYTES);
+    cz_batch_args a; memset(&a, 0, sizeof a);
+    a.in_base = in_exact; a.in_off = in_off.data(); a.in_len = in_len.data();
+    a.out_base = out; a.out_off = out_off.data(); a.out_cap = out_cap.data();
+    a.results = res.data(); a.tasks = nullptr; a.n = (uint32_t)n; a.work_counter = &counter;
+    a.lit_scratch = lit; a.lit_scratch_stride = CZ_LIT_SCRATCH_BYTES;
+    pthread_barrier_init(&emu_barrier, nullptr, 64);
+    { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
+    for (int b = 0; b < grid; b++) {
+        pthread_t th[64]; lane_arg la[64];
+        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
+        for (unsigned l = 0; l < 64; l++) pthread_join(th[l], nullptr);
+    }
+    FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
+    for (uint64_t i = 0; i < n; i++) {
+        fwrite(&res[i], sizeof(cz_frame_result), 1, g);
+        uint64_t w = res[i].bytes_produced <= out_cap[i] ? res[i].bytes_produced : out_cap[i];
+        fwrite(out + out_off[i], 1, w, g);
+    }
+    fclose(g);
+    free(in_exact); free(out); free(lit);
+    return 0;
+}

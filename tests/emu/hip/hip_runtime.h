@@ -1,0 +1,52 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — a minimal CPU stand-in for the handful of HIP device
+ * constructs czstd_kernels.hip uses, so the *unmodified kernel source* can be compiled with
+ * g++ and run under AddressSanitizer/UBSan (GPU sanitizers are not available on the pool).
+ * One emulated workgroup at a time, 64 pthreads = 64 lanes, pthread barriers for
+ * __syncthreads and the cross-lane intrinsics.  Never linked into the product library.
+ */
+#pragma once
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct emu_dim3 { unsigned x, y, z; };
+extern thread_local emu_dim3 threadIdx;
+extern thread_local emu_dim3 blockIdx;
+struct uint4 { uint32_t x, y, z, w; };
+
+extern pthread_barrier_t emu_barrier;
+extern volatile uint64_t emu_xchg[64];
+
+extern void* volatile emu_site[64];          /* last barrier site per lane (hang diagnosis) */
+extern volatile uint64_t emu_sync_count[64];
+extern void* volatile emu_ring[64][64];
+static inline void emu_note(void* site) { emu_ring[threadIdx.x][emu_sync_count[threadIdx.x] & 63] = site; }
+static inline void emu_sync() { emu_sync_count[threadIdx.x]++; pthread_barrier_wait(&emu_barrier); }
+#define __syncthreads() do { __label__ emu_here; emu_here: emu_site[threadIdx.x] = &&emu_here; emu_note(&&emu_here); emu_sync(); } while (0)
+template <class T> __attribute__((noinline)) static T __shfl(T v, int src) {
+    emu_note(__builtin_return_address(0));
+    uint64_t raw = 0; memcpy(&raw, &v, sizeof(T)); emu_xchg[threadIdx.x] = raw; emu_sync();
+    uint64_t r = emu_xchg[src & 63]; emu_sync(); T out; memcpy(&out, &r, sizeof(T)); return out;
+}
+template <class T> __attribute__((noinline)) static T __shfl_up(T v, unsigned d) {
+    emu_note(__builtin_return_address(0));
+    uint64_t raw = 0; memcpy(&raw, &v, sizeof(T)); emu_xchg[threadIdx.x] = raw; emu_sync();
+    uint64_t r = threadIdx.x >= d ? emu_xchg[threadIdx.x - d] : raw; emu_sync(); T out; memcpy(&out, &r, sizeof(T)); return out;
+}
+__attribute__((noinline)) static unsigned long long __ballot(int pred) {
+    emu_note(__builtin_return_address(0));
+    emu_xchg[threadIdx.x] = pred ? 1 : 0; emu_sync();
+    unsigned long long m = 0; for (int i = 0; i < 64; i++) if (emu_xchg[i]) m |= 1ull << i;
+    emu_sync(); return m;
+}
+static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

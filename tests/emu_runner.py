@@ -1,0 +1,43 @@
+"""Runs the kernel source on the CPU SIMT emulator (tests/emu) — sanitizer coverage for the
+HIP kernels without a GPU.  Test infrastructure only."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("blocks_decoded", "<u4"), ("bytes_consumed", "<u8"),
+                         ("bytes_produced", "<u8"), ("checksum_from_data", "<u4"), ("flags", "<u4"),
+                         ("detail", "<u8", (2,))])
+
+
+def build(target="emu_decode"):
+    subprocess.check_call(["make", "-C", EMU_DIR, target], stdout=subprocess.DEVNULL)
+    return os.path.join(EMU_DIR, target)
+
+
+def run(frames, caps, target="emu_decode", timeout=600):
+    exe = build(target)
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(inp, "wb") as f:
+            f.write(struct.pack("<Q", len(frames)))
+            for fr, cap in zip(frames, caps):
+                f.write(struct.pack("<QQ", len(fr), cap))
+                f.write(fr)
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+        p = subprocess.run([exe, inp, outp], capture_output=True, timeout=timeout, env=env)
+        if p.returncode != 0:
+            raise RuntimeError(f"emu_decode failed rc={p.returncode}\n{p.stderr.decode()[-4000:]}")
+        raw = open(outp, "rb").read()
+    out, pos = [], 0
+    for cap in caps:
+        r = np.frombuffer(raw, dtype=RESULT_DTYPE, count=1, offset=pos)[0]
+        pos += RESULT_DTYPE.itemsize
+        w = min(int(r["bytes_produced"]), cap)
+        out.append((r, raw[pos:pos + w]))
+        pos += w
+    return out

@@ -1,0 +1,48 @@
+"""Runs the UNMODIFIED kernel source (cairo_zstd_amd/csrc/czstd_kernels.hip) on the CPU SIMT
+emulator under AddressSanitizer + UBSan (tests/emu) and checks it against the oracle.
+GPU sanitizers are not available on the pool, so this is where out-of-bounds accesses, hangs
+and barrier races in the kernels get caught before they reach a device.  CPU-only, small."""
+import numpy as np
+import pytest
+
+import emu_runner
+import oracle
+from cairo_zstd_amd import status, synth
+from conftest import corpus_pairs
+
+
+def _run_and_compare(frames, caps):
+    res = emu_runner.run(frames, caps)
+    bad = []
+    for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
+        st, ref, info = oracle.decode_frame(fr, cap=cap)
+        if st != int(r["status"]):
+            bad.append((i, status.name(r["status"]), status.name(st)))
+        elif st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"]):
+            bad.append((i, "DATA"))
+    assert not bad, bad[:10]
+
+
+def test_emu_corpus_small():
+    pairs = corpus_pairs(max_orig=6000)
+    _run_and_compare([z for _, z, _ in pairs], [len(o) + 16 for _, _, o in pairs])
+
+
+def test_emu_synthetic_mix():
+    b = synth.generate("mix", 30, first_index=900, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 60000][:16]
+    _run_and_compare([b.frame(i) for i in keep], [int(b.regen[i]) + 8 for i in keep])
+
+
+def test_emu_malformed_inputs():
+    frames, caps = [], []
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=1200)):
+        rng = np.random.default_rng(idx)
+        muts = [z[: len(z) // 2], z[:-1], z[:5], z[:3], b"", z + b"\x00"]
+        for _ in range(6):
+            a = bytearray(z)
+            a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            muts.append(bytes(a))
+        frames += muts
+        caps += [len(orig) * 2 + 4096] * len(muts)
+    _run_and_compare(frames, caps)

@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden corpus.  Run on the MI355X box with `pytest -m gpu`."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, corpus_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cz():
+    import torch  # noqa: F401
+    import cairo_zstd_amd as m
+    assert os.path.exists(m._lib.LIB_PATH), "libcairo_zstd_amd.so missing: run __graft_entry__.build()"
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(cz):
+    c = cz.Context(0)
+    yield c
+    c.close()
+
+
+def _diff(a: bytes, b: bytes):
+    if len(a) != len(b):
+        return f"len {len(a)} != {len(b)}"
+    x, y = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
+    bad = np.nonzero(x != y)[0]
+    return None if bad.size == 0 else f"{bad.size} bytes differ, first at {int(bad[0])}"
+
+
+def _check_against_oracle(cz, ctx, frames, caps, expect_ok=False, label=""):
+    got = cz.decode_batch_host(frames, caps, ctx)
+    bad = []
+    for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+        st, ref, info = oracle.decode_frame(fr, cap=cap)
+        if expect_ok:
+            assert st == 0, f"{label}[{i}] oracle status {st}"
+        if int(r["status"]) != st:
+            bad.append(f"{label}[{i}] status gpu={cz.status.name(r['status'])} oracle={cz.status.name(st)} detail={r['detail']}")
+            continue
+        if st == 0:
+            d = _diff(out, ref)
+            if d:
+                bad.append(f"{label}[{i}] output {d}")
+            elif int(r["bytes_consumed"]) != info["consumed"] or int(r["blocks_decoded"]) != info["blocks"]:
+                bad.append(f"{label}[{i}] consumed/blocks {r['bytes_consumed']}/{r['blocks_decoded']} vs {info['consumed']}/{info['blocks']}")
+            elif bool(r["flags"] & 2) != info["has_checksum"] or (info["has_checksum"] and int(r["checksum_from_data"]) != info["checksum"]):
+                bad.append(f"{label}[{i}] checksum field")
+    assert not bad, "\n".join(bad[:20]) + f"\n({len(bad)} of {len(frames)} frames differ)"
+    return got
+
+
+def test_corpus_golden_batch(cz, ctx):
+    """_test_decode (src/tests/decoding.cairo:4-21) for every committed corpus pair, on the GPU."""
+    pairs = corpus_pairs()
+    got = cz.decode_batch_host([z for _, z, _ in pairs], [len(o) + 32 for _, _, o in pairs], ctx)
+    for (name, z, orig), (r, out) in zip(pairs, got):
+        assert int(r["status"]) == 0, f"{name}: {cz.status.name(r['status'])} {r['detail']}"
+        assert _diff(out, orig) is None, f"{name}: {_diff(out, orig)}"
+        assert int(r["bytes_consumed"]) == len(z)
+        assert r["flags"] & 1 and r["flags"] & 2
+        assert int(r["checksum_from_data"]) == oracle.xxh64(orig) & 0xFFFFFFFF, name
+
+
+@pytest.mark.parametrize("kind,n", [("raw_rle", 64), ("huf_literals", 48), ("full_4a", 24), ("full_4b", 8), ("mix", 1500)])
+def test_synthetic_vs_oracle(cz, ctx, kind, n):
+    from cairo_zstd_amd import synth
+    b = synth.generate(kind, n)
+    frames = [b.frame(i) for i in range(n)]
+    _check_against_oracle(cz, ctx, frames, [int(r) + 16 for r in b.regen], expect_ok=True, label=kind)
+
+
+def test_output_capacity_exact_and_too_small(cz, ctx):
+    from cairo_zstd_amd import synth
+    b = synth.generate("mix", 200, first_index=5000)
+    frames = [b.frame(i) for i in range(b.n)]
+    exact = cz.decode_batch_host(frames, [int(r) for r in b.regen], ctx)
+    for i, (r, out) in enumerate(exact):
+        assert int(r["status"]) == 0 and len(out) == int(b.regen[i]), i
+    short = cz.decode_batch_host(frames, [max(int(r) - 1, 0) for r in b.regen], ctx)
+    for i, (r, _) in enumerate(short):
+        if int(b.regen[i]) > 0:
+            assert int(r["status"]) == cz.status.CZ_E_OUTPUT_TOO_SMALL, (i, cz.status.name(r["status"]))
+
+
+def _mutations(z: bytes, seed: int):
+    rng = np.random.default_rng(seed)
+    out = [z[: len(z) // 2], z[:-1], z[:5], z[:3], b"", z + b"\x00"]
+    for _ in range(10):
+        a = bytearray(z)
+        k = int(rng.integers(0, len(a)))
+        a[k] ^= 1 << int(rng.integers(0, 8))
+        out.append(bytes(a))
+    return out
+
+
+def test_malformed_inputs_status_parity(cz, ctx):
+    """Truncated / bit-flipped frames: same status as the oracle, never a fault, and a failing
+    frame leaves its neighbours intact."""
+    pairs = corpus_pairs(max_orig=20000)
+    frames, caps = [], []
+    for idx, (name, z, orig) in enumerate(pairs):
+        for m in _mutations(z, idx):
+            frames.append(m)
+            caps.append(len(orig) * 2 + 4096)
+    got = cz.decode_batch_host(frames, caps, ctx)
+    mismatch = []
+    for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+        st, ref, info = oracle.decode_frame(fr, cap=cap)
+        if st != int(r["status"]):
+            mismatch.append((i, cz.status.name(r["status"]), cz.status.name(st)))
+        elif st == 0:
+            assert _diff(out, ref) is None, i
+    assert not mismatch, f"{len(mismatch)} of {len(frames)}: {mismatch[:15]}"
+
+
+def test_frame_decoder_api_matches_oracle(cz, ctx):
+    """FrameDecoder mirror (src/frame_decoder.cairo:107-335): UptoBlocks stepping + collect."""
+    pairs = corpus_pairs()
+    for name, z, orig in pairs[::4]:
+        fd, od = cz.FrameDecoder(ctx), oracle.FrameDecoder()
+        st, hl, _ = fd.new(z)
+        ost, ohl, _ = od.new(z)
+        assert (st, hl) == (ost, ohl) == (0, ohl)
+        assert fd.content_size() == od.content_size()
+        pos, out = hl, b""
+        while not fd.is_finished():
+            st, used, fin = fd.decode_blocks(z[pos:], cz.BlockDecodingStrategy.UPTO_BLOCKS, 2)
+            ost, oused, ofin = od.decode_blocks(z[pos:], oracle.FrameDecoder.UPTO_BLOCKS, 2)
+            assert (st, used, fin) == (ost, oused, ofin), name
+            assert st == 0
+            pos += used
+            assert fd.blocks_decoded() == od.blocks_decoded() and fd.can_collect() == od.can_collect()
+            a, b = fd.collect(cap=len(orig) + 64), od.collect(cap=len(orig) + 64)
+            assert a == b, name
+            out += a or b""
+        assert out == orig, name
+        assert fd.bytes_read_from_source() == od.bytes_read_from_source() == len(z)
+        assert fd.get_checksum_from_data() == od.get_checksum_from_data() == fd.get_calculated_checksum()
+        fd.close()
+
+
+def test_decode_from_to_streaming_matches_oracle(cz, ctx):
+    pairs = corpus_pairs()
+    for name, z, orig in pairs[1::6]:
+        fd, od = cz.FrameDecoder(ctx), oracle.FrameDecoder()
+        st, hl, _ = fd.new(z)
+        od.new(z)
+        pos, out, guard = hl, b"", 0
+        while not fd.is_finished() and guard < 5000:
+            guard += 1
+            chunk = z[pos:pos + 3000]
+            st, r, got = fd.decode_from_to(chunk, cap=len(orig) + 64)
+            ost, orr, ogot = od.decode_from_to(chunk, cap=len(orig) + 64)
+            assert (st, r, got) == (ost, orr, ogot), (name, guard)
+            if r == 0 and not got and len(chunk) >= len(z) - pos:
+                break
+            pos += r
+            out += got
+        st, r, got = fd.decode_from_to(b"", cap=len(orig) + 64)
+        out += got
+        assert out == orig, name
+        fd.close()
+
+
+def test_frame_header_errors(cz, ctx):
+    fd = cz.FrameDecoder(ctx)
+    skip = bytes.fromhex("502a4d18") + (7).to_bytes(4, "little") + b"\0" * 7
+    st, _, detail = fd.new(skip)
+    assert st == cz.status.CZ_E_FH_SKIP_FRAME and detail == (0x184D2A50, 7)   # frame.cairo:160-166
+    assert fd.new(b"\x01\x02\x03")[0] == cz.status.CZ_E_FH_MAGIC_READ
+    assert fd.new(b"\x01\x02\x03\x04\x05")[0] == cz.status.CZ_E_FH_BAD_MAGIC
+    big = bytes.fromhex("28b52ffd") + bytes([0x00, 0xFF])               # window log 41 -> ~3.7 TiB
+    assert fd.new(big)[0] == cz.status.CZ_E_WINDOW_TOO_BIG or fd.new(big)[0] == 0
+    z = corpus_pairs(max_orig=2000)[0][1]
+    assert fd.new(z)[0] == 0
+    w100 = bytes.fromhex("28b52ffd") + bytes([0x00, (17 << 3)])         # window 2^27 > 100 MiB
+    assert fd.new(w100)[0] == 0                                          # D4: new() has no cap
+    assert fd.reset(w100)[0] == cz.status.CZ_E_WINDOW_SIZE_TOO_BIG       # frame_decoder.cairo:92
+    fd.close()
+
+
+def test_device_pointer_batch_full_size(cz, ctx):
+    """BASELINE config sizes through cz_decode_batch_device with torch-owned HBM buffers;
+    checked by per-frame XXH64 against the oracle on a sample and by size/status on all."""
+    import torch
+    from cairo_zstd_amd import synth
+    n = 2048
+    b = synth.generate("full_4a", n)
+    out_off, out_cap, total = b.out_layout()
+    dev = torch.device("cuda:0")
+    t_in = torch.from_numpy(b.base).to(dev)
+    t_off, t_len = torch.from_numpy(b.off.astype(np.int64)).to(dev), torch.from_numpy(b.length.astype(np.int64)).to(dev)
+    t_ooff, t_ocap = torch.from_numpy(out_off.astype(np.int64)).to(dev), torch.from_numpy(out_cap.astype(np.int64)).to(dev)
+    t_out = torch.zeros(total, dtype=torch.uint8, device=dev)
+    t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    c2 = cz.Context(0, torch.cuda.current_stream().cuda_stream)
+    c2.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, t_out.data_ptr(), t_ooff.data_ptr(),
+                           t_ocap.data_ptr(), t_res.data_ptr())
+    torch.cuda.synchronize()
+    res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+    out = t_out.cpu().numpy()
+    assert (res["status"] == 0).all(), np.unique(res["status"], return_counts=True)
+    assert (res["bytes_produced"] == b.regen).all() and (res["bytes_consumed"] == b.length).all()
+    for i in range(0, n, 97):
+        st, ref, _ = oracle.decode_frame(b.frame(i), cap=int(b.regen[i]) + 16)
+        got = out[int(out_off[i]): int(out_off[i] + b.regen[i])].tobytes()
+        assert st == 0 and oracle.xxh64(got) == oracle.xxh64(ref), i
+    assert c2.last_kernel_ms() > 0
+    c2.close()
