@@ -70,7 +70,7 @@ def main():
 
     # ---- synthetic batch for this rank (frames rank*F .. rank*F+F-1 of the global batch)
     F = args.frames
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.time()
     batch = synth.generate(args.workload, F, first_index=rank * F, nthreads=max(1, min(32, ncpu // max(1, min(world, 8)))))
     gen_s = time.time() - t0

@@ -10,6 +10,7 @@ All decoding runs in the HIP kernels; nothing here decodes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -38,9 +39,12 @@ class Context:
             self._h = None
             raise CzError(st, "cz_context_create")
         self.device = device
+        self._decoders = weakref.WeakSet()
 
     def close(self):
         if getattr(self, "_h", None):
+            for fd in list(self._decoders):      # frame decoders hold device memory of this context
+                fd.close()
             lib().cz_context_destroy(self._h)
             self._h = None
 
@@ -145,6 +149,7 @@ class FrameDecoder:
         if st:
             self._h = None
             raise CzError(st, "cz_frame_decoder_create")
+        ctx._decoders.add(self)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -154,15 +154,17 @@ def test_decode_from_to_streaming_matches_oracle(cz, ctx):
         fd, od = cz.FrameDecoder(ctx), oracle.FrameDecoder()
         st, hl, _ = fd.new(z)
         od.new(z)
-        pos, out, guard = hl, b"", 0
+        pos, out, guard, step = hl, b"", 0, 3000
         while not fd.is_finished() and guard < 5000:
             guard += 1
-            chunk = z[pos:pos + 3000]
+            chunk = z[pos:pos + step]
             st, r, got = fd.decode_from_to(chunk, cap=len(orig) + 64)
             ost, orr, ogot = od.decode_from_to(chunk, cap=len(orig) + 64)
             assert (st, r, got) == (ost, orr, ogot), (name, guard)
-            if r == 0 and not got and len(chunk) >= len(z) - pos:
-                break
+            assert st == 0
+            if r == 0 and not got:
+                assert len(chunk) < len(z) - pos, name      # a whole block did not fit: feed more
+                step *= 2
             pos += r
             out += got
         st, r, got = fd.decode_from_to(b"", cap=len(orig) + 64)
