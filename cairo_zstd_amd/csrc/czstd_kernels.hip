@@ -27,6 +27,9 @@
 #include "czstd_types.h"
 
 #define LANE ((int)threadIdx.x)
+#define CZ_RING_BYTES 2048u
+#define CZ_RING_BLOCK 1024u
+#define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
 
 
 /* ------------------------------------------------------------------ LDS layout */
@@ -53,7 +56,8 @@ struct CzShared {
     int16_t  probs[3][256];
     uint16_t counters[3][256];
     uint8_t  stage[512];
-    union { uint32_t wtab[512]; struct { uint32_t ll[64], ml[64], off[64]; } seq; } u;
+    union { uint32_t wtab[512]; struct { int32_t pos[64]; uint32_t st[64]; } rec; } u;   /* weights FSE table | chain records */
+    __attribute__((aligned(16))) uint8_t ring[CZ_RING_BYTES];   /* sequences bitstream, indexed by absolute address */
     uint8_t  hbits[264];
     uint16_t sym_base[264];
     uint32_t llml[96];                 /* [0..35] LL base | bits<<24, [40..92] ML */
@@ -159,10 +163,21 @@ __device__ static inline int cz_fb_get(CzFBits& f, uint32_t n, uint32_t* out) {
 }
 
 /* ------------------------------------------------------------------ FSE tables */
-/* packed entry: symbol | num_bits << 8 | base_line << 16  (fse_decoder.cairo:49-53) */
+/* packed entry (fse_decoder.cairo:49-53 plus what the sequence chain needs in ONE lookup):
+ *   [7:0] symbol  [11:8] num_bits  [16:12] extra bits of the symbol's LL/ML/OF code
+ *   [17] code out of range (LL >= 36, ML >= 53, OF >= 32)  [29:20] base_line */
 #define CZ_FSE_SYM(e) ((e) & 0xFFu)
-#define CZ_FSE_NB(e) (((e) >> 8) & 0xFFu)
-#define CZ_FSE_BASE(e) ((e) >> 16)
+#define CZ_FSE_NB(e) (((e) >> 8) & 0xFu)
+#define CZ_FSE_XB(e) (((e) >> 12) & 0x1Fu)
+#define CZ_FSE_INV(e) (((e) >> 17) & 1u)
+#define CZ_FSE_BASE(e) ((e) >> 20)
+/* extra-bits / validity part of an entry for symbol s of table kind (0 LL, 1 OF, 2 ML, 3 none) */
+__device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_t kind, uint32_t s) {
+    if (kind == 0) return s < 36 ? (llml[s] >> 24) << 12 : (1u << 17);
+    if (kind == 1) return s < 32 ? s << 12 : (1u << 17);
+    if (kind == 2) return s < 53 ? (llml[40 + s] >> 24) << 12 : (1u << 17);
+    return 0;
+}
 
 /* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
 __device__ static int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
@@ -197,12 +212,13 @@ __device__ static int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* 
 }
 /* build_decoding_table (fse_decoder.cairo:156-256).  One lane per table; lanes 0..2 run it
  * side by side on different tables. */
-__device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters) {
+__device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters,
+                                    const uint32_t* llml, uint32_t kind) {
     const uint32_t size = 1u << log;
     uint32_t neg = size;
     for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
         counters[s] = 0;
-        if (probs[s] == -1) { neg--; table[neg] = s | (log << 8); }
+        if (probs[s] == -1) { neg--; table[neg] = s | (log << 8) | cz_fse_code_bits(llml, kind, s); }
     }
     uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     for (uint32_t s = 0; s < nprobs; s++) {                             /* :190-226 */
@@ -219,7 +235,7 @@ __device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint3
         uint32_t dbl = slices - n, single = n - dbl, width = size / slices, nb = cz_hbs(width) - 1, bl;
         if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
         else bl = (k - dbl) * width;
-        table[i] = s | (nb << 8) | (bl << 16);
+        table[i] = s | (nb << 8) | (bl << 20) | cz_fse_code_bits(llml, kind, s);
     }
 }
 
@@ -246,7 +262,7 @@ __device__ static int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint3
         int e = cz_fse_read_probs(br, 100, sh.probs[0], &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
         if (e) return e;
         if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
-        cz_fse_build(sh.u.wtab, sh.probs[0], nprobs, log, sh.counters[0]);
+        cz_fse_build(sh.u.wtab, sh.probs[0], nprobs, log, sh.counters[0], sh.llml, 3);
         CzRBits rb; cz_rb_init(rb, g + goff + 1 + fse_bytes, header - fse_bytes);       /* :190-202 */
         if (cz_rb_skip_padding(rb)) return CZ_E_HUF_EXTRA_PADDING;      /* :206-225 */
         uint32_t d1 = sh.u.wtab[cz_rb_get(rb, log)];                    /* :227 */
@@ -554,11 +570,11 @@ struct CzExecCtx {
     uint32_t lit_used;
 };
 
-/* execute up to 64 decoded sequences (sh.u.seq.*), all lanes.  sequence_execution.cairo:12-66,
- * decode_buffer.cairo:62-133.  Returns status (uniform). */
-__device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt) {
+/* execute up to 64 decoded sequences, one per lane (ll, ml, off = resolved offset).
+ * sequence_execution.cairo:12-66, decode_buffer.cairo:62-133.  Returns status (uniform). */
+__device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
     const int active = (uint32_t)LANE < cnt;
-    const uint32_t ll = active ? sh.u.seq.ll[LANE] : 0, ml = active ? sh.u.seq.ml[LANE] : 0, off = active ? sh.u.seq.off[LANE] : 1;
+    if (!active) { ll = 0; ml = 0; off = 1; }
     const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
     const uint32_t sum_ll = __shfl(incl_ll, 63), sum_tot = __shfl(incl_tot, 63);
     const uint32_t lit_start = x.lit_used + (incl_ll - ll);
@@ -631,59 +647,189 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
     return 0;
 }
 
+/* ---- sequences bitstream ring (LDS) ------------------------------------------------------
+ * The reversed bitstream [S, E) is staged into sh.ring by coalesced 16-byte loads, indexed by
+ * ABSOLUTE address (ring[a & 2047]) so that global and LDS accesses are both 16-byte aligned.
+ * Bytes outside [S, E) are written as zero, which is exactly the reference reader's
+ * zero-extension below bit 0 (bit_reader_reverse.cairo:147-159). */
+__device__ static void cz_ring_load_block(CzShared& sh, const uint8_t* S, const uint8_t* E, uintptr_t block) {
+    const uintptr_t a = block + 16u * (uintptr_t)LANE;
+    uint4 v;
+    if (a >= (uintptr_t)S && a + 16 <= (uintptr_t)E) v = *(const uint4*)a;
+    else {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= (uintptr_t)S && q < (uintptr_t)E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    }
+    *(uint4*)&sh.ring[a & (CZ_RING_BYTES - 1)] = v;
+}
+/* 64 stream bits whose most significant bit is stream bit t (t >= 0); lower bits follow */
+__device__ static inline uint64_t cz_ring_window(const CzShared& sh, uint32_t sbits, int32_t t) {
+    const uint32_t g = sbits + (uint32_t)t, wi = g >> 5, r = (g & 31) + 1;
+    const uint32_t* rw = (const uint32_t*)sh.ring;
+    const uint32_t M = CZ_RING_BYTES / 4 - 1;
+    const uint32_t w2 = rw[wi & M], w1 = rw[(wi - 1) & M], w0 = rw[(wi - 2) & M];
+    const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> r), lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> r);
+    return ((uint64_t)hi << 32) | lo;
+}
+/* n-bit field (n <= 32) starting o bits below the top of W (o + n <= 64) */
+__device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) { return (uint32_t)(((W << o) >> 1) >> (63 - n)); }
+
+/* offset-history transforms (sequence_execution.cairo:85-129) as composable maps: each of the
+ * three slots is either a constant (src 3) or old[src] + val.  s packs the three srcs. */
+struct CzHist { uint32_t s, v0, v1, v2; };
+__device__ static inline uint32_t cz_hist_pick(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+/* apply P, then Q */
+__device__ static inline CzHist cz_hist_compose(const CzHist& P, const CzHist& Q) {
+    CzHist R; uint32_t rs = 0;
+    const uint32_t p0 = P.s & 3, p1 = (P.s >> 2) & 3, p2 = (P.s >> 4) & 3;
+    for (int k = 0; k < 3; k++) {
+        const uint32_t qs = (Q.s >> (2 * k)) & 3, qv = k == 0 ? Q.v0 : (k == 1 ? Q.v1 : Q.v2);
+        uint32_t s_, v_;
+        if (qs == 3) { s_ = 3; v_ = qv; }
+        else { s_ = cz_hist_pick(qs, p0, p1, p2); v_ = cz_hist_pick(qs, P.v0, P.v1, P.v2) + qv; }
+        rs |= s_ << (2 * k);
+        if (k == 0) R.v0 = v_; else if (k == 1) R.v1 = v_; else R.v2 = v_;
+    }
+    R.s = rs; return R;
+}
+__device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint32_t h0, uint32_t h1, uint32_t h2) {
+    return src == 3 ? val : cz_hist_pick(src, h0, h1, h2) + val;
+}
+
 /* decode_sequences + execute_sequences for one block.  All lanes.
- * sequence_section_decoder.cairo:35-297, sequence_execution.cairo:12-83. */
+ * sequence_section_decoder.cairo:35-297, sequence_execution.cairo:12-83.
+ * Lane 0 runs only the serial core of the three interleaved FSE state machines (one LDS
+ * round trip per sequence: three table entries + the bit window) and records (bit position,
+ * states) per sequence; the 64 lanes then extract the extra bits, resolve repeat offsets with
+ * a wave scan over history transforms and execute their sequence. */
 __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit) {
     CzBroadcast& bc = sh.bc;
     const uint32_t nseq = bc.nseq;
-    /* lane-0 private decoder state */
-    CzRBits rb; rb.base = blk; rb.bytes_left = 0; rb.buf = 0; rb.avail = 0; rb.remaining = 0;
-    uint32_t sLL = 0, sOF = 0, sML = 0, h0 = sh.st.hist[0], h1 = sh.st.hist[1], h2 = sh.st.hist[2];
+    const uint8_t* S = blk + bc.bitstream_off; const uint8_t* E = blk + bsize;
+    const uint32_t sbits = (uint32_t)((uintptr_t)S & (CZ_RING_BYTES - 1)) * 8u;
+    __syncthreads();
+    /* per-table constants: RLE tables behave like a one-entry table (num_bits 0, base 0) */
     const int32_t rLL = sh.st.fse_rle[0], rOF = sh.st.fse_rle[1], rML = sh.st.fse_rle[2];
+    const uint32_t fLL = rLL >= 0 ? ((uint32_t)rLL | cz_fse_code_bits(sh.llml, 0, (uint32_t)rLL)) : 0;
+    const uint32_t fOF = rOF >= 0 ? ((uint32_t)rOF | cz_fse_code_bits(sh.llml, 1, (uint32_t)rOF)) : 0;
+    const uint32_t fML = rML >= 0 ? ((uint32_t)rML | cz_fse_code_bits(sh.llml, 2, (uint32_t)rML)) : 0;
+    const uint32_t* TLL = sh.st.fse[0]; const uint32_t* TOF = sh.st.fse[1]; const uint32_t* TML = sh.st.fse[2];
+    /* stage the top two 1 KiB blocks of the stream */
+    uintptr_t loaded_lo;
+    {
+        const uintptr_t top = (((uintptr_t)E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZ_RING_BLOCK - 1));
+        cz_ring_load_block(sh, S, E, top); cz_ring_load_block(sh, S, E, top - CZ_RING_BLOCK);
+        loaded_lo = top - CZ_RING_BLOCK;
+    }
+    __syncthreads();
+    int32_t pos = (int32_t)(E - S) * 8;                                 /* bits_remaining, lane 0 is authoritative */
+    uint32_t sLL = 0, sOF = 0, sML = 0;
     if (LANE == 0) {
-        int e = 0;
-        cz_rb_init(rb, blk + bc.bitstream_off, bsize - bc.bitstream_off);               /* :42-44 */
-        if (cz_rb_skip_padding(rb)) e = CZ_E_SEQ_EXTRA_PADDING;                          /* :46-64 */
+        int e = 0, skipped = 0;
+        for (;;) {                                                      /* padding :46-64 */
+            const uint32_t b = pos > 0 ? cz_field(cz_ring_window(sh, sbits, pos - 1), 0, 1) : 0; pos -= 1; skipped++;
+            if (b == 1 || skipped > 8) break;
+        }
+        if (skipped > 8) e = CZ_E_SEQ_EXTRA_PADDING;
         /* init order LL, OF, ML (:207-218); a table that was never set is TableIsUninitialized */
-        if (!e && rLL < 0) { if (!sh.st.fse_log[0]) e = CZ_E_SEQ_TABLE_UNINIT; else sLL = cz_rb_get(rb, sh.st.fse_log[0]); }
-        if (!e && rOF < 0) { if (!sh.st.fse_log[1]) e = CZ_E_SEQ_TABLE_UNINIT; else sOF = cz_rb_get(rb, sh.st.fse_log[1]); }
-        if (!e && rML < 0) { if (!sh.st.fse_log[2]) e = CZ_E_SEQ_TABLE_UNINIT; else sML = cz_rb_get(rb, sh.st.fse_log[2]); }
+        const uint32_t logs[3] = { sh.st.fse_log[0], sh.st.fse_log[1], sh.st.fse_log[2] };
+        const int32_t rl[3] = { rLL, rOF, rML }; uint32_t stv[3] = {0, 0, 0};
+        for (int t = 0; t < 3 && !e; t++) {
+            if (rl[t] >= 0) continue;
+            if (!logs[t]) { e = CZ_E_SEQ_TABLE_UNINIT; break; }
+            stv[t] = pos > 0 ? cz_field(cz_ring_window(sh, sbits, pos - 1), 0, logs[t]) : 0; pos -= (int32_t)logs[t];
+        }
+        sLL = stv[0]; sOF = stv[1]; sML = stv[2];
         bc.chunk_err = e;
     }
     __syncthreads();
     { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
     int exec_err = 0;                                                   /* first execution error, reported only if the
                                                                            rest of the section decodes (reference order) */
+    uint32_t h0 = sh.st.hist[0], h1 = sh.st.hist[1], h2 = sh.st.hist[2];   /* uniform copy in every lane */
     for (uint32_t done = 0; done < nseq; done += 64) {
         const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
+        /* keep CZ_RING_NEED bytes below the cursor staged */
+        {
+            const int32_t p0 = __shfl(pos, 0);
+            const intptr_t cur = (intptr_t)S + ((p0 > 0 ? p0 - 1 : 0) >> 3);
+            if (cur - (intptr_t)CZ_RING_NEED < (intptr_t)loaded_lo) {
+                loaded_lo -= CZ_RING_BLOCK;
+                cz_ring_load_block(sh, S, E, loaded_lo);
+                __syncthreads();
+            }
+        }
         if (LANE == 0) {
             int e = 0;
-            for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286 */
-                const uint32_t eLL = sh.st.fse[0][sLL], eOF = sh.st.fse[1][sOF], eML = sh.st.fse[2][sML];
-                const uint32_t ll_code = rLL >= 0 ? (uint32_t)rLL : CZ_FSE_SYM(eLL);
-                const uint32_t ml_code = rML >= 0 ? (uint32_t)rML : CZ_FSE_SYM(eML);
-                const uint32_t of_code = rOF >= 0 ? (uint32_t)rOF : CZ_FSE_SYM(eOF);
-                if (of_code >= 32) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
-                if (ll_code >= 36 || ml_code >= 53) { e = CZ_E_SEQ_TOO_MANY_BITS; break; } /* num_bits 255 -> TooManyBits :239 */
-                const uint32_t tl = sh.llml[ll_code], tm = sh.llml[40 + ml_code];
-                const uint32_t ob = cz_rb_get(rb, of_code), mb = cz_rb_get(rb, tm >> 24), lb = cz_rb_get(rb, tl >> 24); /* :239 */
-                const uint32_t ov = (1u << of_code) + ob, ll = (tl & 0xFFFFFFu) + lb, ml = (tm & 0xFFFFFFu) + mb;       /* :243-256 */
-                uint32_t actual = 1;
-                if (!exec_err) actual = cz_offset_history(ov, ll, h0, h1, h2);
-                sh.u.seq.ll[i] = ll; sh.u.seq.ml[i] = ml; sh.u.seq.off[i] = actual;
-                if (done + i + 1 < nseq) {                              /* :258-277 update order LL, ML, OF */
-                    if (rLL < 0) sLL = CZ_FSE_BASE(eLL) + cz_rb_get(rb, CZ_FSE_NB(eLL));
-                    if (rML < 0) sML = CZ_FSE_BASE(eML) + cz_rb_get(rb, CZ_FSE_NB(eML));
-                    if (rOF < 0) sOF = CZ_FSE_BASE(eOF) + cz_rb_get(rb, CZ_FSE_NB(eOF));
-                }
-                if (rb.remaining < 0) { e = CZ_E_SEQ_NOT_ENOUGH_BYTES; break; }         /* :281 */
+            for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286, serial core */
+                const uint64_t W = pos > 0 ? cz_ring_window(sh, sbits, pos - 1) : 0;
+                const uint32_t eLL = rLL >= 0 ? fLL : TLL[sLL], eOF = rOF >= 0 ? fOF : TOF[sOF], eML = rML >= 0 ? fML : TML[sML];
+                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 10) | (sML << 20);
+                if (CZ_FSE_INV(eOF)) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
+                if (CZ_FSE_INV(eLL) | CZ_FSE_INV(eML)) { e = CZ_E_SEQ_TOO_MANY_BITS; break; } /* num_bits 255 -> TooManyBits :239 */
+                const uint32_t a = CZ_FSE_XB(eOF) + CZ_FSE_XB(eML) + CZ_FSE_XB(eLL);     /* extra bits, read first (:239) */
+                if (done + i + 1 < nseq) {                              /* :258-277 state updates, order LL, ML, OF */
+                    const uint32_t nl = CZ_FSE_NB(eLL), nm = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF), tot = a + nl + nm + no;
+                    uint64_t V = W; uint32_t o = a;
+                    if (tot > 64) { V = pos - (int32_t)a > 0 ? cz_ring_window(sh, sbits, pos - (int32_t)a - 1) : 0; o = 0; }
+                    sLL = CZ_FSE_BASE(eLL) + cz_field(V, o, nl);
+                    sML = CZ_FSE_BASE(eML) + cz_field(V, o + nl, nm);
+                    sOF = CZ_FSE_BASE(eOF) + cz_field(V, o + nl + nm, no);
+                    pos -= (int32_t)tot;
+                } else pos -= (int32_t)a;
+                if (pos < 0) { e = CZ_E_SEQ_NOT_ENOUGH_BYTES; break; }  /* :281 */
             }
-            if (!e && done + cnt >= nseq && rb.remaining > 0) e = CZ_E_SEQ_EXTRA_BITS;  /* :292 */
+            if (!e && done + cnt >= nseq && pos > 0) e = CZ_E_SEQ_EXTRA_BITS;           /* :292 */
             bc.chunk_err = e;
         }
         __syncthreads();
         { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
-        if (!exec_err) exec_err = cz_execute_chunk(sh, x, lit, cnt);
+        if (!exec_err) {
+            /* every lane finishes its own sequence: extra bits -> (ll, ml, offset_value) */
+            uint32_t ll = 0, ml = 0, ov = 4;
+            const int active = (uint32_t)LANE < cnt;
+            if (active) {
+                const int32_t p = sh.u.rec.pos[LANE]; const uint32_t st = sh.u.rec.st[LANE];
+                const uint32_t eLL = rLL >= 0 ? fLL : TLL[st & 1023], eOF = rOF >= 0 ? fOF : TOF[(st >> 10) & 1023], eML = rML >= 0 ? fML : TML[st >> 20];
+                const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
+                const uint32_t oc = CZ_FSE_XB(eOF), mx = CZ_FSE_XB(eML), lx = CZ_FSE_XB(eLL);
+                const uint32_t tl = sh.llml[CZ_FSE_SYM(eLL)], tm = sh.llml[40 + CZ_FSE_SYM(eML)];
+                ov = (1u << oc) + cz_field(W, 0, oc);                   /* :243 */
+                ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);            /* :249-256 */
+                ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
+            }
+            /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
+            CzHist T; T.s = 0 | (1 << 2) | (2 << 4); T.v0 = T.v1 = T.v2 = 0;              /* identity */
+            if (active) {
+                if (ov > 3) { T.s = 3 | (0 << 2) | (1 << 4); T.v0 = ov - 3; }             /* push */
+                else if (ll > 0) {
+                    if (ov == 2) T.s = 1 | (0 << 2) | (2 << 4);
+                    else if (ov == 3) T.s = 2 | (0 << 2) | (1 << 4);
+                } else {
+                    if (ov == 1) T.s = 1 | (0 << 2) | (2 << 4);
+                    else if (ov == 2) T.s = 2 | (0 << 2) | (1 << 4);
+                    else { T.s = 0 | (0 << 2) | (1 << 4); T.v0 = 0xFFFFFFFFu; }           /* (h0 - 1, h0, h1) */
+                }
+            }
+            for (int d = 1; d < 64; d <<= 1) {
+                CzHist P; P.s = __shfl_up(T.s, (unsigned)d); P.v0 = __shfl_up(T.v0, (unsigned)d); P.v1 = __shfl_up(T.v1, (unsigned)d); P.v2 = __shfl_up(T.v2, (unsigned)d);
+                if (LANE >= d) T = cz_hist_compose(P, T);
+            }
+            CzHist X; X.s = __shfl_up(T.s, 1u); X.v0 = __shfl_up(T.v0, 1u); X.v1 = __shfl_up(T.v1, 1u); X.v2 = __shfl_up(T.v2, 1u);
+            if (LANE == 0) { X.s = 0 | (1 << 2) | (2 << 4); X.v0 = X.v1 = X.v2 = 0; }
+            const uint32_t b0 = cz_hist_eval(X.s & 3, X.v0, h0, h1, h2), b1 = cz_hist_eval((X.s >> 2) & 3, X.v1, h0, h1, h2),
+                           b2 = cz_hist_eval((X.s >> 4) & 3, X.v2, h0, h1, h2);          /* history before this sequence */
+            uint32_t actual;
+            if (ov > 3) actual = ov - 3;
+            else if (ll > 0) actual = ov == 1 ? b0 : (ov == 2 ? b1 : b2);
+            else actual = ov == 1 ? b1 : (ov == 2 ? b2 : b0 - 1);
+            const int lastl = (int)cnt - 1;
+            const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
+            const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
+            h0 = n0; h1 = n1; h2 = n2;
+            exec_err = cz_execute_chunk(x, lit, cnt, ll, ml, actual);
+        }
         __syncthreads();
     }
     if (exec_err) return exec_err;
@@ -752,7 +898,7 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     __syncthreads();
     { const int e = bc.err; __syncthreads(); if (e) return e; }
     if (LANE < 3 && ((bc.build_mask >> LANE) & 1u)) {
-        cz_fse_build(sh.st.fse[LANE], sh.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.counters[LANE]);
+        cz_fse_build(sh.st.fse[LANE], sh.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.counters[LANE], sh.llml, (uint32_t)LANE);
         sh.st.fse_log[LANE] = (uint8_t)bc.acc_log[LANE];
     }
     __syncthreads();
