@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcairo_zstd_amd.so")
+LIB_PATH = os.environ.get("CAIRO_ZSTD_AMD_LIB") or os.path.join(CSRC, "libcairo_zstd_amd.so")   # override: diagnostic builds
 
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("blocks_decoded", "<u4"), ("bytes_consumed", "<u8"),
                          ("bytes_produced", "<u8"), ("checksum_from_data", "<u4"), ("flags", "<u4"),
@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
     L.cz_context_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cz_context_last_kernel_ms.restype = C.c_int
     L.cz_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cz_context_read_profile.restype = C.c_int
+    L.cz_context_read_profile.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.cz_decode_batch_device.restype = C.c_int
     L.cz_decode_batch_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.cz_decode_batch_host.restype = C.c_int

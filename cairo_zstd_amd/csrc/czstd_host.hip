@@ -35,6 +35,7 @@ struct cz_context {
     int last_hip_error = 0;
     /* staging for cz_decode_batch_host */
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    unsigned long long* d_prof = nullptr;   /* CZ_PROFILE builds: per-phase cycle sums */
 };
 
 #define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
@@ -66,8 +67,24 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
         if (c->work_counter) (void)hipFree(c->work_counter);
         delete c; return CZ_E_HIP;
     }
+#ifdef CZ_PROFILE
+    if (hipMalloc((void**)&c->d_prof, 64 * 8) == hipSuccess) (void)hipMemset(c->d_prof, 0, 64 * 8);
+#endif
     *out = c;
     return CZ_OK;
+}
+
+/* Diagnostic builds (-DCZ_PROFILE): copies out and clears the per-phase cycle sums; returns the
+ * number of phases, 0 in the product build. */
+CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, int cap) {
+    if (!c || !c->d_prof) return 0;
+    unsigned long long tmp[64];
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    if (hipMemcpy(tmp, c->d_prof, sizeof tmp, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    (void)hipMemset(c->d_prof, 0, sizeof tmp);
+    int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
+    for (int i = 0; i < n; i++) out[i] = tmp[i];
+    return n;
 }
 
 CZ_EXPORT void cz_context_destroy(cz_context* c) {
@@ -77,6 +94,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->lit_scratch) (void)hipFree(c->lit_scratch);
     if (c->work_counter) (void)hipFree(c->work_counter);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -111,6 +129,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_LIT_SCRATCH_BYTES;
+    a.prof = c->d_prof;
     const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));

@@ -27,6 +27,19 @@
 #include "czstd_types.h"
 
 #define LANE ((int)threadIdx.x)
+/* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
+ * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
+ * frame.  No stamp executes in the product build. */
+#ifdef CZ_PROFILE
+#define CZ_PROF_DECL unsigned long long cz_t_ = 0
+#define CZ_PROF_T0() do { if (LANE == 0) cz_t_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define CZ_PROF_ACC(sh_, idx) do { if (LANE == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); (sh_).prof[idx] += n_ - cz_t_; cz_t_ = n_; } } while (0)
+#else
+#define CZ_PROF_DECL
+#define CZ_PROF_T0() do { } while (0)
+#define CZ_PROF_ACC(sh_, idx) do { } while (0)
+#endif
+enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER, CZ_P_COUNT };
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
@@ -63,6 +76,9 @@ struct CzShared {
     uint32_t llml[96];                 /* [0..35] LL base | bits<<24, [40..92] ML */
     CzBroadcast bc;
     uint32_t frame_idx;
+#ifdef CZ_PROFILE
+    unsigned long long prof[CZ_P_COUNT];
+#endif
 };
 
 /* sequence_section_decoder.cairo:299-345 / :347-395 */
@@ -164,18 +180,22 @@ __device__ static inline int cz_fb_get(CzFBits& f, uint32_t n, uint32_t* out) {
 
 /* ------------------------------------------------------------------ FSE tables */
 /* packed entry (fse_decoder.cairo:49-53 plus what the sequence chain needs in ONE lookup):
- *   [7:0] symbol  [11:8] num_bits  [16:12] extra bits of the symbol's LL/ML/OF code
- *   [17] code out of range (LL >= 36, ML >= 53, OF >= 32)  [29:20] base_line */
-#define CZ_FSE_SYM(e) ((e) & 0xFFu)
-#define CZ_FSE_NB(e) (((e) >> 8) & 0xFu)
-#define CZ_FSE_XB(e) (((e) >> 12) & 0x1Fu)
-#define CZ_FSE_INV(e) (((e) >> 17) & 1u)
-#define CZ_FSE_BASE(e) ((e) >> 20)
+ *   [6:0]  extra bits of the symbol's LL/ML/OF code (<= 31; 2 bits of headroom)
+ *   [12:7] num_bits (<= 9; 2 bits of headroom)      [13] code out of range (LL>=36, ML>=53, OF>=32)
+ *   [22:14] base_line                                [31:24] symbol
+ * The headroom lets the chain add the three entries of a sequence and read the summed extra
+ * bits and summed state bits straight out of the sum. */
+#define CZ_FSE_SYM(e) ((e) >> 24)
+#define CZ_FSE_NB(e) (((e) >> 7) & 0x3Fu)
+#define CZ_FSE_XB(e) ((e) & 0x7Fu)
+#define CZ_FSE_INV(e) (((e) >> 13) & 1u)
+#define CZ_FSE_BASE(e) (((e) >> 14) & 0x1FFu)
+#define CZ_FSE_PACK(sym, nb, base) (((uint32_t)(sym) << 24) | ((uint32_t)(nb) << 7) | ((uint32_t)(base) << 14))
 /* extra-bits / validity part of an entry for symbol s of table kind (0 LL, 1 OF, 2 ML, 3 none) */
 __device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_t kind, uint32_t s) {
-    if (kind == 0) return s < 36 ? (llml[s] >> 24) << 12 : (1u << 17);
-    if (kind == 1) return s < 32 ? s << 12 : (1u << 17);
-    if (kind == 2) return s < 53 ? (llml[40 + s] >> 24) << 12 : (1u << 17);
+    if (kind == 0) return s < 36 ? (llml[s] >> 24) : (1u << 13);
+    if (kind == 1) return s < 32 ? s : (1u << 13);
+    if (kind == 2) return s < 53 ? (llml[40 + s] >> 24) : (1u << 13);
     return 0;
 }
 
@@ -218,24 +238,24 @@ __device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint3
     uint32_t neg = size;
     for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
         counters[s] = 0;
-        if (probs[s] == -1) { neg--; table[neg] = s | (log << 8) | cz_fse_code_bits(llml, kind, s); }
+        if (probs[s] == -1) { neg--; table[neg] = CZ_FSE_PACK(s, log, 0) | cz_fse_code_bits(llml, kind, s); }
     }
     uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     for (uint32_t s = 0; s < nprobs; s++) {                             /* :190-226 */
         int32_t p = probs[s];
         for (int32_t j = 0; j < p; j++) {
-            table[pos] = s;
+            table[pos] = s << 24;
             do { pos = (pos + step) & mask; } while (pos >= neg);
         }
     }
     for (uint32_t i = 0; i < neg; i++) {                                /* :231-255, :377-400 */
-        uint32_t s = table[i] & 0xFFu, n = (uint32_t)probs[s], k = counters[s];
+        uint32_t s = table[i] >> 24, n = (uint32_t)probs[s], k = counters[s];
         counters[s] = (uint16_t)(k + 1);
         uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
         uint32_t dbl = slices - n, single = n - dbl, width = size / slices, nb = cz_hbs(width) - 1, bl;
         if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
         else bl = (k - dbl) * width;
-        table[i] = s | (nb << 8) | (bl << 20) | cz_fse_code_bits(llml, kind, s);
+        table[i] = CZ_FSE_PACK(s, nb, bl) | cz_fse_code_bits(llml, kind, s);
     }
 }
 
@@ -572,7 +592,8 @@ struct CzExecCtx {
 
 /* execute up to 64 decoded sequences, one per lane (ll, ml, off = resolved offset).
  * sequence_execution.cairo:12-66, decode_buffer.cairo:62-133.  Returns status (uniform). */
-__device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
+__device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
+    CZ_PROF_DECL; CZ_PROF_T0();
     const int active = (uint32_t)LANE < cnt;
     if (!active) { ll = 0; ml = 0; off = 1; }
     const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
@@ -606,6 +627,7 @@ __device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t 
         cz_lit_coop_copy(x.out + os, lit, ls, n);
     }
     __syncthreads();
+    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
 
     /* matches: dependency rounds.  W = first byte not yet guaranteed written = match
        destination of the first undone sequence; a sequence may go once its source range
@@ -643,6 +665,7 @@ __device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t 
         if (ready) done = 1;
         __syncthreads();
     }
+    CZ_PROF_ACC(sh, CZ_P_MATCH);
     x.produced += sum_tot; x.lit_used += sum_ll;
     return 0;
 }
@@ -708,12 +731,14 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     const uint32_t nseq = bc.nseq;
     const uint8_t* S = blk + bc.bitstream_off; const uint8_t* E = blk + bsize;
     const uint32_t sbits = (uint32_t)((uintptr_t)S & (CZ_RING_BYTES - 1)) * 8u;
+    CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
     /* per-table constants: RLE tables behave like a one-entry table (num_bits 0, base 0) */
     const int32_t rLL = sh.st.fse_rle[0], rOF = sh.st.fse_rle[1], rML = sh.st.fse_rle[2];
-    const uint32_t fLL = rLL >= 0 ? ((uint32_t)rLL | cz_fse_code_bits(sh.llml, 0, (uint32_t)rLL)) : 0;
-    const uint32_t fOF = rOF >= 0 ? ((uint32_t)rOF | cz_fse_code_bits(sh.llml, 1, (uint32_t)rOF)) : 0;
-    const uint32_t fML = rML >= 0 ? ((uint32_t)rML | cz_fse_code_bits(sh.llml, 2, (uint32_t)rML)) : 0;
+    const uint32_t fLL = rLL >= 0 ? (CZ_FSE_PACK(rLL, 0, 0) | cz_fse_code_bits(sh.llml, 0, (uint32_t)rLL)) : 0;
+    const uint32_t fOF = rOF >= 0 ? (CZ_FSE_PACK(rOF, 0, 0) | cz_fse_code_bits(sh.llml, 1, (uint32_t)rOF)) : 0;
+    const uint32_t fML = rML >= 0 ? (CZ_FSE_PACK(rML, 0, 0) | cz_fse_code_bits(sh.llml, 2, (uint32_t)rML)) : 0;
+    const int any_rle = (rLL >= 0) | (rOF >= 0) | (rML >= 0);
     const uint32_t* TLL = sh.st.fse[0]; const uint32_t* TOF = sh.st.fse[1]; const uint32_t* TML = sh.st.fse[2];
     /* stage the top two 1 KiB blocks of the stream */
     uintptr_t loaded_lo;
@@ -745,6 +770,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     }
     __syncthreads();
     { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+    CZ_PROF_ACC(sh, CZ_P_RING);
     int exec_err = 0;                                                   /* first execution error, reported only if the
                                                                            rest of the section decodes (reference order) */
     uint32_t h0 = sh.st.hist[0], h1 = sh.st.hist[1], h2 = sh.st.hist[2];   /* uniform copy in every lane */
@@ -760,12 +786,52 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
                 __syncthreads();
             }
         }
+        CZ_PROF_ACC(sh, CZ_P_RING);
         if (LANE == 0) {
+            /* Fast pass: straight-line, no per-sequence branches; any invalid code or overrun only
+               sets a flag, and the chunk is then redone by the careful loop below, which finds the
+               first failing sequence and its reference error code. */
+            const int32_t pos_save = pos; const uint32_t sLL_save = sLL, sOF_save = sOF, sML_save = sML;
+            const int is_last_chunk = done + cnt >= nseq;
+            const uint32_t full = is_last_chunk ? cnt - 1 : cnt;
+            uint32_t bad = 0; int32_t neg = 0; int slow = 0;
+            const uint32_t* rw = (const uint32_t*)sh.ring;
+            const uint32_t M = CZ_RING_BYTES / 4 - 1;
+            for (uint32_t i = 0; i < full; i++) {
+                const uint32_t g = sbits + (uint32_t)pos - 1u, wi = g >> 5, r = (g & 31) + 1;
+                const uint32_t w2 = rw[wi & M], w1 = rw[(wi - 1) & M], w0 = rw[(wi - 2) & M];
+                uint32_t eLL = TLL[sLL & 511], eOF = TOF[sOF & 511], eML = TML[sML & 511];
+                if (any_rle) { eLL = rLL >= 0 ? fLL : eLL; eOF = rOF >= 0 ? fOF : eOF; eML = rML >= 0 ? fML : eML; }
+                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 9) | (sML << 18);
+                const uint32_t sum = eLL + eOF + eML, a = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
+                bad |= eLL | eOF | eML;
+                if (a > 37) { slow = 1; break; }                        /* > 64 bits in one sequence: careful loop */
+                const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> r), lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> r);
+                const uint32_t xh = (uint32_t)(((((uint64_t)hi << 32) | lo) << a) >> 32);   /* bits right after the extra bits */
+                const uint32_t nl = CZ_FSE_NB(eLL), nm = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
+                sLL = CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl);         /* update order LL, ML, OF (:258-277) */
+                sML = CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm, nm);
+                sOF = CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm - no, no);
+                pos -= (int32_t)(a + nbs);
+                neg |= pos;
+            }
+            if (!slow && is_last_chunk) {                               /* the block's last sequence: no state update */
+                uint32_t eLL = TLL[sLL & 511], eOF = TOF[sOF & 511], eML = TML[sML & 511];
+                if (any_rle) { eLL = rLL >= 0 ? fLL : eLL; eOF = rOF >= 0 ? fOF : eOF; eML = rML >= 0 ? fML : eML; }
+                sh.u.rec.pos[cnt - 1] = pos; sh.u.rec.st[cnt - 1] = sLL | (sOF << 9) | (sML << 18);
+                bad |= eLL | eOF | eML;
+                pos -= (int32_t)((eLL + eOF + eML) & 0x7F);
+                neg |= pos;
+                if (pos > 0) slow = 1;                                  /* ExtraBits: let the careful loop report it */
+            }
+            if (!slow && !((bad >> 13) & 1) && neg >= 0) bc.chunk_err = 0;
+            else {
+            pos = pos_save; sLL = sLL_save; sOF = sOF_save; sML = sML_save;
             int e = 0;
-            for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286, serial core */
+            for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286, serial core (careful) */
                 const uint64_t W = pos > 0 ? cz_ring_window(sh, sbits, pos - 1) : 0;
                 const uint32_t eLL = rLL >= 0 ? fLL : TLL[sLL], eOF = rOF >= 0 ? fOF : TOF[sOF], eML = rML >= 0 ? fML : TML[sML];
-                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 10) | (sML << 20);
+                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 9) | (sML << 18);
                 if (CZ_FSE_INV(eOF)) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
                 if (CZ_FSE_INV(eLL) | CZ_FSE_INV(eML)) { e = CZ_E_SEQ_TOO_MANY_BITS; break; } /* num_bits 255 -> TooManyBits :239 */
                 const uint32_t a = CZ_FSE_XB(eOF) + CZ_FSE_XB(eML) + CZ_FSE_XB(eLL);     /* extra bits, read first (:239) */
@@ -782,16 +848,18 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             }
             if (!e && done + cnt >= nseq && pos > 0) e = CZ_E_SEQ_EXTRA_BITS;           /* :292 */
             bc.chunk_err = e;
+            }
         }
         __syncthreads();
         { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+        CZ_PROF_ACC(sh, CZ_P_CHAIN);
         if (!exec_err) {
             /* every lane finishes its own sequence: extra bits -> (ll, ml, offset_value) */
             uint32_t ll = 0, ml = 0, ov = 4;
             const int active = (uint32_t)LANE < cnt;
             if (active) {
                 const int32_t p = sh.u.rec.pos[LANE]; const uint32_t st = sh.u.rec.st[LANE];
-                const uint32_t eLL = rLL >= 0 ? fLL : TLL[st & 1023], eOF = rOF >= 0 ? fOF : TOF[(st >> 10) & 1023], eML = rML >= 0 ? fML : TML[st >> 20];
+                const uint32_t eLL = rLL >= 0 ? fLL : TLL[st & 511], eOF = rOF >= 0 ? fOF : TOF[(st >> 9) & 511], eML = rML >= 0 ? fML : TML[(st >> 18) & 511];
                 const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
                 const uint32_t oc = CZ_FSE_XB(eOF), mx = CZ_FSE_XB(eML), lx = CZ_FSE_XB(eLL);
                 const uint32_t tl = sh.llml[CZ_FSE_SYM(eLL)], tm = sh.llml[40 + CZ_FSE_SYM(eML)];
@@ -828,7 +896,9 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
             const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
             h0 = n0; h1 = n1; h2 = n2;
-            exec_err = cz_execute_chunk(x, lit, cnt, ll, ml, actual);
+            CZ_PROF_ACC(sh, CZ_P_EXTRACT);
+            exec_err = cz_execute_chunk(sh, x, lit, cnt, ll, ml, actual);
+            CZ_PROF_T0();
         }
         __syncthreads();
     }
@@ -842,6 +912,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         x.produced += rest;
     }
     __syncthreads();
+    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
     return 0;
 }
 
@@ -849,6 +920,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
 __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch) {
     CzBroadcast& bc = sh.bc;
+    CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
     const uint32_t stage_hi = bsize < 512 ? bsize : 512;
     for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.stage[i] = blk[i];
@@ -857,6 +929,7 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     __syncthreads();
     { const int e = bc.err; __syncthreads(); if (e) return e; }         /* read, then fence the slot before it is rewritten */
     if (bc.huf_fill) { cz_huf_fill(sh, bc.huf_nsym); __syncthreads(); }
+    CZ_PROF_ACC(sh, CZ_P_HUFBUILD);
     /* literals */
     CzLit lit; lit.rle = 0; lit.byte = 0; lit.len = bc.regen; lit.p = blk;
     const uint32_t lt = bc.lit_type, nseq_early = bc.seq_hdr_err ? 1u : bc.nseq;
@@ -875,6 +948,7 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
         lit.p = target;
         __syncthreads();
     }
+    CZ_PROF_ACC(sh, CZ_P_HUFDEC);
     if (bc.seq_hdr_err) return bc.seq_hdr_err;                          /* block_decoder.cairo:198-204 */
     if (bc.nseq == 0) {                                                 /* :229-232 */
         if (lt < 2) {
@@ -903,6 +977,7 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     }
     __syncthreads();
     x.lit_used = 0;
+    CZ_PROF_ACC(sh, CZ_P_SEQTAB);
     return cz_sequences(sh, blk, bsize, x, lit);
 }
 
@@ -918,6 +993,7 @@ struct CzFrameIO {
 __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, cz_frame_result* res) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
+    CZ_PROF_DECL; CZ_PROF_T0();
     if (io.parse_header) {
         if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(io.src, io.src_len, bc); }
         __syncthreads();
@@ -960,10 +1036,13 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
             cz_coop_fill(x.out + x.produced, io.src[body], bsize);
             x.produced += bsize;
         } else {
+            CZ_PROF_ACC(sh, CZ_P_HDR);
             err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch);
+            CZ_PROF_T0();
             if (err) break;
         }
         __syncthreads();
+        if (btype != 2) CZ_PROF_ACC(sh, CZ_P_RAWRLE);
         pos = body + content; blocks++;
         if (blast) {                                                    /* frame_decoder.cairo:189-200 / :300-312 */
             flags |= CZ_RESULT_FINISHED;
@@ -1002,6 +1081,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 2) cz_decode_frames_
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
     uint8_t* lit_scratch = a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride;
+#ifdef CZ_PROFILE
+    if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
+#endif
     for (;;) {
         __syncthreads();
         if (LANE == 0) sh.frame_idx = atomicAdd(a.work_counter, 1u);
@@ -1028,6 +1110,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 2) cz_decode_frames_
             cz_state_reset(sh);
             __syncthreads();
             cz_run_frame(sh, io, lit_scratch, &a.results[f]);
+#ifdef CZ_PROFILE
+            if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
+#endif
             if (LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
         }
     }

@@ -41,6 +41,7 @@ typedef struct cz_batch_args {
     uint32_t n;
     uint32_t* work_counter;                   /* zeroed before every launch */
     uint8_t* lit_scratch; uint64_t lit_scratch_stride;   /* one region per resident workgroup */
+    unsigned long long* prof;                 /* diagnostic build only: per-phase cycle sums (NULL otherwise) */
 } cz_batch_args;
 
 #endif

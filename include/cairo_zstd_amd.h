@@ -93,6 +93,11 @@ int cz_decode_batch_host(cz_context* ctx,
  * Blocks until that launch has finished. */
 int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
 
+/* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the
+ * per-phase shader-cycle sums accumulated by the kernels; returns the number of phases written
+ * (0 in the product library, which executes no stamps). */
+int cz_context_read_profile(cz_context* ctx, unsigned long long* out, int cap);
+
 /* ------------------------------------------------- stateless header parsers */
 /* read_frame_header (src/frame.cairo:152-284) + FrameHeaderTrait::window_size (:106-129). */
 typedef struct cz_frame_header {

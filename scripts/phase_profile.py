@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-cycle shares of cz_decode_frames_kernel (needs the -DCZ_PROFILE
+build: make -C cairo_zstd_amd/csrc prof).  Never quote this build's run time; read the SHARES."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CAIRO_ZSTD_AMD_LIB"] = os.path.join(ROOT, "cairo_zstd_amd", "csrc", "libcairo_zstd_amd_prof.so")
+import numpy as np
+import torch
+
+import cairo_zstd_amd as cz
+from cairo_zstd_amd import synth
+
+PHASES = ["hdr", "huf_build", "huf_decode", "seq_tables", "ring", "chain", "extract", "lit_copy", "match", "raw_rle", "other"]
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "full_4a"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    b = synth.generate(kind, n)
+    out_off, out_cap, total = b.out_layout()
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(x).to(dev) for x in (b.base, b.off.astype(np.int64), b.length.astype(np.int64), out_off.astype(np.int64), out_cap.astype(np.int64))]
+    t_out = torch.empty(total, dtype=torch.uint8, device=dev)
+    t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
+    buf = (C.c_uint64 * 64)()
+    for it in range(2):
+        ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
+        torch.cuda.synchronize()
+        k = cz.lib().cz_context_read_profile(ctx._h, buf, 64)
+    ms = ctx.last_kernel_ms()
+    vals = [buf[i] for i in range(k)]
+    tot = sum(vals) or 1
+    res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+    print(f"{kind} n={n} kernel {ms:.3f} ms (instrumented), status ok={bool((res['status'] == 0).all())}, launch={ctx.launch_info()}")
+    for name, v in zip(PHASES, vals):
+        print(f"  {name:11s} {v / n:14.0f} cycles/frame  {100.0 * v / tot:5.1f} %")
+    print(f"  total       {tot / n:14.0f} cycles/frame")
+
+
+if __name__ == "__main__":
+    main()
