@@ -60,7 +60,7 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     c->occupancy = occ; c->grid_max = c->num_cu * occ;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CZ_E_HIP; } c->own_stream = true; }
-    if (hipMalloc((void**)&c->lit_scratch, (size_t)c->grid_max * CZ_LIT_SCRATCH_BYTES) != hipSuccess ||
+    if (hipMalloc((void**)&c->lit_scratch, (size_t)c->grid_max * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
         hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
         hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         if (c->lit_scratch) (void)hipFree(c->lit_scratch);
@@ -128,7 +128,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n == 0) return CZ_OK;
     if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
     cz_batch_args a = proto;
-    a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_LIT_SCRATCH_BYTES;
+    a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
     a.prof = c->d_prof;
     const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));

@@ -27,6 +27,13 @@
 #include "czstd_types.h"
 
 #define LANE ((int)threadIdx.x)
+#define CZ_NOINLINE __attribute__((noinline))
+/* Values that are the same in every lane (read from the LDS broadcast slots, or produced by a
+ * cross-lane broadcast) are pinned to scalar registers: keeps the VGPR budget for per-lane work
+ * and lets the scalar unit do the uniform arithmetic. */
+__device__ static inline uint32_t cz_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ static inline int32_t cz_unii(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_uni((uint32_t)(v >> 32)) << 32) | cz_uni((uint32_t)v); }
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
  * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
  * frame.  No stamp executes in the product build. */
@@ -64,22 +71,37 @@ struct CzBroadcast {
     uint32_t chunk_cnt; int32_t chunk_err;
 };
 
+/* LDS per workgroup (= per frame in flight).  The carried state of the reference's
+ * DecoderScratch (scratch.cairo:11-19) that must survive from block to block stays resident:
+ * three FSE tables, RLE symbols, offset history.  Everything else is phase-local and shares
+ * region `a`:
+ *   T1 parse literals section / Huffman weights   (stage, probs0, counters0, wtab)
+ *   T2 Huffman table, live while the literal streams decode        (huf)
+ *   T3 parse + build the sequence tables                           (stage, probs, counters)
+ *   T4 sequence decode                                             (bit ring, chain records)
+ * The Huffman table is the only carried item that does not stay in LDS: when a block that
+ * created one is not the last block it is spilled to a 4 KiB global slot and re-read by
+ * Treeless blocks (literals_section_decoder.cairo:82-86). */
 struct CzShared {
-    cz_device_frame_state st;          /* carried across blocks (scratch.cairo:11-19) */
-    int16_t  probs[3][256];
-    uint16_t counters[3][256];
-    uint8_t  stage[512];
-    union { uint32_t wtab[512]; struct { int32_t pos[64]; uint32_t st[64]; } rec; } u;   /* weights FSE table | chain records */
-    __attribute__((aligned(16))) uint8_t ring[CZ_RING_BYTES];   /* sequences bitstream, indexed by absolute address */
-    uint8_t  hbits[264];
-    uint16_t sym_base[264];
-    uint32_t llml[96];                 /* [0..35] LL base | bits<<24, [40..92] ML */
+    uint32_t fse_ll[512], fse_ml[512], fse_of[256];
+    uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
+    union {
+        uint16_t huf[2048];
+        struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; } t1;
+        struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
+        struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64]; } t4;   /* mirror[8..15] == ring[2040..2047] */
+    } a;
+    union {
+        struct { uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
+        struct { __attribute__((aligned(16))) uint8_t win[4][256]; uint8_t out[4][32]; } h;   /* T2: per-stream bit windows + output staging */
+    } b;
     CzBroadcast bc;
     uint32_t frame_idx;
 #ifdef CZ_PROFILE
     unsigned long long prof[CZ_P_COUNT];
 #endif
 };
+__device__ static inline uint32_t* cz_fse_table(CzShared& sh, int t) { return t == 0 ? sh.fse_ll : (t == 1 ? sh.fse_of : sh.fse_ml); }
 
 /* sequence_section_decoder.cairo:299-345 / :347-395 */
 __device__ static const uint32_t CZ_LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -94,6 +116,7 @@ __device__ static const int8_t CZ_ML_DEFAULT[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,
 /* math.cairo:266-271: 1-based index of the highest set bit */
 __device__ static inline uint32_t cz_hbs(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
 
+__device__ static inline void cz_init_llml(CzShared& sh);
 /* ------------------------------------------------------------------ wave helpers */
 __device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
     for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, (unsigned)d); if (LANE >= d) v += t; }
@@ -200,7 +223,7 @@ __device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_
 }
 
 /* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
-__device__ static int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
+__device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
                                         uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above) {
     uint32_t v;
     if (cz_fb_get(br, 4, &v)) return CZ_E_FSE_GETBITS;                  /* :265-268 */
@@ -232,7 +255,7 @@ __device__ static int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* 
 }
 /* build_decoding_table (fse_decoder.cairo:156-256).  One lane per table; lanes 0..2 run it
  * side by side on different tables. */
-__device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters,
+__device__ static __attribute__((noinline)) void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters,
                                     const uint32_t* llml, uint32_t kind) {
     const uint32_t size = 1u << log;
     uint32_t neg = size;
@@ -262,37 +285,37 @@ __device__ static void cz_fse_build(uint32_t* table, const int16_t* probs, uint3
 /* ------------------------------------------------------------------ Huffman table */
 /* read_weights + the serial half of build_table_from_weights
  * (huff0_decoder.cairo:159-319, :321-431).  Lane 0.  Leaves per-symbol code lengths in
- * sh.hbits[0..nsym) and first-cell indices in sh.sym_base[]; the table itself is filled by
+ * sh.b.c.hbits[0..nsym) and first-cell indices in sh.b.c.sym_base[]; the table itself is filled by
  * all lanes afterwards (cz_huf_fill).  *bytes_used per :313-318. */
-__device__ static int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
+__device__ static __attribute__((noinline)) int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
                                            uint32_t goff, uint32_t* bytes_used, uint32_t* nsym_out) {
     /* g = block start, the tree description begins at block offset goff, len bytes available */
     if (len == 0) return CZ_E_HUF_SOURCE_EMPTY;                         /* :162 */
-    CzFBits fb; fb.g = g; fb.stage = sh.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = 0;
+    CzFBits fb; fb.g = g; fb.stage = sh.a.t1.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = 0;
     const uint32_t header = cz_fb_byte(fb, goff);
-    uint8_t* w = sh.hbits; uint32_t nw = 0;
+    uint8_t* w = sh.b.c.hbits; uint32_t nw = 0;
     if (header < 128) {                                                 /* :168-277 */
         const uint32_t fl = len - 1;
         if (header > fl) return CZ_E_HUF_NOT_ENOUGH_BYTES_FOR_WEIGHTS;  /* :171 */
         /* FSE description: reader positioned at block offset goff+1 */
-        CzFBits br; br.g = g + goff + 1; br.len = fl; br.stage = sh.stage; br.idx = 0;
+        CzFBits br; br.g = g + goff + 1; br.len = fl; br.stage = sh.a.t1.stage; br.idx = 0;
         br.stage_lo = 0; br.stage_hi = 0;
-        if (goff + 1 >= stage_lo && goff + 1 < stage_hi) { br.stage = sh.stage + (goff + 1 - stage_lo); br.stage_lo = 0; br.stage_hi = stage_hi - (goff + 1); }
+        if (goff + 1 >= stage_lo && goff + 1 < stage_hi) { br.stage = sh.a.t1.stage + (goff + 1 - stage_lo); br.stage_lo = 0; br.stage_hi = stage_hi - (goff + 1); }
         uint32_t nprobs, log, fse_bytes;
-        int e = cz_fse_read_probs(br, 100, sh.probs[0], &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
+        int e = cz_fse_read_probs(br, 100, sh.a.t1.probs0, &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
         if (e) return e;
         if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
-        cz_fse_build(sh.u.wtab, sh.probs[0], nprobs, log, sh.counters[0], sh.llml, 3);
+        cz_fse_build(sh.a.t1.wtab, sh.a.t1.probs0, nprobs, log, sh.a.t1.counters0, sh.b.c.llml, 3);
         CzRBits rb; cz_rb_init(rb, g + goff + 1 + fse_bytes, header - fse_bytes);       /* :190-202 */
         if (cz_rb_skip_padding(rb)) return CZ_E_HUF_EXTRA_PADDING;      /* :206-225 */
-        uint32_t d1 = sh.u.wtab[cz_rb_get(rb, log)];                    /* :227 */
-        uint32_t d2 = sh.u.wtab[cz_rb_get(rb, log)];                    /* :233 */
+        uint32_t d1 = sh.a.t1.wtab[cz_rb_get(rb, log)];                    /* :227 */
+        uint32_t d2 = sh.a.t1.wtab[cz_rb_get(rb, log)];                    /* :233 */
         for (;;) {                                                      /* :242-274 */
             if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d1); nw++;
-            d1 = sh.u.wtab[CZ_FSE_BASE(d1) + cz_rb_get(rb, CZ_FSE_NB(d1))];
+            d1 = sh.a.t1.wtab[CZ_FSE_BASE(d1) + cz_rb_get(rb, CZ_FSE_NB(d1))];
             if (rb.remaining <= -1) { if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d2); nw++; break; }
             if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d2); nw++;
-            d2 = sh.u.wtab[CZ_FSE_BASE(d2) + cz_rb_get(rb, CZ_FSE_NB(d2))];
+            d2 = sh.a.t1.wtab[CZ_FSE_BASE(d2) + cz_rb_get(rb, CZ_FSE_NB(d2))];
             if (rb.remaining <= -1) { if (nw < 260) w[nw] = (uint8_t)CZ_FSE_SYM(d1); nw++; break; }
             if (nw > 255) return CZ_E_HUF_TOO_MANY_WEIGHTS;             /* :271 */
         }
@@ -318,7 +341,7 @@ __device__ static int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint3
     const uint32_t max_bits = cz_hbs(sum), left = (1u << max_bits) - sum;
     if (left == 0 || (left & (left - 1))) return CZ_E_HUF_LEFTOVER_NOT_POW2;            /* :359 */
     const uint32_t last_w = cz_hbs(left);
-    sh.st.huf_max_bits = (uint8_t)max_bits;                             /* :383 (set before the check, as the reference) */
+    sh.huf_max_bits = (uint8_t)max_bits;                             /* :383 (set before the check, as the reference) */
     if (max_bits > 11) return CZ_E_HUF_MAX_BITS_TOO_HIGH;               /* :385 */
     uint32_t rank_cnt[13], rank_idx[13];
     for (int b = 0; b < 13; b++) { rank_cnt[b] = 0; rank_idx[b] = 0; }
@@ -329,35 +352,35 @@ __device__ static int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint3
     for (uint32_t b = max_bits; b > 0; b--) rank_idx[b - 1] = rank_idx[b] + rank_cnt[b] * (1u << (max_bits - b)); /* :414-429 */
     for (uint32_t s = 0; s <= nw; s++) {                                /* :433-450 */
         uint32_t b = w[s];
-        if (b) { sh.sym_base[s] = (uint16_t)rank_idx[b]; rank_idx[b] += 1u << (max_bits - b); }
+        if (b) { sh.b.c.sym_base[s] = (uint16_t)rank_idx[b]; rank_idx[b] += 1u << (max_bits - b); }
     }
     *nsym_out = nw + 1;
     return 0;
 }
 /* all lanes: the cell-filling half (huff0_decoder.cairo:451-463).  entry = symbol | bits<<8 */
-__device__ static void cz_huf_fill(CzShared& sh, uint32_t nsym) {
-    const uint32_t max_bits = sh.st.huf_max_bits;
+__device__ static __attribute__((noinline)) void cz_huf_fill(CzShared& sh, uint32_t nsym) {
+    const uint32_t max_bits = sh.huf_max_bits;
     for (uint32_t s = 0; s < nsym; s++) {
-        const uint32_t b = sh.hbits[s];
+        const uint32_t b = sh.b.c.hbits[s];
         if (!b) continue;
-        const uint32_t base = sh.sym_base[s], len = 1u << (max_bits - b);
+        const uint32_t base = sh.b.c.sym_base[s], len = 1u << (max_bits - b);
         const uint16_t e = (uint16_t)(s | (b << 8));
-        for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.st.huf[base + k] = e;
+        for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.a.huf[base + k] = e;
     }
 }
 /* One huff0 stream, one lane (literals_section_decoder.cairo:183-243).  Writes at most `cap`
  * bytes to out but keeps counting.  flags: 1 ExtraPadding, 2 stream did not end exactly. */
-__device__ static void cz_huf_stream(const CzShared& sh, const uint8_t* src, uint32_t len, uint8_t* out, uint32_t cap,
+__device__ static __attribute__((noinline)) void cz_huf_stream(const CzShared& sh, const uint8_t* src, uint32_t len, uint8_t* out, uint32_t cap,
                                      uint32_t* count, uint32_t* flags) {
     CzRBits rb; cz_rb_init(rb, src, len);
     if (cz_rb_skip_padding(rb)) { *count = 0; *flags = 1; return; }    /* :190-207 */
-    const uint32_t mb = sh.st.huf_max_bits;
+    const uint32_t mb = sh.huf_max_bits;
     uint32_t n = 0;
     /* peek form of init_state/next_state (huff0_decoder.cairo:81-106): state = next mb bits.
        bits_remaining(ref) = rb.remaining - mb; loop while it is > -mb (:216-228). */
     while (rb.remaining > 0) {
         cz_rb_refill(rb);
-        const uint32_t e = sh.st.huf[(uint32_t)(rb.buf >> (64 - mb))];
+        const uint32_t e = sh.a.huf[(uint32_t)(rb.buf >> (64 - mb))];
         const uint32_t nb = e >> 8;
         if (n < cap) out[n] = (uint8_t)e;
         n++;
@@ -368,7 +391,7 @@ __device__ static void cz_huf_stream(const CzShared& sh, const uint8_t* src, uin
 
 /* ------------------------------------------------------------------ frame / block headers */
 /* read_frame_header + window_size (frame.cairo:152-284, :106-129).  Lane 0. */
-__device__ static int cz_parse_frame_header(const uint8_t* p, uint64_t len, CzBroadcast& bc) {
+__device__ static __attribute__((noinline)) int cz_parse_frame_header(const uint8_t* p, uint64_t len, CzBroadcast& bc) {
     if (len < 4) return CZ_E_FH_MAGIC_READ;
     const uint32_t magic = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
     uint32_t i = 4;
@@ -413,9 +436,9 @@ __device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, u
 /* LiteralsSection::parse_from_header (literals_section.cairo:81-175) + the serial parts of
  * decompress_literals (literals_section_decoder.cairo:58-117) + SequencesHeader::parse_from_header
  * (sequence_section.cairo:77-114).  Lane 0; results in sh.bc. */
-__device__ static int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_hi) {
+__device__ static __attribute__((noinline)) int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_hi) {
     CzBroadcast& bc = sh.bc;
-    CzFBits fb; fb.g = blk; fb.stage = sh.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
+    CzFBits fb; fb.g = blk; fb.stage = sh.a.t1.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
     if (bsize == 0) return CZ_E_LS_GETBITS;                             /* :84-90 */
     const uint32_t b0 = cz_fb_byte(fb, 0), type = b0 & 3, fmt = (b0 >> 2) & 3;
     uint32_t need = type <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
@@ -443,7 +466,7 @@ __device__ static int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32
             bc.huf_fill = 1; bc.huf_nsym = nsym;
             if (used > left) return CZ_E_BLOCK_TRUNCATED;               /* (panic) slice(bytes_read, len) :89 */
             off += used; left -= used;
-        } else if (sh.st.huf_max_bits == 0) return CZ_E_LIT_UNINIT_HUF_TABLE;           /* :82-86 */
+        } else if (sh.huf_max_bits == 0) return CZ_E_LIT_UNINIT_HUF_TABLE;           /* :82-86 */
         if (streams == 4) {
             if (left < 6) return CZ_E_LIT_MISSING_JUMP_HEADER;          /* :92 */
             const uint32_t j1 = cz_fb_byte(fb, off) + (cz_fb_byte(fb, off + 1) << 8);
@@ -475,24 +498,120 @@ __device__ static int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32
     return 0;
 }
 
+__device__ static inline void cz_init_llml(CzShared& sh) {
+    for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.b.c.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
+    for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.b.c.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+}
+
+/* The huff0 streams of one block, decoded from LDS (literals_section_decoder.cairo:183-243).
+ * Lanes 0..nstreams-1 each own one backward bit reader; the bytes they consume are staged by
+ * all lanes with coalesced 16-byte loads into a 256-byte ring per stream (indexed by absolute
+ * address, zero outside the stream = the reference reader's zero-extension), and the symbols
+ * they produce are staged in LDS and flushed by all lanes, 32 symbols per stream per round.
+ * out_k = target + k*seg, at most cap_k bytes are written but every symbol is counted.
+ * Results: bc.st_count[k], bc.st_flags[k] (1 ExtraPadding, 2 stream did not end exactly). */
+__device__ static void cz_huf_streams_lds(CzShared& sh, const uint8_t* blk, uint8_t* target, uint32_t nstreams, uint32_t seg, uint32_t cap_last, int fits) {
+    CzBroadcast& bc = sh.bc;
+    const uint32_t mb = cz_uni(sh.huf_max_bits);
+    /* per-stream constants, computed by every lane for the stream it helps staging (lane>>3) and,
+       for lanes < nstreams, the stream it decodes */
+    const uint32_t ks = (uint32_t)LANE >> 3;                            /* staging role: stream of lanes 0..31 */
+    const uint32_t kd = (uint32_t)LANE < nstreams ? (uint32_t)LANE : 0; /* decoding role */
+    const uint8_t* Sd = blk + bc.stream_off[kd]; const uint32_t lend = bc.stream_len[kd]; const uint8_t* Ed = Sd + lend;
+    const uint8_t* Ss = blk + bc.stream_off[ks & 3]; const uint8_t* Es = Ss + bc.stream_len[ks & 3];
+    const int decoder = (uint32_t)LANE < nstreams;
+    /* decoder state */
+    uint64_t buf = 0; int32_t avail = 0, rem = 0; uint32_t n = 0, flags = 0, cap = 0;
+    uintptr_t next = 0;                                                 /* absolute address of the next dword to take */
+    intptr_t loaded_lo = 0;                                             /* lowest staged address of my stream (128-aligned) */
+    int active = 0;
+    if (decoder) {
+        cap = fits ? (kd < 3 && nstreams == 4 ? seg : cap_last) : 0;
+        const uint32_t lastb = lend ? Ed[-1] : 0;
+        if (lastb == 0) flags = 1;                                      /* > 8 padding reads: ExtraPadding (:190-207) */
+        else { rem = (int32_t)lend * 8 - (int32_t)(__clz((int)lastb) - 24 + 1); active = 1; }
+        next = ((uintptr_t)Ed - 1) & ~(uintptr_t)3;
+        loaded_lo = (intptr_t)(((uintptr_t)Ed - 1) & ~(uintptr_t)127) + 128;   /* nothing staged yet */
+    }
+    int first = 1;
+    uint32_t round = 0;
+    for (;;) {
+        if (!__ballot(active && rem > 0)) break;
+        /* 1. staging: keep >= 64 bytes below every live cursor in the ring (two blocks the first time) */
+        for (int pass = 0; pass < 2; pass++) {
+            const int need = decoder && active && rem > 0 && ((intptr_t)next - 64 < loaded_lo);
+            const unsigned long long nm = __ballot(need);
+            if (!nm) break;
+            if (need) loaded_lo -= 128;
+            const uint32_t lo32 = (uint32_t)(uintptr_t)loaded_lo, hi32 = (uint32_t)((uint64_t)(uintptr_t)loaded_lo >> 32);
+            const uintptr_t blkaddr = ((uintptr_t)__shfl(hi32, (int)(ks & 3)) << 32) | __shfl(lo32, (int)(ks & 3));
+            if (LANE < 32 && ((nm >> (ks & 3)) & 1ull)) {
+                const uintptr_t a = blkaddr + 16u * ((uint32_t)LANE & 7);
+                uint4 v;
+                if (a >= (uintptr_t)Ss && a + 16 <= (uintptr_t)Es) v = *(const uint4*)a;
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t bb = 0; bb < 16; bb++) { const uintptr_t q = a + bb; if (q >= (uintptr_t)Ss && q < (uintptr_t)Es) w[bb >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (bb & 3)); }
+                    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+                }
+                *(uint4*)&sh.b.h.win[ks & 3][a & 255] = v;
+            }
+            if (!first) break;                                          /* steady state: one block per round is enough */
+        }
+        first = 0;
+        __syncthreads();
+        /* 2. decode up to 32 symbols per stream */
+        uint32_t c = 0;
+        if (decoder && active && rem > 0) {
+            const uint32_t* wr = (const uint32_t*)sh.b.h.win[kd];
+            if (round == 0) {                                           /* the partial top dword: bytes [next, Ed) */
+                const uint32_t nb8 = (uint32_t)((uintptr_t)Ed - next) * 8;          /* 8..32 */
+                uint32_t w = wr[(next & 255) >> 2];
+                if (nb8 < 32) w &= (1u << nb8) - 1u;
+                buf = (uint64_t)w << (64 - nb8); avail = (int32_t)nb8; next -= 4;
+                const uint32_t pad = (uint32_t)lend * 8 - (uint32_t)rem;            /* padding + marker bits */
+                buf <<= pad; avail -= (int32_t)pad;
+            }
+            uint8_t* o = sh.b.h.out[kd];
+            while (c < 32 && rem > 0) {
+                if (avail <= 32) { const uint32_t w = wr[(next & 255) >> 2]; next -= 4; buf |= (uint64_t)w << (32 - avail); avail += 32; }
+                const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
+                const uint32_t nb = e >> 8;
+                o[c++] = (uint8_t)e;
+                buf <<= nb; avail -= (int32_t)nb; rem -= (int32_t)nb;
+            }
+            if (rem <= 0) { active = 0; if (rem != 0) flags |= 2; }     /* :234-241 */
+        }
+        if (decoder) bc.st_count[kd] = c;
+        __syncthreads();
+        /* 3. flush: 4 x 32 staged symbols, two byte stores per lane */
+        for (uint32_t i = (uint32_t)LANE; i < 128; i += 64) {
+            const uint32_t k = i >> 5, j = i & 31;
+            if (k < nstreams) {
+                const uint32_t ck = bc.st_count[k], at = round * 32 + j;
+                const uint32_t capk = fits ? (k < 3 && nstreams == 4 ? seg : cap_last) : 0;
+                if (j < ck && at < capk) target[(uint64_t)k * seg + at] = sh.b.h.out[k][j];
+            }
+        }
+        n += c;
+        round++;
+        __syncthreads();
+    }
+    if (decoder) { bc.st_count[kd] = n; bc.st_flags[kd] = flags | ((n != cap) ? 4u : 0u); }
+    __syncthreads();
+}
+
 /* Huffman literal streams -> `target` (regen bytes).  All lanes enter; returns status
  * (uniform).  literals_section_decoder.cairo:91-178. */
-__device__ static int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, uint8_t* target) {
+__device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, uint8_t* target) {
     CzBroadcast& bc = sh.bc;
-    const uint32_t regen = bc.regen, streams = bc.nstreams;
+    const uint32_t regen = cz_uni(bc.regen), streams = cz_uni(bc.nstreams);
     if (streams == 4) {
         const uint32_t seg = (regen + 3) >> 2;
         const int fits = 3 * seg <= regen;
-        if (LANE < 4) {
-            uint32_t cap = 0, o = (uint32_t)LANE * seg;
-            if (fits) cap = LANE < 3 ? seg : regen - 3 * seg;
-            uint32_t cnt, fl;
-            cz_huf_stream(sh, blk + bc.stream_off[LANE], bc.stream_len[LANE], target + (fits ? o : 0), cap, &cnt, &fl);
-            bc.st_count[LANE] = cnt; bc.st_flags[LANE] = fl | ((cnt != cap) ? 4u : 0u);
-        }
-        __syncthreads();
-        const uint32_t f0 = bc.st_flags[0], f1 = bc.st_flags[1], f2 = bc.st_flags[2], f3 = bc.st_flags[3];
-        const uint32_t total = bc.st_count[0] + bc.st_count[1] + bc.st_count[2] + bc.st_count[3];
+        cz_huf_streams_lds(sh, blk, target, 4, seg, fits ? regen - 3 * seg : 0, fits);
+        const uint32_t f0 = cz_uni(bc.st_flags[0]), f1 = cz_uni(bc.st_flags[1]), f2 = cz_uni(bc.st_flags[2]), f3 = cz_uni(bc.st_flags[3]);
+        const uint32_t total = cz_uni(bc.st_count[0] + bc.st_count[1] + bc.st_count[2] + bc.st_count[3]);
         __syncthreads();
         /* first failing stream in stream order decides (reference decodes them sequentially) */
         const uint32_t fl[4] = { f0, f1, f2, f3 };
@@ -513,13 +632,8 @@ __device__ static int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, u
         }
         return 0;
     }
-    if (LANE == 0) {                                                    /* :118-170, no end-of-stream test */
-        uint32_t cnt, fl;
-        cz_huf_stream(sh, blk + bc.stream_off[0], bc.stream_len[0], target, regen, &cnt, &fl);
-        bc.st_count[0] = cnt; bc.st_flags[0] = fl;
-    }
-    __syncthreads();
-    const uint32_t sf = bc.st_flags[0], sc = bc.st_count[0];
+    cz_huf_streams_lds(sh, blk, target, 1, 0, regen, 1);               /* :118-170, no end-of-stream test */
+    const uint32_t sf = cz_uni(bc.st_flags[0]), sc = cz_uni(bc.st_count[0]);
     __syncthreads();
     if (sf & 1u) return CZ_E_LIT_EXTRA_PADDING;
     if (sc != regen) return CZ_E_LIT_COUNT_MISMATCH;
@@ -529,7 +643,7 @@ __device__ static int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, u
 /* ------------------------------------------------------------------ sequences */
 /* maybe_update_fse_tables, serial part (sequence_section_decoder.cairo:405-647): modes,
  * RLE bytes, probability descriptions.  Lane 0.  Sets build_mask / nprobs / acc_log. */
-__device__ static int cz_parse_seq_tables(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_lo, uint32_t stage_hi) {
+__device__ static __attribute__((noinline)) int cz_parse_seq_tables(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_lo, uint32_t stage_hi) {
     CzBroadcast& bc = sh.bc;
     uint32_t off = bc.seq_body_off;
     bc.build_mask = 0;
@@ -541,21 +655,21 @@ __device__ static int cz_parse_seq_tables(CzShared& sh, const uint8_t* blk, uint
         if (modes[t] == 0) {                                            /* Predefined */
             const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
             const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u;
-            for (uint32_t s = 0; s < n; s++) sh.probs[t][s] = d[s];
+            for (uint32_t s = 0; s < n; s++) sh.a.t3.probs[t][s] = d[s];
             bc.nprobs[t] = n; bc.acc_log[t] = t == 1 ? 5u : 6u; bc.build_mask |= 1u << t;
-            sh.st.fse_rle[t] = -1;
+            sh.fse_rle[t] = -1;
         } else if (modes[t] == 1) {                                     /* RLE */
             if (left == 0) return miss[t];
-            CzFBits fb; fb.g = blk; fb.stage = sh.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
-            sh.st.fse_rle[t] = (int32_t)cz_fb_byte(fb, off); off += 1;
+            CzFBits fb; fb.g = blk; fb.stage = sh.a.t3.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
+            sh.fse_rle[t] = (int32_t)cz_fb_byte(fb, off); off += 1;
         } else if (modes[t] == 2) {                                     /* FSE_Compressed */
-            CzFBits br; br.g = blk + off; br.len = left; br.idx = 0; br.stage = sh.stage; br.stage_lo = 0; br.stage_hi = 0;
-            if (off >= stage_lo && off < stage_hi) { br.stage = sh.stage + (off - stage_lo); br.stage_hi = stage_hi - off; }
+            CzFBits br; br.g = blk + off; br.len = left; br.idx = 0; br.stage = sh.a.t3.stage; br.stage_lo = 0; br.stage_hi = 0;
+            if (off >= stage_lo && off < stage_hi) { br.stage = sh.a.t3.stage + (off - stage_lo); br.stage_hi = stage_hi - off; }
             uint32_t np, lg, used;
-            int e = cz_fse_read_probs(br, max_log[t], sh.probs[t], &np, &lg, &used, 100);
+            int e = cz_fse_read_probs(br, max_log[t], sh.a.t3.probs[t], &np, &lg, &used, 100);
             if (e) return e;
             bc.nprobs[t] = np; bc.acc_log[t] = lg; bc.build_mask |= 1u << t;
-            sh.st.fse_rle[t] = -1;
+            sh.fse_rle[t] = -1;
             off += used;
             if (off > bsize) return CZ_E_BLOCK_TRUNCATED;
         }                                                               /* Repeat: keep */
@@ -597,7 +711,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
     const int active = (uint32_t)LANE < cnt;
     if (!active) { ll = 0; ml = 0; off = 1; }
     const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
-    const uint32_t sum_ll = __shfl(incl_ll, 63), sum_tot = __shfl(incl_tot, 63);
+    const uint32_t sum_ll = cz_uni(__shfl(incl_ll, 63)), sum_tot = cz_uni(__shfl(incl_tot, 63));
     const uint32_t lit_start = x.lit_used + (incl_ll - ll);
     const uint64_t out_start = x.produced + (uint64_t)(incl_tot - tot);
     const uint64_t dst = out_start + ll;                                /* where the match goes */
@@ -610,7 +724,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
         else if (dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
     }
     const unsigned long long emask = __ballot(e != 0);
-    if (emask) { const int first = __ffsll((long long)emask) - 1; return __shfl(e, first); }
+    if (emask) { const int first = __ffsll((long long)emask) - 1; return cz_unii(__shfl(e, first)); }
 
     /* literals: short runs per lane, long runs cooperatively */
     const int long_lit = ll > 32;
@@ -622,8 +736,8 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
     unsigned long long lm = __ballot(long_lit);
     while (lm) {
         const int j = __ffsll((long long)lm) - 1; lm &= lm - 1;
-        const uint32_t n = __shfl(ll, j), ls = __shfl(lit_start, j);
-        const uint64_t os = ((uint64_t)__shfl((uint32_t)(out_start >> 32), j) << 32) | __shfl((uint32_t)out_start, j);
+        const uint32_t n = cz_uni(__shfl(ll, j)), ls = cz_uni(__shfl(lit_start, j));
+        const uint64_t os = ((uint64_t)cz_uni(__shfl((uint32_t)(out_start >> 32), j)) << 32) | cz_uni(__shfl((uint32_t)out_start, j));
         cz_lit_coop_copy(x.out + os, lit, ls, n);
     }
     __syncthreads();
@@ -648,8 +762,8 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
         unsigned long long big = __ballot(ready && ml > 32);
         while (big) {
             const int j = __ffsll((long long)big) - 1; big &= big - 1;
-            const uint32_t n = __shfl(ml, j), o = __shfl(off, j);
-            const uint64_t dj = ((uint64_t)__shfl((uint32_t)(dst >> 32), j) << 32) | __shfl((uint32_t)dst, j);
+            const uint32_t n = cz_uni(__shfl(ml, j)), o = cz_uni(__shfl(off, j));
+            const uint64_t dj = ((uint64_t)cz_uni(__shfl((uint32_t)(dst >> 32), j)) << 32) | cz_uni(__shfl((uint32_t)dst, j));
             uint8_t* d = x.out + dj; const uint8_t* s = d - o;
             if (o >= n) cz_coop_copy(d, s, n);
             else if (o >= 64) {
@@ -671,7 +785,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
 }
 
 /* ---- sequences bitstream ring (LDS) ------------------------------------------------------
- * The reversed bitstream [S, E) is staged into sh.ring by coalesced 16-byte loads, indexed by
+ * The reversed bitstream [S, E) is staged into sh.a.t4.ring by coalesced 16-byte loads, indexed by
  * ABSOLUTE address (ring[a & 2047]) so that global and LDS accesses are both 16-byte aligned.
  * Bytes outside [S, E) are written as zero, which is exactly the reference reader's
  * zero-extension below bit 0 (bit_reader_reverse.cairo:147-159). */
@@ -684,12 +798,14 @@ __device__ static void cz_ring_load_block(CzShared& sh, const uint8_t* S, const 
         for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= (uintptr_t)S && q < (uintptr_t)E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
         v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     }
-    *(uint4*)&sh.ring[a & (CZ_RING_BYTES - 1)] = v;
+    const uint32_t slot = (uint32_t)(a & (CZ_RING_BYTES - 1));
+    *(uint4*)&sh.a.t4.ring[slot] = v;
+    if (slot == CZ_RING_BYTES - 16) { *(uint32_t*)&sh.a.t4.mirror[8] = v.z; *(uint32_t*)&sh.a.t4.mirror[12] = v.w; }
 }
 /* 64 stream bits whose most significant bit is stream bit t (t >= 0); lower bits follow */
 __device__ static inline uint64_t cz_ring_window(const CzShared& sh, uint32_t sbits, int32_t t) {
     const uint32_t g = sbits + (uint32_t)t, wi = g >> 5, r = (g & 31) + 1;
-    const uint32_t* rw = (const uint32_t*)sh.ring;
+    const uint32_t* rw = (const uint32_t*)sh.a.t4.ring;
     const uint32_t M = CZ_RING_BYTES / 4 - 1;
     const uint32_t w2 = rw[wi & M], w1 = rw[(wi - 1) & M], w0 = rw[(wi - 2) & M];
     const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> r), lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> r);
@@ -728,18 +844,18 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
  * a wave scan over history transforms and execute their sequence. */
 __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit) {
     CzBroadcast& bc = sh.bc;
-    const uint32_t nseq = bc.nseq;
-    const uint8_t* S = blk + bc.bitstream_off; const uint8_t* E = blk + bsize;
+    const uint32_t nseq = cz_uni(bc.nseq);
+    const uint8_t* S = blk + cz_uni(bc.bitstream_off); const uint8_t* E = blk + bsize;
     const uint32_t sbits = (uint32_t)((uintptr_t)S & (CZ_RING_BYTES - 1)) * 8u;
     CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
     /* per-table constants: RLE tables behave like a one-entry table (num_bits 0, base 0) */
-    const int32_t rLL = sh.st.fse_rle[0], rOF = sh.st.fse_rle[1], rML = sh.st.fse_rle[2];
-    const uint32_t fLL = rLL >= 0 ? (CZ_FSE_PACK(rLL, 0, 0) | cz_fse_code_bits(sh.llml, 0, (uint32_t)rLL)) : 0;
-    const uint32_t fOF = rOF >= 0 ? (CZ_FSE_PACK(rOF, 0, 0) | cz_fse_code_bits(sh.llml, 1, (uint32_t)rOF)) : 0;
-    const uint32_t fML = rML >= 0 ? (CZ_FSE_PACK(rML, 0, 0) | cz_fse_code_bits(sh.llml, 2, (uint32_t)rML)) : 0;
+    const int32_t rLL = cz_unii(sh.fse_rle[0]), rOF = cz_unii(sh.fse_rle[1]), rML = cz_unii(sh.fse_rle[2]);
+    const uint32_t fLL = rLL >= 0 ? (CZ_FSE_PACK(rLL, 0, 0) | cz_fse_code_bits(sh.b.c.llml, 0, (uint32_t)rLL)) : 0;
+    const uint32_t fOF = rOF >= 0 ? (CZ_FSE_PACK(rOF, 0, 0) | cz_fse_code_bits(sh.b.c.llml, 1, (uint32_t)rOF)) : 0;
+    const uint32_t fML = rML >= 0 ? (CZ_FSE_PACK(rML, 0, 0) | cz_fse_code_bits(sh.b.c.llml, 2, (uint32_t)rML)) : 0;
     const int any_rle = (rLL >= 0) | (rOF >= 0) | (rML >= 0);
-    const uint32_t* TLL = sh.st.fse[0]; const uint32_t* TOF = sh.st.fse[1]; const uint32_t* TML = sh.st.fse[2];
+    const uint32_t* TLL = sh.fse_ll; const uint32_t* TOF = sh.fse_of; const uint32_t* TML = sh.fse_ml;
     /* stage the top two 1 KiB blocks of the stream */
     uintptr_t loaded_lo;
     {
@@ -758,7 +874,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         }
         if (skipped > 8) e = CZ_E_SEQ_EXTRA_PADDING;
         /* init order LL, OF, ML (:207-218); a table that was never set is TableIsUninitialized */
-        const uint32_t logs[3] = { sh.st.fse_log[0], sh.st.fse_log[1], sh.st.fse_log[2] };
+        const uint32_t logs[3] = { sh.fse_log[0], sh.fse_log[1], sh.fse_log[2] };
         const int32_t rl[3] = { rLL, rOF, rML }; uint32_t stv[3] = {0, 0, 0};
         for (int t = 0; t < 3 && !e; t++) {
             if (rl[t] >= 0) continue;
@@ -769,16 +885,16 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         bc.chunk_err = e;
     }
     __syncthreads();
-    { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+    { const int e = cz_unii(bc.chunk_err); __syncthreads(); if (e) return e; }
     CZ_PROF_ACC(sh, CZ_P_RING);
     int exec_err = 0;                                                   /* first execution error, reported only if the
                                                                            rest of the section decodes (reference order) */
-    uint32_t h0 = sh.st.hist[0], h1 = sh.st.hist[1], h2 = sh.st.hist[2];   /* uniform copy in every lane */
+    uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);   /* uniform copy in every lane */
     for (uint32_t done = 0; done < nseq; done += 64) {
         const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
         /* keep CZ_RING_NEED bytes below the cursor staged */
         {
-            const int32_t p0 = __shfl(pos, 0);
+            const int32_t p0 = cz_unii(__shfl(pos, 0));
             const intptr_t cur = (intptr_t)S + ((p0 > 0 ? p0 - 1 : 0) >> 3);
             if (cur - (intptr_t)CZ_RING_NEED < (intptr_t)loaded_lo) {
                 loaded_lo -= CZ_RING_BLOCK;
@@ -794,31 +910,36 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             const int32_t pos_save = pos; const uint32_t sLL_save = sLL, sOF_save = sOF, sML_save = sML;
             const int is_last_chunk = done + cnt >= nseq;
             const uint32_t full = is_last_chunk ? cnt - 1 : cnt;
-            uint32_t bad = 0; int32_t neg = 0; int slow = 0;
-            const uint32_t* rw = (const uint32_t*)sh.ring;
-            const uint32_t M = CZ_RING_BYTES / 4 - 1;
+            uint32_t bad = 0; int32_t neg = 0; uint32_t slow = 0;
+                        /* u = ring-space bit address just above the next unread bit; the three dwords at and
+               below u>>5 hold the next 64+ stream bits (the ring is mirrored 8 bytes below its
+               start, so ba-4 / ba-8 never wrap). */
+            int32_t u = (int32_t)sbits + pos;
+            const uint8_t* ringb = sh.a.t4.ring;
             for (uint32_t i = 0; i < full; i++) {
-                const uint32_t g = sbits + (uint32_t)pos - 1u, wi = g >> 5, r = (g & 31) + 1;
-                const uint32_t w2 = rw[wi & M], w1 = rw[(wi - 1) & M], w0 = rw[(wi - 2) & M];
-                uint32_t eLL = TLL[sLL & 511], eOF = TOF[sOF & 511], eML = TML[sML & 511];
+                const uint32_t ba = ((uint32_t)u >> 3) & (CZ_RING_BYTES - 4);
+                const uint32_t w2 = *(const uint32_t*)(ringb + ba), w1 = *(const uint32_t*)(ringb + ba - 4), w0 = *(const uint32_t*)(ringb + ba - 8);
+                uint32_t eLL = TLL[sLL], eOF = TOF[sOF], eML = TML[sML];
                 if (any_rle) { eLL = rLL >= 0 ? fLL : eLL; eOF = rOF >= 0 ? fOF : eOF; eML = rML >= 0 ? fML : eML; }
-                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 9) | (sML << 18);
+                sh.a.t4.rec_pos[i] = u - (int32_t)sbits; sh.a.t4.rec_st[i] = sLL | (sOF << 9) | (sML << 18);
                 const uint32_t sum = eLL + eOF + eML, a = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
                 bad |= eLL | eOF | eML;
-                if (a > 37) { slow = 1; break; }                        /* > 64 bits in one sequence: careful loop */
-                const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> r), lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> r);
-                const uint32_t xh = (uint32_t)(((((uint64_t)hi << 32) | lo) << a) >> 32);   /* bits right after the extra bits */
+                slow |= a > 32;                                         /* rare: more than 32 extra bits -> careful loop */
+                /* 32 stream bits that follow the `a` extra bits (read order: extras first, :239) */
+                const uint32_t ph = (uint32_t)u & 31, sel = ph >= a;
+                const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a) & 31);
                 const uint32_t nl = CZ_FSE_NB(eLL), nm = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
                 sLL = CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl);         /* update order LL, ML, OF (:258-277) */
                 sML = CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm, nm);
                 sOF = CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm - no, no);
-                pos -= (int32_t)(a + nbs);
-                neg |= pos;
+                u -= (int32_t)(a + nbs);
+                neg |= u - (int32_t)sbits;
             }
+            pos = u - (int32_t)sbits;
             if (!slow && is_last_chunk) {                               /* the block's last sequence: no state update */
-                uint32_t eLL = TLL[sLL & 511], eOF = TOF[sOF & 511], eML = TML[sML & 511];
+                uint32_t eLL = TLL[sLL & 1023], eOF = TOF[sOF & 1023], eML = TML[sML & 1023];
                 if (any_rle) { eLL = rLL >= 0 ? fLL : eLL; eOF = rOF >= 0 ? fOF : eOF; eML = rML >= 0 ? fML : eML; }
-                sh.u.rec.pos[cnt - 1] = pos; sh.u.rec.st[cnt - 1] = sLL | (sOF << 9) | (sML << 18);
+                sh.a.t4.rec_pos[cnt - 1] = pos; sh.a.t4.rec_st[cnt - 1] = sLL | (sOF << 9) | (sML << 18);
                 bad |= eLL | eOF | eML;
                 pos -= (int32_t)((eLL + eOF + eML) & 0x7F);
                 neg |= pos;
@@ -831,7 +952,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286, serial core (careful) */
                 const uint64_t W = pos > 0 ? cz_ring_window(sh, sbits, pos - 1) : 0;
                 const uint32_t eLL = rLL >= 0 ? fLL : TLL[sLL], eOF = rOF >= 0 ? fOF : TOF[sOF], eML = rML >= 0 ? fML : TML[sML];
-                sh.u.rec.pos[i] = pos; sh.u.rec.st[i] = sLL | (sOF << 9) | (sML << 18);
+                sh.a.t4.rec_pos[i] = pos; sh.a.t4.rec_st[i] = sLL | (sOF << 9) | (sML << 18);
                 if (CZ_FSE_INV(eOF)) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
                 if (CZ_FSE_INV(eLL) | CZ_FSE_INV(eML)) { e = CZ_E_SEQ_TOO_MANY_BITS; break; } /* num_bits 255 -> TooManyBits :239 */
                 const uint32_t a = CZ_FSE_XB(eOF) + CZ_FSE_XB(eML) + CZ_FSE_XB(eLL);     /* extra bits, read first (:239) */
@@ -851,18 +972,18 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             }
         }
         __syncthreads();
-        { const int e = bc.chunk_err; __syncthreads(); if (e) return e; }
+        { const int e = cz_unii(bc.chunk_err); __syncthreads(); if (e) return e; }
         CZ_PROF_ACC(sh, CZ_P_CHAIN);
         if (!exec_err) {
             /* every lane finishes its own sequence: extra bits -> (ll, ml, offset_value) */
             uint32_t ll = 0, ml = 0, ov = 4;
             const int active = (uint32_t)LANE < cnt;
             if (active) {
-                const int32_t p = sh.u.rec.pos[LANE]; const uint32_t st = sh.u.rec.st[LANE];
+                const int32_t p = sh.a.t4.rec_pos[LANE]; const uint32_t st = sh.a.t4.rec_st[LANE];
                 const uint32_t eLL = rLL >= 0 ? fLL : TLL[st & 511], eOF = rOF >= 0 ? fOF : TOF[(st >> 9) & 511], eML = rML >= 0 ? fML : TML[(st >> 18) & 511];
                 const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
                 const uint32_t oc = CZ_FSE_XB(eOF), mx = CZ_FSE_XB(eML), lx = CZ_FSE_XB(eLL);
-                const uint32_t tl = sh.llml[CZ_FSE_SYM(eLL)], tm = sh.llml[40 + CZ_FSE_SYM(eML)];
+                const uint32_t tl = sh.b.c.llml[CZ_FSE_SYM(eLL)], tm = sh.b.c.llml[40 + CZ_FSE_SYM(eML)];
                 ov = (1u << oc) + cz_field(W, 0, oc);                   /* :243 */
                 ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);            /* :249-256 */
                 ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
@@ -895,7 +1016,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             const int lastl = (int)cnt - 1;
             const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
             const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
-            h0 = n0; h1 = n1; h2 = n2;
+            h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
             CZ_PROF_ACC(sh, CZ_P_EXTRACT);
             exec_err = cz_execute_chunk(sh, x, lit, cnt, ll, ml, actual);
             CZ_PROF_T0();
@@ -903,7 +1024,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         __syncthreads();
     }
     if (exec_err) return exec_err;
-    if (LANE == 0) { sh.st.hist[0] = h0; sh.st.hist[1] = h1; sh.st.hist[2] = h2; }
+    if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
     /* remaining literals (sequence_execution.cairo:72-78) */
     if (x.lit_used < lit.len) {
         const uint32_t rest = lit.len - x.lit_used;
@@ -918,39 +1039,50 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
 
 /* ------------------------------------------------------------------ one compressed block */
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
-__device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch) {
+__device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch,
+                                           uint16_t* huf_global, int last_block) {
     CzBroadcast& bc = sh.bc;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
     const uint32_t stage_hi = bsize < 512 ? bsize : 512;
-    for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.stage[i] = blk[i];
+    for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.a.t1.stage[i] = blk[i];
     __syncthreads();
     if (LANE == 0) bc.err = cz_parse_sections(sh, blk, bsize, stage_hi);
     __syncthreads();
-    { const int e = bc.err; __syncthreads(); if (e) return e; }         /* read, then fence the slot before it is rewritten */
-    if (bc.huf_fill) { cz_huf_fill(sh, bc.huf_nsym); __syncthreads(); }
+    { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
+    if (bc.huf_fill) {
+        cz_huf_fill(sh, bc.huf_nsym); __syncthreads();
+        if (!last_block) {                                              /* carried for later Treeless blocks */
+            for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)huf_global)[i] = ((const uint32_t*)sh.a.huf)[i];
+        }
+    } else if (bc.lit_type == 3) {                                      /* Treeless: bring the carried table back */
+        for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)sh.a.huf)[i] = ((const uint32_t*)huf_global)[i];
+        __syncthreads();
+    }
     CZ_PROF_ACC(sh, CZ_P_HUFBUILD);
     /* literals */
-    CzLit lit; lit.rle = 0; lit.byte = 0; lit.len = bc.regen; lit.p = blk;
-    const uint32_t lt = bc.lit_type, nseq_early = bc.seq_hdr_err ? 1u : bc.nseq;
-    const uint32_t lit_hdr = bc.lit_total - (lt >= 2 ? 0 : 0);
-    (void)lit_hdr;
-    if (lt == 0) { lit.p = blk + (bc.lit_total - bc.regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
-    else if (lt == 1) { lit.rle = 1; lit.byte = blk[bc.lit_total - 1]; } /* RLE :43-46 */
+    const uint32_t regen = cz_uni(bc.regen), lit_total = cz_uni(bc.lit_total), nseq = cz_uni(bc.nseq);
+    const int seq_hdr_err = cz_unii(bc.seq_hdr_err);
+    CzLit lit; lit.rle = 0; lit.byte = 0; lit.len = regen; lit.p = blk;
+    const uint32_t lt = cz_uni(bc.lit_type), nseq_early = seq_hdr_err ? 1u : nseq;
+    if (lt == 0) { lit.p = blk + (lit_total - regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
+    else if (lt == 1) { lit.rle = 1; lit.byte = blk[lit_total - 1]; } /* RLE :43-46 */
     else {
         uint8_t* target = lit_scratch;
         if (nseq_early == 0) {                                          /* no sequences: decode straight into the output */
-            if (x.produced + bc.regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+            if (x.produced + regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
             target = x.out + x.produced;
-        } else if (bc.regen > CZ_LIT_SCRATCH_BYTES) return CZ_E_UNSUPPORTED;
+        } else if (regen > CZ_LIT_SCRATCH_BYTES) return CZ_E_UNSUPPORTED;
         const int e = cz_decode_huf_literals(sh, blk, target);
         if (e) return e;
         lit.p = target;
         __syncthreads();
+        cz_init_llml(sh);                                               /* region b held the stream windows */
+        __syncthreads();
     }
     CZ_PROF_ACC(sh, CZ_P_HUFDEC);
-    if (bc.seq_hdr_err) return bc.seq_hdr_err;                          /* block_decoder.cairo:198-204 */
-    if (bc.nseq == 0) {                                                 /* :229-232 */
+    if (seq_hdr_err) return seq_hdr_err;                                /* block_decoder.cairo:198-204 */
+    if (nseq == 0) {                                                 /* :229-232 */
         if (lt < 2) {
             if (x.produced + lit.len > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
             cz_lit_coop_copy(x.out + x.produced, lit, 0, lit.len);
@@ -960,20 +1092,18 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
         return 0;
     }
     /* sequence tables */
-    const uint32_t so = bc.seq_body_off;
-    uint32_t st_lo = 0, st_hi = stage_hi;
-    if (so + 192 > stage_hi && so < bsize) {                            /* restage around the table descriptions */
-        __syncthreads();
-        st_lo = so; st_hi = bsize - so < 512 ? bsize : so + 512;
-        for (uint32_t i = st_lo + (uint32_t)LANE; i < st_hi; i += 64) sh.stage[i - st_lo] = blk[i];
-        __syncthreads();
-    }
+    const uint32_t so = cz_uni(bc.seq_body_off);
+    /* T3: stage the table descriptions (region `a` no longer holds the T1 stage) */
+    __syncthreads();
+    const uint32_t st_lo = so < bsize ? so : bsize, st_hi = bsize - st_lo < 512 ? bsize : st_lo + 512;
+    for (uint32_t i = st_lo + (uint32_t)LANE; i < st_hi; i += 64) sh.a.t3.stage[i - st_lo] = blk[i];
+    __syncthreads();
     if (LANE == 0) bc.err = cz_parse_seq_tables(sh, blk, bsize, st_lo, st_hi);
     __syncthreads();
-    { const int e = bc.err; __syncthreads(); if (e) return e; }
+    { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }
     if (LANE < 3 && ((bc.build_mask >> LANE) & 1u)) {
-        cz_fse_build(sh.st.fse[LANE], sh.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.counters[LANE], sh.llml, (uint32_t)LANE);
-        sh.st.fse_log[LANE] = (uint8_t)bc.acc_log[LANE];
+        cz_fse_build(cz_fse_table(sh, LANE), sh.a.t3.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.a.t3.counters[LANE], sh.b.c.llml, (uint32_t)LANE);
+        sh.fse_log[LANE] = (uint8_t)bc.acc_log[LANE];
     }
     __syncthreads();
     x.lit_used = 0;
@@ -990,15 +1120,15 @@ struct CzFrameIO {
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
-__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, cz_frame_result* res) {
+__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, uint16_t* huf_global, cz_frame_result* res) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
     CZ_PROF_DECL; CZ_PROF_T0();
     if (io.parse_header) {
         if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(io.src, io.src_len, bc); }
         __syncthreads();
-        err = bc.err;
-        if (!err) { pos = bc.hdr_len; io.window = bc.window_size; io.has_checksum = bc.has_checksum; }
+        err = cz_unii(bc.err);
+        if (!err) { pos = cz_uni(bc.hdr_len); io.window = cz_uni64(bc.window_size); io.has_checksum = cz_uni(bc.has_checksum); }
         __syncthreads();
     }
     CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
@@ -1019,8 +1149,8 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
             bc.err = e;
         }
         __syncthreads();
-        err = bc.err;
-        const uint32_t btype = bc.btype, bsize = bc.bsize, blast = bc.blast;
+        err = cz_unii(bc.err);
+        const uint32_t btype = cz_uni(bc.btype), bsize = cz_uni(bc.bsize), blast = cz_uni(bc.blast);
         __syncthreads();
         if (err) break;
         const uint64_t body = pos + 3, avail = io.src_len - body;
@@ -1037,7 +1167,7 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
             x.produced += bsize;
         } else {
             CZ_PROF_ACC(sh, CZ_P_HDR);
-            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch);
+            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch, huf_global, (int)blast);
             CZ_PROF_T0();
             if (err) break;
         }
@@ -1069,17 +1199,16 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
 
 __device__ static void cz_state_reset(CzShared& sh) {                   /* scratch.cairo:23-40 */
     if (LANE == 0) {
-        sh.st.hist[0] = 1; sh.st.hist[1] = 4; sh.st.hist[2] = 8;
-        sh.st.fse_rle[0] = sh.st.fse_rle[1] = sh.st.fse_rle[2] = -1;
-        sh.st.fse_log[0] = sh.st.fse_log[1] = sh.st.fse_log[2] = 0; sh.st.huf_max_bits = 0;
+        sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
+        sh.fse_rle[0] = sh.fse_rle[1] = sh.fse_rle[2] = -1;
+        sh.fse_log[0] = sh.fse_log[1] = sh.fse_log[2] = 0; sh.huf_max_bits = 0;
     }
 }
 
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
-extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 2) cz_decode_frames_kernel(cz_batch_args a) {
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_kernel(cz_batch_args a) {
     __shared__ CzShared sh;
-    for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
-    for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+    cz_init_llml(sh);
     uint8_t* lit_scratch = a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride;
 #ifdef CZ_PROFILE
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
@@ -1088,28 +1217,38 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 2) cz_decode_frames_
         __syncthreads();
         if (LANE == 0) sh.frame_idx = atomicAdd(a.work_counter, 1u);
         __syncthreads();
-        const uint32_t f = sh.frame_idx;
+        const uint32_t f = cz_uni(sh.frame_idx);
         if (f >= a.n) break;
+        cz_init_llml(sh);                                               /* region b may hold a failed frame's stream windows */
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];
             io.src = t.src; io.src_len = t.src_len; io.dst = t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
             io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
             io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming;
-            /* restore carried state */
-            uint32_t* d = (uint32_t*)&sh.st; const uint32_t* s = (const uint32_t*)t.state;
-            for (uint32_t i = (uint32_t)LANE; i < sizeof(cz_device_frame_state) / 4; i += 64) d[i] = s[i];
+            /* restore carried state (the Huffman table stays in t.state->huf until a Treeless block asks for it) */
+            cz_device_frame_state* gs = t.state;
+            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { sh.fse_ll[i] = gs->fse[0][i]; sh.fse_ml[i] = gs->fse[2][i]; }
+            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) sh.fse_of[i] = gs->fse[1][i];
+            if (LANE == 0) {
+                for (int k = 0; k < 3; k++) { sh.hist[k] = gs->hist[k]; sh.fse_rle[k] = gs->fse_rle[k]; sh.fse_log[k] = gs->fse_log[k]; }
+                sh.huf_max_bits = gs->huf_max_bits;
+            }
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, &a.results[f]);
-            uint32_t* d2 = (uint32_t*)t.state; const uint32_t* s2 = (const uint32_t*)&sh.st;
-            for (uint32_t i = (uint32_t)LANE; i < sizeof(cz_device_frame_state) / 4; i += 64) d2[i] = s2[i];
+            cz_run_frame(sh, io, lit_scratch, gs->huf, &a.results[f]);
+            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = sh.fse_ll[i]; gs->fse[2][i] = sh.fse_ml[i]; }
+            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = sh.fse_of[i];
+            if (LANE == 0) {
+                for (int k = 0; k < 3; k++) { gs->hist[k] = sh.hist[k]; gs->fse_rle[k] = sh.fse_rle[k]; gs->fse_log[k] = sh.fse_log[k]; }
+                gs->huf_max_bits = sh.huf_max_bits;
+            }
         } else {
             io.src = a.in_base + a.in_off[f]; io.src_len = a.in_len[f]; io.dst = a.out_base + a.out_off[f]; io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
             io.strategy = 0; io.strategy_n = 0; io.streaming = 0;
             cz_state_reset(sh);
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, &a.results[f]);
+            cz_run_frame(sh, io, lit_scratch, (uint16_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES), &a.results[f]);
 #ifdef CZ_PROFILE
             if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
 #endif

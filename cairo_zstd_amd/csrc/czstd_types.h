@@ -7,6 +7,7 @@
 
 #define CZ_WG_THREADS 64                      /* one wavefront per frame */
 #define CZ_LIT_SCRATCH_BYTES (256 * 1024 + 256) /* Huffman regenerated size < 2^18 (literals_section.cairo:156-168) */
+#define CZ_WG_SCRATCH_BYTES (CZ_LIT_SCRATCH_BYTES + 4096)  /* + the spilled Huffman table of the frame in flight */
 
 /* Carried per-frame decoder state = the reference's DecoderScratch minus the buffers
  * (src/decoding/scratch.cairo:11-19): Huffman table, three FSE tables + RLE symbols,

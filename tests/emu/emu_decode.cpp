@@ -67,12 +67,12 @@ int main(int argc, char** argv) {
     std::vector<cz_frame_result> res(n);
     uint32_t counter = 0;
     const int grid = 2;
-    uint8_t* lit = (uint8_t*)malloc((size_t)grid * CZ_LIT_SCRATCH_BYTES);
+    uint8_t* lit = (uint8_t*)malloc((size_t)grid * CZ_WG_SCRATCH_BYTES);
     cz_batch_args a; memset(&a, 0, sizeof a);
     a.in_base = in_exact; a.in_off = in_off.data(); a.in_len = in_len.data();
     a.out_base = out; a.out_off = out_off.data(); a.out_cap = out_cap.data();
     a.results = res.data(); a.tasks = nullptr; a.n = (uint32_t)n; a.work_counter = &counter;
-    a.lit_scratch = lit; a.lit_scratch_stride = CZ_LIT_SCRATCH_BYTES;
+    a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
     pthread_barrier_init(&emu_barrier, nullptr, 64);
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
     for (int b = 0; b < grid; b++) {

@@ -48,6 +48,8 @@ __attribute__((noinline)) static unsigned long long __ballot(int pred) {
     emu_sync(); return m;
 }
 static inline uint32_t __builtin_amdgcn_ubfe(uint32_t x, uint32_t off, uint32_t width) { off &= 31; width &= 31; return width ? (x >> off) & ((1u << width) - 1u) : 0u; }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   /* callers only pass wave-uniform values */
 static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
