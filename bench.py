@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="include an RCCL gather of the decoded arenas to rank 0 in the step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--verify", type=int, default=16, help="frames per rank checked against the oracle after the run")
     args = ap.parse_args()
 
@@ -66,13 +67,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import cairo_zstd_amd as cz
+    from cairo_zstd_amd import dist as czdist
     from cairo_zstd_amd import synth
 
     # ---- synthetic batch for this rank (frames rank*F .. rank*F+F-1 of the global batch)
     F = args.frames
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.time()
-    batch = synth.generate(args.workload, F, first_index=rank * F, nthreads=max(1, min(32, ncpu // max(1, min(world, 8)))))
+    batch = synth.generate(args.workload, F, first_index=czdist.shard_first_index(F, rank), nthreads=max(1, min(32, ncpu // max(1, min(world, 8)))))
     gen_s = time.time() - t0
     out_off, out_cap, out_total = batch.out_layout(256)
     alg_bytes = int(batch.length.sum() + batch.regen.sum())       # compressed bytes read once + decoded bytes written once
@@ -90,23 +92,15 @@ def main():
 
     gather_bufs = None
     if args.gather and world > 1:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([out_total], dtype=torch.int64, device=dev))
+        sizes = czdist.all_sizes(out_total, dev)
         if rank == 0:
-            gather_bufs = [torch.empty(int(s.item()), dtype=torch.uint8, device=dev) for s in sizes]
+            gather_bufs = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
 
     def step():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
                                 t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
         if args.gather and world > 1:
-            # final gather of the decoded arenas: direct peer sends to the root so that all of its
-            # xGMI links are used concurrently (a ring would be bound by one link)
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, gather_bufs[r], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, t_out, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            czdist.gather_to_root(t_out, gather_bufs, 0)
 
     def barrier():
         if world > 1:
@@ -146,14 +140,50 @@ def main():
         del out_host
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([float(regen_bytes), float(alg_bytes), 1.0 if ok else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        regen_all, alg_all, ok_all = float(tot[0].item()), float(tot[1].item()), int(tot[2].item()) == world
+        elapsed = czdist.max_over_ranks(elapsed, dev)
+        regen_all, alg_all, ok_cnt = czdist.sum_over_ranks([regen_bytes, alg_bytes, 1.0 if ok else 0.0], dev)
+        ok_all = int(ok_cnt) == world
     else:
         regen_all, alg_all, ok_all = float(regen_bytes), float(alg_bytes), ok
+
+    # ---- the other single-GPU BASELINE configs, measured after the timed region (N=1 only): same
+    # step definition, fewer steps; reported under "other_workloads" so the line shows every config
+    others = {}
+    copy_ceiling = None
+    if world == 1 and not args.no_other_workloads:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b2 = torch.empty_like(a)
+        for _ in range(2):
+            b2.copy_(a)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            b2.copy_(a)
+        torch.cuda.synchronize()
+        copy_ceiling = 2.0 * a.numel() * 5 / (time.perf_counter() - t1) / 1e9
+        del a, b2
+        for wl in ("raw_rle", "huf_literals", "full_4a"):
+            if wl == args.workload:
+                continue
+            ob = synth.generate(wl, F, nthreads=max(1, min(32, ncpu)))
+            o_off, o_cap, o_total = ob.out_layout(256)
+            ti = torch.from_numpy(ob.base).to(dev)
+            td = [torch.from_numpy(x.astype(np.int64)).to(dev) for x in (ob.off, ob.length, o_off, o_cap)]
+            to = torch.empty(o_total, dtype=torch.uint8, device=dev)
+            tr = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            ms = []
+            for it in range(3):
+                ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), F, to.data_ptr(), td[2].data_ptr(),
+                                        td[3].data_ptr(), tr.data_ptr())
+                ms.append(ctx.last_kernel_ms())
+            r2 = tr.cpu().numpy().view(cz.RESULT_DTYPE)
+            okw = bool((r2["status"] == 0).all() and (r2["bytes_produced"] == ob.regen).all())
+            ab = int(ob.length.sum() + ob.regen.sum())
+            k = float(np.mean(ms[1:]))
+            others[wl] = {"decompressed_MBps": float(ob.regen.sum()) / (k * 1e-3) / 1e6, "kernel_ms": k,
+                          "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "all_frames_ok": okw}
+            del ti, td, to, tr
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -178,6 +208,11 @@ def main():
                          "kernel_ms_all": [round(float(x), 4) for x in kernel_ms], **ctx.launch_info()},
             "synth_seconds": round(gen_s, 2),
         }
+        if copy_ceiling is not None:
+            line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
+            line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling
+        if others:
+            line["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             import oracle
             threads = ncpu

@@ -123,18 +123,33 @@ __device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
     return v;
 }
 
-/* all-lane copy, 16 B per lane per step once dst is 16-byte aligned */
-__device__ static void cz_coop_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
-    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+/* all-lane copy, 16 B per lane per step once dst is 16-byte aligned.  Both pointers are
+ * global memory: say so, so that the loop uses global_load / global_store (not flat_*). */
+typedef __attribute__((address_space(1))) const uint8_t* cz_gcptr;
+typedef __attribute__((address_space(1))) uint8_t* cz_gptr;
+typedef __attribute__((address_space(1))) uint4* cz_gptr4;
+__device__ static void cz_coop_copy(uint8_t* dst_, const uint8_t* src_, uint64_t n) {
+    cz_gptr dst = (cz_gptr)dst_; cz_gcptr src = (cz_gcptr)src_;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst_ & 15u)) & 15u);
     if (head > n) head = (uint32_t)n;
     if ((uint32_t)LANE < head) dst[LANE] = src[LANE];
     dst += head; src += head; n -= head;
     const uint64_t nvec = n >> 4;
-    for (uint64_t i = (uint64_t)LANE; i < nvec; i += 64) {
-        uint4 v; __builtin_memcpy(&v, src + 16 * i, 16);          /* source may be unaligned */
-        *(uint4*)(dst + 16 * i) = v;
+    uint64_t i = (uint64_t)LANE;
+    /* 4 KiB per wave in flight: four independent 16-byte loads per lane before the first store,
+       so the loop is bound by bandwidth rather than by one HBM round trip per KiB */
+    for (; i + 3 * 64 < nvec; i += 4 * 64) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], (const void*)(src + 16 * (i + 64 * k)), 16);   /* source may be unaligned */
+#pragma unroll
+        for (int k = 0; k < 4; k++) __builtin_memcpy((void*)(dst + 16 * (i + 64 * k)), &v[k], 16);
     }
-    for (uint64_t i = (nvec << 4) + (uint64_t)LANE; i < n; i += 64) dst[i] = src[i];
+    for (; i < nvec; i += 64) {
+        uint4 v; __builtin_memcpy(&v, (const void*)(src + 16 * i), 16);
+        __builtin_memcpy((void*)(dst + 16 * i), &v, 16);
+    }
+    for (uint64_t t = (nvec << 4) + (uint64_t)LANE; t < n; t += 64) dst[t] = src[t];
 }
 __device__ static void cz_coop_fill(uint8_t* dst, uint8_t byte, uint64_t n) {
     uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
