@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--verify", type=int, default=16, help="frames per rank checked against the oracle after the run")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
     import torch
@@ -61,10 +63,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ngpu = torch.cuda.device_count()
+    if args.dist_backend == "nccl":
+        assert local_rank < ngpu, f"rank {rank}: LOCAL_RANK {local_rank} but only {ngpu} GPU(s) visible"
+    local_dev = local_rank % ngpu
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # device of the tiny control tensors
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import cairo_zstd_amd as cz
     from cairo_zstd_amd import dist as czdist
@@ -88,19 +98,19 @@ def main():
     t_out = torch.empty(out_total, dtype=torch.uint8, device=dev)
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
-    ctx = cz.Context(local_rank, stream.cuda_stream)
+    ctx = cz.Context(local_dev, stream.cuda_stream)
 
     gather_bufs = None
     if args.gather and world > 1:
-        sizes = czdist.all_sizes(out_total, dev)
+        sizes = czdist.all_sizes(out_total, cdev)
         if rank == 0:
-            gather_bufs = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
+            gather_bufs = [torch.empty(sz, dtype=torch.uint8, device=cdev) for sz in sizes]
 
     def step():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
                                 t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
         if args.gather and world > 1:
-            czdist.gather_to_root(t_out, gather_bufs, 0)
+            czdist.gather_to_root(t_out if args.dist_backend == "nccl" else t_out.cpu(), gather_bufs, 0)
 
     def barrier():
         if world > 1:
@@ -140,8 +150,8 @@ def main():
         del out_host
 
     if world > 1:
-        elapsed = czdist.max_over_ranks(elapsed, dev)
-        regen_all, alg_all, ok_cnt = czdist.sum_over_ranks([regen_bytes, alg_bytes, 1.0 if ok else 0.0], dev)
+        elapsed = czdist.max_over_ranks(elapsed, cdev)
+        regen_all, alg_all, ok_cnt = czdist.sum_over_ranks([regen_bytes, alg_bytes, 1.0 if ok else 0.0], cdev)
         ok_all = int(ok_cnt) == world
     else:
         regen_all, alg_all, ok_all = float(regen_bytes), float(alg_bytes), ok
