@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--verify", type=int, default=16, help="frames per rank checked against the oracle after the run")
+    ap.add_argument("--no-chain-prepass", action="store_true", help="run the FSE chains inside cz_decode_frames_kernel (single launch)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -99,6 +100,9 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
+    chain_prepass = not args.no_chain_prepass
+    if chain_prepass:
+        ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20))      # 8 B per sequence + 32 B per block
 
     gather_bufs = None
     if args.gather and world > 1:
@@ -209,7 +213,8 @@ def main():
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}", "frames_per_gpu": F,
                        "frames_total": F * world, "compressed_bytes_per_gpu": int(batch.length.sum()),
                        "decoded_bytes_per_gpu": regen_bytes, "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-                       "gather_in_step": bool(args.gather and world > 1)},
+                       "gather_in_step": bool(args.gather and world > 1),
+                       "launches_per_step": "cz_chain_kernel + cz_decode_frames_kernel" if chain_prepass else "cz_decode_frames_kernel"},
             "bit_exact": bool(ok_all), "frames_verified_vs_oracle": verified,
             "algorithmic_GBps_whole_job": alg_all * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "kernel": "cz_decode_frames_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -60,6 +60,12 @@ class Context:
         lib().cz_context_launch_info(self._h, C.byref(wg), C.byref(th), C.byref(cu))
         return dict(workgroups=wg.value, threads_per_workgroup=th.value, compute_units=cu.value)
 
+    def set_chain_arena(self, nbytes: int):
+        """Enable (nbytes > 0) / disable (0) the FSE-chain pre-pass (cz_chain_kernel) for batch decodes."""
+        st = lib().cz_context_set_chain_arena(self._h, nbytes)
+        if st:
+            raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         st = lib().cz_context_last_kernel_ms(self._h, C.byref(ms))

@@ -1,0 +1,289 @@
+/*
+ * czstd_chain.hip — cz_chain_kernel: the FSE-chain pre-pass.
+ *
+ * The interleaved LL/OF/ML FSE state machines of a sequences section are ONE serial dependency
+ * chain per block (sequence_section_decoder.cairo:223-286), and a chain step costs one LDS round
+ * trip plus ~60 in-order instructions whatever the number of active lanes.  In
+ * cz_decode_frames_kernel that chain runs on lane 0 of a 64-lane wave (1/64 of the issue
+ * bandwidth used) and the frames in flight per CU are capped by that kernel's 10.6 KB of LDS.
+ * Here the chain is all a lane does: EIGHT frames per wave, one per lane 0..7, each with its own
+ * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.9 KB per chain, 24 chains per CU);
+ * lanes 8..63 only help staging bytes.  Per sequence the lane appends one 8-byte record
+ * (bit position | LL,ML,OF codes) to the chain arena; cz_decode_frames_kernel then extracts the
+ * extra bits, resolves offsets and executes the sequences without running any chain itself.
+ *
+ * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
+ * table error, invalid code, overrun, left-over bits, more than 32 extra bits in a sequence,
+ * arena overflow, > 64 symbols in a table description) it marks the whole frame "no chain info"
+ * (frame_first[f] = 0) and the main kernel decodes that frame entirely by itself, producing the
+ * reference's status codes in the reference's order.  Nothing here reports errors.
+ */
+#define CZC_SLOTS 8
+#define CZC_MAXSYM 64
+#define CZC_RING 256u
+#define CZC_BLOCK 128u
+#define CZC_NEED 96u        /* >= 8 steps x 89 bits */
+#define CZC_STEPS 8u
+
+struct CzChainSlot {
+    uint32_t fse_ll[512], fse_ml[512], fse_of[256];
+    int16_t  probs[CZC_MAXSYM]; uint16_t counters[CZC_MAXSYM];
+    __attribute__((aligned(16))) uint8_t stage[256];     /* head of the sequences section, linear */
+    __attribute__((aligned(16))) uint8_t mirror[16];     /* mirror[8..15] == ring[248..255] */
+    uint8_t ring[CZC_RING];                              /* reversed bitstream, indexed by absolute address & 255 */
+};
+struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; };
+
+/* 16 bytes at absolute address a, zero outside [S, E) */
+__device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E) {
+    uint4 v;
+    if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (const void*)a, 16); return v; }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+}
+/* lanes 8k..8k+7 stage one 128-byte block (128-aligned absolute address) of slot k's bitstream */
+__device__ static inline void czc_stage_ring(CzChainShared& cs, unsigned long long needmask, uintptr_t block, uintptr_t S, uintptr_t E) {
+    const uint32_t k = (uint32_t)LANE >> 3;
+    /* block / S / E are the OWNER lane's values: fetch them from lane k */
+    const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)block >> 32), (int)k) << 32) | __shfl((uint32_t)block, (int)k);
+    const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)S >> 32), (int)k) << 32) | __shfl((uint32_t)S, (int)k);
+    const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)E >> 32), (int)k) << 32) | __shfl((uint32_t)E, (int)k);
+    if ((needmask >> k) & 1ull) {
+        const uintptr_t a = bk + 16u * ((uint32_t)LANE & 7);
+        const uint4 v = czc_load16(a, Sk, Ek);
+        const uint32_t slot = (uint32_t)(a & (CZC_RING - 1));
+        *(uint4*)&cs.slot[k].ring[slot] = v;
+        if (slot == CZC_RING - 16) { *(uint32_t*)&cs.slot[k].mirror[8] = v.z; *(uint32_t*)&cs.slot[k].mirror[12] = v.w; }
+    }
+}
+/* 64 stream bits below ring-space bit address u (exclusive); see cz_ring_window */
+__device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
+    const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4), ph = (uint32_t)u & 31;
+    const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
+    /* bits [u-64, u): u = 32*wi + ph, word wi holds bits >= u when ph == 0 */
+    const uint64_t hi = (((uint64_t)w2 << 32) | w1), lo = (((uint64_t)w1 << 32) | w0);
+    const uint32_t h = ph ? (uint32_t)(hi >> ph) : w1, l = ph ? (uint32_t)(lo >> ph) : w0;
+    return ((uint64_t)h << 32) | l;
+}
+
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
+    __shared__ CzChainShared cs;
+    for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) cs.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
+    for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) cs.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+    __syncthreads();
+    const int owner = LANE < CZC_SLOTS;
+    CzChainSlot& sl = cs.slot[owner ? LANE : 0];
+    for (;;) {
+        /* ---- one frame per slot */
+        uint32_t f = 0xFFFFFFFFu;
+        if (owner) f = atomicAdd(a.chain_counter, 1u);
+        int frame_live = owner && f < a.n;
+        if (!__ballot(frame_live)) break;
+        const uint8_t* src = nullptr; uint64_t len = 0, pos = 0;
+        int punt = 0;
+        uint32_t logs[3] = {0, 0, 0}; int32_t rles[3] = {-1, -1, -1};
+        uint64_t first_hdr = 0, prev_hdr = 0;
+        if (frame_live) {
+            src = a.in_base + a.in_off[f]; len = a.in_len[f];
+            /* frame header (frame.cairo:152-284): only its length and validity matter here */
+            if (len < 5) punt = 1;
+            else {
+                const uint32_t magic = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+                const uint32_t d = src[4];
+                const uint32_t single = (d >> 5) & 1, didf = d & 3, dl = didf == 3 ? 4 : didf, flag = d >> 6;
+                const uint32_t fl = flag == 0 ? (single ? 1u : 0u) : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
+                const uint32_t hl = 5 + (single ? 0 : 1) + dl + fl;
+                if (magic != 0xFD2FB528u || len < hl) punt = 1;
+                else if (!single) { const uint32_t wd = src[5]; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) punt = 1; }
+                pos = hl;
+            }
+            if (punt) frame_live = 0;
+        }
+        int frame_done = !frame_live;
+        /* ---- blocks: every slot advances to its next block that has sequences */
+        while (__ballot(!frame_done)) {
+            const uint8_t* blk = nullptr; uint32_t bsize = 0, nseq = 0, modes = 0, sbody = 0, blast = 0;
+            int have = 0;
+            if (!frame_done) {
+                for (;;) {                                              /* block_decoder.cairo:237-321 */
+                    if (len - pos < 3) { punt = 1; break; }
+                    const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
+                    const uint32_t type = (b0 >> 1) & 3, size = (b0 >> 3) | (b1 << 5) | (b2 << 13);
+                    blast = b0 & 1;
+                    if (type == 3 || size > 128u * 1024u) { punt = 1; break; }
+                    const uint64_t body = pos + 3; const uint32_t content = type == 1 ? 1u : size;
+                    if (len - body < content) { punt = 1; break; }
+                    if (type != 2) { pos = body + content; if (blast) break; continue; }
+                    /* literals section header (literals_section.cairo:81-175): sizes only */
+                    const uint8_t* p = src + body;
+                    if (size == 0) { punt = 1; break; }
+                    const uint32_t l0 = p[0], lt = l0 & 3, fmt = (l0 >> 2) & 3;
+                    const uint32_t need = lt <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
+                    if (size < need) { punt = 1; break; }
+                    const uint32_t l1 = need > 1 ? p[1] : 0, l2 = need > 2 ? p[2] : 0, l3 = need > 3 ? p[3] : 0, l4 = need > 4 ? p[4] : 0;
+                    uint32_t upper;
+                    if (lt <= 1) { const uint32_t regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
+                    else upper = fmt <= 1 ? (l1 >> 6) + (l2 << 2) : (fmt == 2 ? (l2 >> 2) + (l3 << 6) : (l2 >> 6) + (l3 << 2) + (l4 << 10));
+                    if (size - need < upper) { punt = 1; break; }
+                    const uint32_t so = need + upper, sl_ = size - so;  /* sequence_section.cairo:77-114 */
+                    if (sl_ == 0) { punt = 1; break; }
+                    const uint32_t s0 = p[so];
+                    if (s0 == 0) { pos = body + content; if (blast) break; continue; }
+                    uint32_t n = 0, hb = 0;
+                    if (s0 <= 127) { if (sl_ < 2) { punt = 1; break; } n = s0; hb = 1; }
+                    else if (s0 <= 254) { if (sl_ < 3) { punt = 1; break; } n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
+                    else { if (sl_ < 4) { punt = 1; break; } n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
+                    if (n == 0) { pos = body + content; if (blast) break; continue; }   /* 128,0: sequences = 0 but a modes byte */
+                    blk = p; bsize = size; nseq = n; modes = p[so + hb]; sbody = so + hb + 1;
+                    pos = body + content; have = 1;
+                    break;
+                }
+                if (punt || !have) frame_done = 1;
+            }
+            /* ---- stage the head of the sequences section (table descriptions) linearly: 256 bytes */
+            {
+                const unsigned long long hm = __ballot(have);
+                if (hm) {
+                    const uintptr_t base = (uintptr_t)blk + sbody, Sx = (uintptr_t)blk, Ex = (uintptr_t)blk + bsize;
+                    const uint32_t k = (uint32_t)LANE >> 3;
+                    const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)base >> 32), (int)k) << 32) | __shfl((uint32_t)base, (int)k);
+                    const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)Sx >> 32), (int)k) << 32) | __shfl((uint32_t)Sx, (int)k);
+                    const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)Ex >> 32), (int)k) << 32) | __shfl((uint32_t)Ex, (int)k);
+                    if ((hm >> k) & 1ull) for (uint32_t c = (uint32_t)LANE & 7; c < 16; c += 8) *(uint4*)&cs.slot[k].stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
+                    __syncthreads();
+                }
+            }
+            /* ---- tables (sequence_section_decoder.cairo:405-647), serial per lane */
+            uint32_t bitoff = 0; uint64_t hdr = 0;
+            uint32_t fLL = 0, fOF = 0, fML = 0;
+            if (have) {
+                uint32_t off = sbody;
+                const uint32_t md[3] = { (modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3 };
+                const uint32_t max_log[3] = { 9, 8, 9 };
+                for (int t = 0; t < 3 && !punt; t++) {
+                    uint32_t* table = t == 0 ? sl.fse_ll : (t == 1 ? sl.fse_of : sl.fse_ml);
+                    if (md[t] == 0) {
+                        const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
+                        const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u, lg = t == 1 ? 5u : 6u;
+                        for (uint32_t s = 0; s < n; s++) sl.probs[s] = d[s];
+                        cz_fse_build(table, sl.probs, n, lg, sl.counters, cs.llml, (uint32_t)t);
+                        logs[t] = lg; rles[t] = -1;
+                    } else if (md[t] == 1) {
+                        if (off >= bsize) { punt = 1; break; }
+                        rles[t] = blk[off]; off += 1;
+                    } else if (md[t] == 2) {
+                        CzFBits br; br.g = blk + off; br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
+                        if (off - sbody < 256) { br.stage = sl.stage + (off - sbody); br.stage_hi = 256 - (off - sbody); }
+                        uint32_t np, lg, used;
+                        if (cz_fse_read_probs(br, max_log[t], sl.probs, &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }
+                        cz_fse_build(table, sl.probs, np, lg, sl.counters, cs.llml, (uint32_t)t);
+                        logs[t] = lg; rles[t] = -1; off += used;
+                        if (off > bsize) { punt = 1; break; }
+                    } else if (rles[t] < 0 && logs[t] == 0) { punt = 1; break; }     /* Repeat of nothing */
+                }
+                bitoff = off;
+                if (!punt) {                                            /* arena: 4-word header + nseq records */
+                    const unsigned long long units = 4ull + nseq;
+                    hdr = 8ull + atomicAdd(a.chain_top, units);      /* indices 0..7 are reserved (0 = none) */
+                    if (hdr + units > a.chain_capacity) punt = 1;
+                }
+                if (punt) { have = 0; frame_done = 1; }
+                else {
+                    fLL = rles[0] >= 0 ? (CZ_FSE_PACK(rles[0], 0, 0) | cz_fse_code_bits(cs.llml, 0, (uint32_t)rles[0])) : 0;
+                    fOF = rles[1] >= 0 ? (CZ_FSE_PACK(rles[1], 0, 0) | cz_fse_code_bits(cs.llml, 1, (uint32_t)rles[1])) : 0;
+                    fML = rles[2] >= 0 ? (CZ_FSE_PACK(rles[2], 0, 0) | cz_fse_code_bits(cs.llml, 2, (uint32_t)rles[2])) : 0;
+                }
+            }
+            /* ---- bit ring: stage the top two 128-byte blocks of every live stream */
+            const uintptr_t S = have ? (uintptr_t)blk + bitoff : 0, E = have ? (uintptr_t)blk + bsize : 0;
+            const uint32_t sbits = (uint32_t)(S & (CZC_RING - 1)) * 8u;
+            intptr_t loaded_lo = 0;
+            {
+                const unsigned long long hm = __ballot(have);
+                __syncthreads();
+                if (hm) {
+                    const uintptr_t top = (E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZC_BLOCK - 1);
+                    czc_stage_ring(cs, hm, top, S, E);
+                    czc_stage_ring(cs, hm, top - CZC_BLOCK, S, E);
+                    loaded_lo = (intptr_t)(top - CZC_BLOCK);
+                    __syncthreads();
+                }
+            }
+            /* ---- chain */
+            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, bad = 0, slow = 0; int32_t neg = 0;
+            int chain_live = have;
+            if (have) {
+                int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
+                for (;;) {                                              /* padding :46-64 */
+                    const uint32_t b = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> 63) : 0; p -= 1; skipped++;
+                    if (b == 1 || skipped > 8) break;
+                }
+                if (skipped > 8) slow = 1;
+                uint32_t stv[3] = {0, 0, 0};
+                for (int t = 0; t < 3; t++) {                           /* init order LL, OF, ML (:207-218) */
+                    if (rles[t] >= 0) continue;
+                    stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - logs[t])) : 0; p -= (int32_t)logs[t];
+                }
+                sLL = stv[0]; sOF = stv[1]; sML = stv[2];
+                if (p < 0) slow = 1;
+                u = (int32_t)sbits + p;
+            }
+            uint64_t* rec = a.chain_arena + hdr + 4;
+            const int rLLf = rles[0] >= 0, rOFf = rles[1] >= 0, rMLf = rles[2] >= 0;
+            while (__ballot(chain_live)) {
+                /* keep CZC_NEED bytes below every live cursor staged */
+                {
+                    const intptr_t cur = (intptr_t)S + ((u - (int32_t)sbits > 0 ? u - (int32_t)sbits - 1 : 0) >> 3);
+                    const int need = chain_live && (cur - (intptr_t)CZC_NEED < loaded_lo);
+                    const unsigned long long nm = __ballot(need);
+                    if (nm) {
+                        if (need) loaded_lo -= (intptr_t)CZC_BLOCK;
+                        __syncthreads();
+                        czc_stage_ring(cs, nm, (uintptr_t)loaded_lo, S, E);
+                        __syncthreads();
+                    }
+                }
+                if (chain_live) {
+                    const uint32_t left = nseq - done, steps = left < CZC_STEPS ? left : CZC_STEPS;
+                    for (uint32_t i = 0; i < steps; i++) {              /* sequence_section_decoder.cairo:223-286, serial core */
+                        const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
+                        const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
+                        uint32_t eLL = sl.fse_ll[sLL & 511], eOF = sl.fse_of[sOF & 255], eML = sl.fse_ml[sML & 511];
+                        eLL = rLLf ? fLL : eLL; eOF = rOFf ? fOF : eOF; eML = rMLf ? fML : eML;
+                        const uint32_t codes = CZ_FSE_SYM(eLL) | (CZ_FSE_SYM(eML) << 8) | (CZ_FSE_SYM(eOF) << 16);
+                        rec[done + i] = (uint64_t)(uint32_t)(u - (int32_t)sbits) | ((uint64_t)codes << 32);
+                        const uint32_t sum = eLL + eOF + eML, a_ = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
+                        bad |= eLL | eOF | eML;
+                        slow |= a_ > 32;
+                        const int lastseq = done + i + 1 == nseq;       /* the block's last sequence updates no state (:258) */
+                        const uint32_t ph = (uint32_t)u & 31, sel = ph >= a_;
+                        const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
+                        const uint32_t nl = CZ_FSE_NB(eLL), nm_ = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
+                        sLL = CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl);
+                        sML = CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_);
+                        sOF = CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no);
+                        u -= (int32_t)(lastseq ? a_ : a_ + nbs);
+                        neg |= u - (int32_t)sbits;
+                    }
+                    done += steps;
+                    if (done >= nseq) chain_live = 0;
+                }
+            }
+            /* ---- finalize the block */
+            if (have) {
+                if (((bad >> 13) & 1) || slow || neg < 0 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* invalid code / > 32 extra bits / overrun / ExtraBits */
+                else {
+                    uint64_t* h = a.chain_arena + hdr;
+                    h[0] = ((uint64_t)nseq << 32); h[1] = bitoff; h[2] = 0; h[3] = 0;
+                    if (prev_hdr) a.chain_arena[prev_hdr + 2] = hdr; else first_hdr = hdr;
+                    prev_hdr = hdr;
+                    if (blast) frame_done = 1;
+                }
+            } else if (!frame_done && blast) frame_done = 1;
+            __syncthreads();
+        }
+        if (owner && f < a.n) a.frame_first[f] = punt ? 0 : first_hdr;
+    }
+}

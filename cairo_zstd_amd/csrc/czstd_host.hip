@@ -21,6 +21,7 @@
 #include "czstd_types.h"
 
 #include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
+#include "czstd_chain.hip"
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -36,6 +37,11 @@ struct cz_context {
     /* staging for cz_decode_batch_host */
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
     unsigned long long* d_prof = nullptr;   /* CZ_PROFILE builds: per-phase cycle sums */
+    /* optional FSE-chain pre-pass */
+    uint64_t* chain_arena = nullptr; uint64_t chain_capacity = 0;   /* 8-byte units */
+    unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
+    uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
+    int chain_grid = 0;
 };
 
 #define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
@@ -95,6 +101,9 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->work_counter) (void)hipFree(c->work_counter);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_prof) (void)hipFree(c->d_prof);
+    if (c->chain_arena) (void)hipFree(c->chain_arena);
+    if (c->chain_top) (void)hipFree(c->chain_top);
+    if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -123,6 +132,24 @@ CZ_EXPORT int cz_context_last_kernel_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 
+/* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context and
+ * sizes its record arena: 8 bytes per sequence + 32 per block; frames that do not fit fall back
+ * to in-kernel chains, so any size is safe. */
+CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
+    if (!c) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->chain_arena) { (void)hipFree(c->chain_arena); c->chain_arena = nullptr; c->chain_capacity = 0; }
+    if (!bytes) return CZ_OK;
+    if (!c->chain_top) { CZ_HIP(c, hipMalloc((void**)&c->chain_top, 64)); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
+    CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
+    c->chain_capacity = bytes / 8;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_chain_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 2;
+    c->chain_grid = c->num_cu * occ;
+    return CZ_OK;
+}
+
 /* ------------------------------------------------------------------ launch */
 static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n == 0) return CZ_OK;
@@ -133,6 +160,21 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
+    if (c->chain_arena && !a.tasks) {
+        /* pass A: eight frames per wave, one FSE chain per lane -> records in the arena */
+        if (c->frame_first_cap < n) {
+            if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
+            CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8)); c->frame_first_cap = n;
+        }
+        CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
+        a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
+        a.frame_first = c->frame_first; a.chain_counter = c->chain_counter;
+        const size_t waves = (n + 7) / 8;
+        const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
+        hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        CZ_HIP(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), 0, c->stream, a);
     CZ_HIP(c, hipGetLastError());
     CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));

@@ -239,7 +239,7 @@ __device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_
 
 /* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
 __device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
-                                        uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above) {
+                                        uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above, uint32_t cap = 256) {
     uint32_t v;
     if (cz_fb_get(br, 4, &v)) return CZ_E_FSE_GETBITS;                  /* :265-268 */
     uint32_t log = 5 + v;                                               /* :270 */
@@ -254,12 +254,12 @@ __device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, u
         else if (v > mask) value = v - low;
         else value = v;
         int32_t prob = (int32_t)value - 1;
-        if (n < 256) probs[n] = (int16_t)prob;
+        if (n < cap) probs[n] = (int16_t)prob;
         n++;
         if (prob != 0) counter += prob > 0 ? (uint32_t)prob : 1u;
         else for (;;) {                                                 /* :322-340 */
             if (cz_fb_get(br, 2, &v)) return CZ_E_FSE_GETBITS;
-            for (uint32_t k = 0; k < v; k++) { if (n < 256) probs[n] = 0; n++; }
+            for (uint32_t k = 0; k < v; k++) { if (n < cap) probs[n] = 0; n++; }
             if (v != 3) break;
         }
     }
@@ -851,6 +851,45 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
     return src == 3 ? val : cz_hist_pick(src, h0, h1, h2) + val;
 }
 
+/* Resolves the repeat offsets of up to 64 sequences (one per lane) with a wave scan over
+ * history transforms, advances the uniform history (h0,h1,h2) and executes the chunk. */
+__device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t ov,
+                                             uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    const int active = (uint32_t)LANE < cnt;
+    CZ_PROF_DECL; CZ_PROF_T0();
+    /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
+    CzHist T; T.s = 0 | (1 << 2) | (2 << 4); T.v0 = T.v1 = T.v2 = 0;              /* identity */
+    if (active) {
+        if (ov > 3) { T.s = 3 | (0 << 2) | (1 << 4); T.v0 = ov - 3; }             /* push */
+        else if (ll > 0) {
+            if (ov == 2) T.s = 1 | (0 << 2) | (2 << 4);
+            else if (ov == 3) T.s = 2 | (0 << 2) | (1 << 4);
+        } else {
+            if (ov == 1) T.s = 1 | (0 << 2) | (2 << 4);
+            else if (ov == 2) T.s = 2 | (0 << 2) | (1 << 4);
+            else { T.s = 0 | (0 << 2) | (1 << 4); T.v0 = 0xFFFFFFFFu; }           /* (h0 - 1, h0, h1) */
+        }
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        CzHist P; P.s = __shfl_up(T.s, (unsigned)d); P.v0 = __shfl_up(T.v0, (unsigned)d); P.v1 = __shfl_up(T.v1, (unsigned)d); P.v2 = __shfl_up(T.v2, (unsigned)d);
+        if (LANE >= d) T = cz_hist_compose(P, T);
+    }
+    CzHist X; X.s = __shfl_up(T.s, 1u); X.v0 = __shfl_up(T.v0, 1u); X.v1 = __shfl_up(T.v1, 1u); X.v2 = __shfl_up(T.v2, 1u);
+    if (LANE == 0) { X.s = 0 | (1 << 2) | (2 << 4); X.v0 = X.v1 = X.v2 = 0; }
+    const uint32_t b0 = cz_hist_eval(X.s & 3, X.v0, h0, h1, h2), b1 = cz_hist_eval((X.s >> 2) & 3, X.v1, h0, h1, h2),
+                   b2 = cz_hist_eval((X.s >> 4) & 3, X.v2, h0, h1, h2);          /* history before this sequence */
+    uint32_t actual;
+    if (ov > 3) actual = ov - 3;
+    else if (ll > 0) actual = ov == 1 ? b0 : (ov == 2 ? b1 : b2);
+    else actual = ov == 1 ? b1 : (ov == 2 ? b2 : b0 - 1);
+    const int lastl = (int)cnt - 1;
+    const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
+    const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
+    h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
+    CZ_PROF_ACC(sh, CZ_P_EXTRACT);
+    return cz_execute_chunk(sh, x, lit, cnt, ll, ml, actual);
+}
+
 /* decode_sequences + execute_sequences for one block.  All lanes.
  * sequence_section_decoder.cairo:35-297, sequence_execution.cairo:12-83.
  * Lane 0 runs only the serial core of the three interleaved FSE state machines (one LDS
@@ -1003,37 +1042,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
                 ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);            /* :249-256 */
                 ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
             }
-            /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
-            CzHist T; T.s = 0 | (1 << 2) | (2 << 4); T.v0 = T.v1 = T.v2 = 0;              /* identity */
-            if (active) {
-                if (ov > 3) { T.s = 3 | (0 << 2) | (1 << 4); T.v0 = ov - 3; }             /* push */
-                else if (ll > 0) {
-                    if (ov == 2) T.s = 1 | (0 << 2) | (2 << 4);
-                    else if (ov == 3) T.s = 2 | (0 << 2) | (1 << 4);
-                } else {
-                    if (ov == 1) T.s = 1 | (0 << 2) | (2 << 4);
-                    else if (ov == 2) T.s = 2 | (0 << 2) | (1 << 4);
-                    else { T.s = 0 | (0 << 2) | (1 << 4); T.v0 = 0xFFFFFFFFu; }           /* (h0 - 1, h0, h1) */
-                }
-            }
-            for (int d = 1; d < 64; d <<= 1) {
-                CzHist P; P.s = __shfl_up(T.s, (unsigned)d); P.v0 = __shfl_up(T.v0, (unsigned)d); P.v1 = __shfl_up(T.v1, (unsigned)d); P.v2 = __shfl_up(T.v2, (unsigned)d);
-                if (LANE >= d) T = cz_hist_compose(P, T);
-            }
-            CzHist X; X.s = __shfl_up(T.s, 1u); X.v0 = __shfl_up(T.v0, 1u); X.v1 = __shfl_up(T.v1, 1u); X.v2 = __shfl_up(T.v2, 1u);
-            if (LANE == 0) { X.s = 0 | (1 << 2) | (2 << 4); X.v0 = X.v1 = X.v2 = 0; }
-            const uint32_t b0 = cz_hist_eval(X.s & 3, X.v0, h0, h1, h2), b1 = cz_hist_eval((X.s >> 2) & 3, X.v1, h0, h1, h2),
-                           b2 = cz_hist_eval((X.s >> 4) & 3, X.v2, h0, h1, h2);          /* history before this sequence */
-            uint32_t actual;
-            if (ov > 3) actual = ov - 3;
-            else if (ll > 0) actual = ov == 1 ? b0 : (ov == 2 ? b1 : b2);
-            else actual = ov == 1 ? b1 : (ov == 2 ? b2 : b0 - 1);
-            const int lastl = (int)cnt - 1;
-            const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
-            const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
-            h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
-            CZ_PROF_ACC(sh, CZ_P_EXTRACT);
-            exec_err = cz_execute_chunk(sh, x, lit, cnt, ll, ml, actual);
+            exec_err = cz_history_and_execute(sh, x, lit, cnt, ll, ml, ov, h0, h1, h2);
             CZ_PROF_T0();
         }
         __syncthreads();
@@ -1052,10 +1061,70 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     return 0;
 }
 
+/* Same as cz_sequences, for a block whose FSE chain was already run by cz_chain_kernel: the
+ * per-sequence records (bit position, LL/ML/OF codes) come from the chain arena, so this pass
+ * needs neither the decoding tables nor the serial core — only the bit ring for the extra bits. */
+__device__ static int cz_sequences_rec(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit,
+                                       const uint64_t* rec, uint32_t nseq, uint32_t bitstream_off) {
+    const uint8_t* S = blk + bitstream_off; const uint8_t* E = blk + bsize;
+    const uint32_t sbits = (uint32_t)((uintptr_t)S & (CZ_RING_BYTES - 1)) * 8u;
+    CZ_PROF_DECL; CZ_PROF_T0();
+    __syncthreads();
+    uintptr_t loaded_lo;
+    {
+        const uintptr_t top = (((uintptr_t)E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZ_RING_BLOCK - 1));
+        cz_ring_load_block(sh, S, E, top); cz_ring_load_block(sh, S, E, top - CZ_RING_BLOCK);
+        loaded_lo = top - CZ_RING_BLOCK;
+    }
+    __syncthreads();
+    int exec_err = 0;
+    uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
+    for (uint32_t done = 0; done < nseq; done += 64) {
+        const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
+        const int active = (uint32_t)LANE < cnt;
+        const uint64_t r = active ? rec[done + (uint32_t)LANE] : 0;     /* coalesced 8-byte loads */
+        const int32_t p = (int32_t)(uint32_t)r; const uint32_t codes = (uint32_t)(r >> 32);
+        {
+            const int32_t p0 = cz_unii(__shfl(p, 0));
+            const intptr_t cur = (intptr_t)S + ((p0 > 0 ? p0 - 1 : 0) >> 3);
+            if (cur - (intptr_t)CZ_RING_NEED < (intptr_t)loaded_lo) {
+                __syncthreads();
+                loaded_lo -= CZ_RING_BLOCK;
+                cz_ring_load_block(sh, S, E, loaded_lo);
+                __syncthreads();
+            }
+        }
+        CZ_PROF_ACC(sh, CZ_P_RING);
+        uint32_t ll = 0, ml = 0, ov = 4;
+        if (active) {
+            const uint32_t llc = codes & 0xFF, mlc = (codes >> 8) & 0xFF, oc = (codes >> 16) & 0xFF;
+            const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
+            const uint32_t tl = sh.b.c.llml[llc], tm = sh.b.c.llml[40 + mlc];
+            ov = (1u << oc) + cz_field(W, 0, oc);                       /* sequence_section_decoder.cairo:243 */
+            ml = (tm & 0xFFFFFFu) + cz_field(W, oc, tm >> 24);          /* :249-256 */
+            ll = (tl & 0xFFFFFFu) + cz_field(W, oc + (tm >> 24), tl >> 24);
+        }
+        exec_err = cz_history_and_execute(sh, x, lit, cnt, ll, ml, ov, h0, h1, h2);
+        CZ_PROF_T0();
+        if (exec_err) return exec_err;
+        __syncthreads();
+    }
+    if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
+    if (x.lit_used < lit.len) {                                         /* sequence_execution.cairo:72-78 */
+        const uint32_t rest = lit.len - x.lit_used;
+        if (x.produced + rest > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+        cz_lit_coop_copy(x.out + x.produced, lit, x.lit_used, rest);
+        x.produced += rest;
+    }
+    __syncthreads();
+    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ one compressed block */
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
 __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch,
-                                           uint16_t* huf_global, int last_block) {
+                                           uint16_t* huf_global, int last_block, const uint64_t* arena, uint64_t& chain_cursor) {
     CzBroadcast& bc = sh.bc;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
@@ -1106,6 +1175,17 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
         __syncthreads();
         return 0;
     }
+    if (chain_cursor) {
+        /* cz_chain_kernel already ran this block's FSE chain: header = {status|nseq, bitstream_off, next} */
+        const uint64_t w0 = arena[chain_cursor], w1 = arena[chain_cursor + 1], w2 = arena[chain_cursor + 2];
+        const uint64_t* rec = arena + chain_cursor + 4;
+        chain_cursor = cz_uni64(w2);
+        const uint32_t rn = cz_uni((uint32_t)(w0 >> 32)), boff = cz_uni((uint32_t)w1);
+        if (rn != nseq) return CZ_E_INVALID_ARG;                        /* cannot happen: both passes walk the same bytes */
+        x.lit_used = 0;
+        CZ_PROF_ACC(sh, CZ_P_SEQTAB);
+        return cz_sequences_rec(sh, blk, bsize, x, lit, rec, nseq, boff);
+    }
     /* sequence tables */
     const uint32_t so = cz_uni(bc.seq_body_off);
     /* T3: stage the table descriptions (region `a` no longer holds the T1 stage) */
@@ -1135,7 +1215,8 @@ struct CzFrameIO {
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
-__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, uint16_t* huf_global, cz_frame_result* res) {
+__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, uint16_t* huf_global, cz_frame_result* res,
+                                    const uint64_t* arena, uint64_t chain_cursor) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
     CZ_PROF_DECL; CZ_PROF_T0();
@@ -1182,7 +1263,7 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
             x.produced += bsize;
         } else {
             CZ_PROF_ACC(sh, CZ_P_HDR);
-            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch, huf_global, (int)blast);
+            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor);
             CZ_PROF_T0();
             if (err) break;
         }
@@ -1250,7 +1331,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
                 sh.huf_max_bits = gs->huf_max_bits;
             }
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, gs->huf, &a.results[f]);
+            cz_run_frame(sh, io, lit_scratch, gs->huf, &a.results[f], nullptr, 0);
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = sh.fse_ll[i]; gs->fse[2][i] = sh.fse_ml[i]; }
             for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = sh.fse_of[i];
             if (LANE == 0) {
@@ -1263,7 +1344,8 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
             io.strategy = 0; io.strategy_n = 0; io.streaming = 0;
             cz_state_reset(sh);
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, (uint16_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES), &a.results[f]);
+            cz_run_frame(sh, io, lit_scratch, (uint16_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES), &a.results[f], a.chain_arena,
+                         a.chain_arena ? cz_uni64(a.frame_first[f]) : 0);
 #ifdef CZ_PROFILE
             if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
 #endif

@@ -43,6 +43,12 @@ typedef struct cz_batch_args {
     uint32_t* work_counter;                   /* zeroed before every launch */
     uint8_t* lit_scratch; uint64_t lit_scratch_stride;   /* one region per resident workgroup */
     unsigned long long* prof;                 /* diagnostic build only: per-phase cycle sums (NULL otherwise) */
+    /* optional FSE-chain pre-pass (cz_chain_kernel): NULL / 0 = disabled.  arena[] is in 8-byte units:
+       per block {status|nseq<<32, bitstream_off, next header index, 0} then nseq records
+       (bit position | LL,ML,OF codes << 32); frame_first[f] = index of frame f's first header, 0 = the
+       frame has no chain info and cz_decode_frames_kernel runs the chains itself */
+    uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
+    uint32_t* chain_counter;
 } cz_batch_args;
 
 #endif

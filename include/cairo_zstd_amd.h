@@ -88,6 +88,14 @@ int cz_decode_batch_host(cz_context* ctx,
                          void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,
                          cz_frame_result* results);
 
+/* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context
+ * and sizes its record arena (8 bytes per sequence + 32 per block; ~6x the compressed bytes
+ * covers BASELINE config 4a).  With the pre-pass a batch decode is two launches:
+ * cz_chain_kernel (eight frames per wave, one FSE state-machine chain per lane) writes
+ * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, or
+ * that are irregular in any way, are decoded entirely by cz_decode_frames_kernel as without it. */
+int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
+
 /* Duration in milliseconds of the most recent decode launch on this context, measured with
  * hipEvents recorded on the context stream around the kernel (bench.py's roofline leg).
  * Blocks until that launch has finished. */

@@ -37,13 +37,14 @@ static void* emu_watchdog(void*) {
 }
 
 #include "czstd_kernels.hip"
+#include "czstd_chain.hip"
 
-struct lane_arg { cz_batch_args a; unsigned lane, block; };
+struct lane_arg { cz_batch_args a; unsigned lane, block; int which; };
 static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    cz_decode_frames_kernel(la->a);
+    if (la->which == 0) cz_chain_kernel(la->a); else cz_decode_frames_kernel(la->a);
     emu_lane_done[la->lane] = 1;
     return nullptr;
 }
@@ -73,11 +74,22 @@ int main(int argc, char** argv) {
     a.out_base = out; a.out_off = out_off.data(); a.out_cap = out_cap.data();
     a.results = res.data(); a.tasks = nullptr; a.n = (uint32_t)n; a.work_counter = &counter;
     a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
+    /* EMU_CHAIN=<bytes>: run the FSE-chain pre-pass first, with an arena of that many bytes */
+    const char* ce = getenv("EMU_CHAIN");
+    unsigned long long chain_top[4] = {0, 0, 0, 0}; uint32_t chain_counter = 0;
+    std::vector<uint64_t> frame_first(n ? n : 1, 0);
+    uint64_t* arena = nullptr;
+    if (ce && atoll(ce) > 0) {
+        size_t bytes = (size_t)atoll(ce);
+        arena = (uint64_t*)malloc(bytes); a.chain_arena = arena; a.chain_capacity = bytes / 8; a.chain_top = chain_top;
+        a.frame_first = frame_first.data(); a.chain_counter = &chain_counter;
+    }
     pthread_barrier_init(&emu_barrier, nullptr, 64);
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
+    for (int pass = arena ? 0 : 1; pass < 2; pass++)
     for (int b = 0; b < grid; b++) {
         pthread_t th[64]; lane_arg la[64];
-        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
+        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; la[l].which = pass; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
         for (unsigned l = 0; l < 64; l++) pthread_join(th[l], nullptr);
     }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
@@ -87,6 +99,7 @@ int main(int argc, char** argv) {
         fwrite(out + out_off[i], 1, w, g);
     }
     fclose(g);
-    free(in_exact); free(out); free(lit);
+    if (arena) { unsigned long long used = 0; for (uint64_t i = 0; i < n; i++) used += frame_first[i] != 0; fprintf(stderr, "EMU_CHAIN: %llu of %llu frames have chain records, arena top %llu\n", used, (unsigned long long)n, chain_top[0]); }
+    free(in_exact); free(out); free(lit); free(arena);
     return 0;
 }

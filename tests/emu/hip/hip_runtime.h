@@ -53,3 +53,4 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   /* calle
 static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

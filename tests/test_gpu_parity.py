@@ -219,3 +219,34 @@ def test_device_pointer_batch_full_size(cz, ctx):
         assert st == 0 and oracle.xxh64(got) == oracle.xxh64(ref), i
     assert c2.last_kernel_ms() > 0
     c2.close()
+
+
+@pytest.mark.parametrize("arena_mb", [0.02, 256])
+def test_chain_prepass_matches_oracle(cz, arena_mb):
+    """cz_chain_kernel + cz_decode_frames_kernel (two-pass pipeline) == oracle, also when the record
+    arena is far too small (frames fall back to in-kernel chains) and on malformed frames."""
+    from cairo_zstd_amd import synth
+    c = cz.Context(0)
+    c.set_chain_arena(int(arena_mb * (1 << 20)))
+    try:
+        frames, caps = [], []
+        for kind, n in (("full_4a", 12), ("full_4b", 4), ("mix", 800), ("huf_literals", 4), ("raw_rle", 4)):
+            b = synth.generate(kind, n, first_index=77)
+            frames += [b.frame(i) for i in range(n)]
+            caps += [int(r) + 16 for r in b.regen]
+        for name, z, orig in corpus_pairs():
+            frames.append(z)
+            caps.append(len(orig) + 32)
+        for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=6000)):
+            for m in _mutations(z, idx)[:10]:
+                frames.append(m)
+                caps.append(len(orig) * 2 + 4096)
+        got = cz.decode_batch_host(frames, caps, c)
+        bad = []
+        for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+            st, ref, info = oracle.decode_frame(fr, cap=cap)
+            if st != int(r["status"]) or (st == 0 and out != ref):
+                bad.append((i, cz.status.name(r["status"]), cz.status.name(st)))
+        assert not bad, bad[:10]
+    finally:
+        c.close()
