@@ -100,7 +100,7 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
-    chain_prepass = not args.no_chain_prepass
+    chain_prepass = not args.no_chain_prepass and args.workload not in ("raw_rle", "huf_literals")   # no sequences there
     if chain_prepass:
         ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20))      # 8 B per sequence + 32 B per block
 
@@ -179,6 +179,8 @@ def main():
         for wl in ("raw_rle", "huf_literals", "full_4a"):
             if wl == args.workload:
                 continue
+            # the chain pre-pass only pays for frames that have sequences sections
+            ctx.set_chain_arena(0 if wl in ("raw_rle", "huf_literals") or not chain_prepass else int(batch.length.sum()) * 6 + (64 << 20))
             ob = synth.generate(wl, F, nthreads=max(1, min(32, ncpu)))
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)

@@ -7,8 +7,8 @@
  * cz_decode_frames_kernel that chain runs on lane 0 of a 64-lane wave (1/64 of the issue
  * bandwidth used) and the frames in flight per CU are capped by that kernel's 10.6 KB of LDS.
  * Here the chain is all a lane does: EIGHT frames per wave, one per lane 0..7, each with its own
- * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.9 KB per chain, 24 chains per CU);
- * lanes 8..63 only help staging bytes.  Per sequence the lane appends one 8-byte record
+ * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.9 KB per chain, 24 chains per CU in three
+ * waves; 12 slots x 2 waves measured no faster); the other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
  * (bit position | LL,ML,OF codes) to the chain arena; cz_decode_frames_kernel then extracts the
  * extra bits, resolves offsets and executes the sequences without running any chain itself.
  *
@@ -19,6 +19,7 @@
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
 #define CZC_SLOTS 8
+#define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 #define CZC_MAXSYM 64
 #define CZC_RING 256u
 #define CZC_BLOCK 128u
@@ -43,15 +44,16 @@ __device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E)
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
-/* lanes 8k..8k+7 stage one 128-byte block (128-aligned absolute address) of slot k's bitstream */
+/* lanes k*LPS .. k*LPS+LPS-1 stage one 128-byte block (128-aligned absolute address) of slot k's bitstream */
 __device__ static inline void czc_stage_ring(CzChainShared& cs, unsigned long long needmask, uintptr_t block, uintptr_t S, uintptr_t E) {
-    const uint32_t k = (uint32_t)LANE >> 3;
+    const uint32_t k = (uint32_t)LANE / CZC_LPS < CZC_SLOTS ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
+    const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
     /* block / S / E are the OWNER lane's values: fetch them from lane k */
     const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)block >> 32), (int)k) << 32) | __shfl((uint32_t)block, (int)k);
     const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)S >> 32), (int)k) << 32) | __shfl((uint32_t)S, (int)k);
     const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)E >> 32), (int)k) << 32) | __shfl((uint32_t)E, (int)k);
-    if ((needmask >> k) & 1ull) {
-        const uintptr_t a = bk + 16u * ((uint32_t)LANE & 7);
+    if (helper && ((needmask >> k) & 1ull)) for (uint32_t c = j; c < CZC_BLOCK / 16; c += CZC_LPS) {
+        const uintptr_t a = bk + 16u * c;
         const uint4 v = czc_load16(a, Sk, Ek);
         const uint32_t slot = (uint32_t)(a & (CZC_RING - 1));
         *(uint4*)&cs.slot[k].ring[slot] = v;
@@ -66,6 +68,36 @@ __device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
     const uint64_t hi = (((uint64_t)w2 << 32) | w1), lo = (((uint64_t)w1 << 32) | w0);
     const uint32_t h = ph ? (uint32_t)(hi >> ph) : w1, l = ph ? (uint32_t)(lo >> ph) : w0;
     return ((uint64_t)h << 32) | l;
+}
+
+/* `steps` chain steps of one lane (sequence_section_decoder.cairo:223-286, serial core).
+ * RLE: some table of this wave is in RLE mode (entries are then selected per lane);
+ * TAIL: the group may contain the block's last sequence (which updates no state, :258). */
+template <bool RLE, bool TAIL>
+__device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, uint32_t steps, uint32_t nseq, uint32_t done, uint32_t sbits,
+                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& bad, uint32_t& slow, int32_t& neg,
+                                        int rLLf, int rOFf, int rMLf, uint32_t fLL, uint32_t fOF, uint32_t fML) {
+    for (uint32_t i = 0; i < steps; i++) {
+        const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
+        const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
+        uint32_t eLL = sl.fse_ll[sLL], eOF = sl.fse_of[sOF], eML = sl.fse_ml[sML];
+        if (RLE) { eLL = rLLf ? fLL : eLL; eOF = rOFf ? fOF : eOF; eML = rMLf ? fML : eML; }
+        /* record: bit position | LL, ML, OF codes (the symbol is the top byte of each entry) */
+        const uint32_t codes = (eLL >> 24) | ((eML >> 24) << 8) | ((eOF >> 24) << 16);
+        rec[done + i] = (uint64_t)(uint32_t)(u - (int32_t)sbits) | ((uint64_t)codes << 32);
+        const uint32_t sum = eLL + eOF + eML, a_ = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
+        bad |= eLL | eOF | eML;
+        slow |= a_ > 32;
+        const uint32_t ph = (uint32_t)u & 31, sel = ph >= a_;
+        const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
+        const uint32_t nl = CZ_FSE_NB(eLL), nm_ = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
+        sLL = (CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl)) & 511;
+        sML = (CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_)) & 511;
+        sOF = (CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
+        if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nbs);
+        else u -= (int32_t)(a_ + nbs);
+        neg |= u - (int32_t)sbits;
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
@@ -147,11 +179,12 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 const unsigned long long hm = __ballot(have);
                 if (hm) {
                     const uintptr_t base = (uintptr_t)blk + sbody, Sx = (uintptr_t)blk, Ex = (uintptr_t)blk + bsize;
-                    const uint32_t k = (uint32_t)LANE >> 3;
+                    const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
+                    const uint32_t k = helper ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
                     const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)base >> 32), (int)k) << 32) | __shfl((uint32_t)base, (int)k);
                     const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)Sx >> 32), (int)k) << 32) | __shfl((uint32_t)Sx, (int)k);
                     const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)Ex >> 32), (int)k) << 32) | __shfl((uint32_t)Ex, (int)k);
-                    if ((hm >> k) & 1ull) for (uint32_t c = (uint32_t)LANE & 7; c < 16; c += 8) *(uint4*)&cs.slot[k].stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
+                    if (helper && ((hm >> k) & 1ull)) for (uint32_t c = j; c < 16; c += CZC_LPS) *(uint4*)&cs.slot[k].stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
                     __syncthreads();
                 }
             }
@@ -245,30 +278,18 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         __syncthreads();
                     }
                 }
-                if (chain_live) {
-                    const uint32_t left = nseq - done, steps = left < CZC_STEPS ? left : CZC_STEPS;
-                    for (uint32_t i = 0; i < steps; i++) {              /* sequence_section_decoder.cairo:223-286, serial core */
-                        const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
-                        const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
-                        uint32_t eLL = sl.fse_ll[sLL & 511], eOF = sl.fse_of[sOF & 255], eML = sl.fse_ml[sML & 511];
-                        eLL = rLLf ? fLL : eLL; eOF = rOFf ? fOF : eOF; eML = rMLf ? fML : eML;
-                        const uint32_t codes = CZ_FSE_SYM(eLL) | (CZ_FSE_SYM(eML) << 8) | (CZ_FSE_SYM(eOF) << 16);
-                        rec[done + i] = (uint64_t)(uint32_t)(u - (int32_t)sbits) | ((uint64_t)codes << 32);
-                        const uint32_t sum = eLL + eOF + eML, a_ = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
-                        bad |= eLL | eOF | eML;
-                        slow |= a_ > 32;
-                        const int lastseq = done + i + 1 == nseq;       /* the block's last sequence updates no state (:258) */
-                        const uint32_t ph = (uint32_t)u & 31, sel = ph >= a_;
-                        const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
-                        const uint32_t nl = CZ_FSE_NB(eLL), nm_ = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
-                        sLL = CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl);
-                        sML = CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_);
-                        sOF = CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no);
-                        u -= (int32_t)(lastseq ? a_ : a_ + nbs);
-                        neg |= u - (int32_t)sbits;
+                {
+                    /* uniform choice of the loop flavour for this group of CZC_STEPS steps */
+                    const uint32_t left = nseq - done;
+                    const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
+                    const int rle = __ballot(chain_live && (rLLf | rOFf | rMLf)) != 0;
+                    if (chain_live) {
+                        const uint32_t steps = left < CZC_STEPS ? left : CZC_STEPS;
+                        if (!tail && !rle) czc_group<false, false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, bad, slow, neg, 0, 0, 0, 0, 0, 0);
+                        else czc_group<true, true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, bad, slow, neg, rLLf, rOFf, rMLf, fLL, fOF, fML);
+                        done += steps;
+                        if (done >= nseq) chain_live = 0;
                     }
-                    done += steps;
-                    if (done >= nseq) chain_live = 0;
                 }
             }
             /* ---- finalize the block */

@@ -62,11 +62,12 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     if (!strstr(prop.gcnArchName, "gfx950")) { delete c; return CZ_E_NO_DEVICE; }   /* kernels are built for gfx950 only */
     c->num_cu = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, CZ_FSE_LDS_BYTES) != hipSuccess || occ <= 0) occ = 4;
     c->occupancy = occ; c->grid_max = c->num_cu * occ;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CZ_E_HIP; } c->own_stream = true; }
-    if (hipMalloc((void**)&c->lit_scratch, (size_t)c->grid_max * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
+    const int scratch_slots = c->grid_max;   /* one scratch region per resident workgroup */
+    if (hipMalloc((void**)&c->lit_scratch, (size_t)scratch_slots * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
         hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
         hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         if (c->lit_scratch) (void)hipFree(c->lit_scratch);
@@ -170,12 +171,14 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
         a.frame_first = c->frame_first; a.chain_counter = c->chain_counter;
-        const size_t waves = (n + 7) / 8;
+        const size_t waves = (n + CZC_SLOTS - 1) / CZC_SLOTS;
         const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+    /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
+       kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
+    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, a);
     CZ_HIP(c, hipGetLastError());
     CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));
     c->timed = true; c->last_grid = grid;

@@ -83,7 +83,7 @@ struct CzBroadcast {
  * created one is not the last block it is spilled to a 4 KiB global slot and re-read by
  * Treeless blocks (literals_section_decoder.cairo:82-86). */
 struct CzShared {
-    uint32_t fse_ll[512], fse_ml[512], fse_of[256];
+    uint32_t *fse_ll, *fse_ml, *fse_of;   /* 512 + 512 + 256 entries, in the dynamic part of LDS (CZ_FSE_LDS_BYTES) */
     uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
     union {
         uint16_t huf[2048];
@@ -1304,6 +1304,8 @@ __device__ static void cz_state_reset(CzShared& sh) {                   /* scrat
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_kernel(cz_batch_args a) {
     __shared__ CzShared sh;
+    CZ_DYNAMIC_LDS(cz_dyn_lds);                                         /* CZ_FSE_LDS_BYTES */
+    if (LANE == 0) { sh.fse_ll = cz_dyn_lds; sh.fse_ml = cz_dyn_lds + 512; sh.fse_of = cz_dyn_lds + 1024; }
     cz_init_llml(sh);
     uint8_t* lit_scratch = a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride;
 #ifdef CZ_PROFILE

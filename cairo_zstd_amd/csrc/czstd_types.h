@@ -5,6 +5,11 @@
 #include <stdint.h>
 #include "cairo_zstd_amd.h"
 
+#define CZ_FSE_LDS_BYTES ((512 + 512 + 256) * 4)
+/* dynamic LDS declaration (the CPU emulation harness of tests/emu supplies a static stand-in) */
+#ifndef CZ_DYNAMIC_LDS
+#define CZ_DYNAMIC_LDS(name) extern __shared__ uint32_t name[]
+#endif
 #define CZ_WG_THREADS 64                      /* one wavefront per frame */
 #define CZ_LIT_SCRATCH_BYTES (256 * 1024 + 256) /* Huffman regenerated size < 2^18 (literals_section.cairo:156-168) */
 #define CZ_WG_SCRATCH_BYTES (CZ_LIT_SCRATCH_BYTES + 4096)  /* + the spilled Huffman table of the frame in flight */

@@ -86,10 +86,11 @@ int main(int argc, char** argv) {
     }
     pthread_barrier_init(&emu_barrier, nullptr, 64);
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
+    /* passes: [chain pre-pass,] main kernel */
     for (int pass = arena ? 0 : 1; pass < 2; pass++)
     for (int b = 0; b < grid; b++) {
         pthread_t th[64]; lane_arg la[64];
-        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; la[l].which = pass; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
+        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; la[l].which = pass == 0 ? 0 : 1; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
         for (unsigned l = 0; l < 64; l++) pthread_join(th[l], nullptr);
     }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;

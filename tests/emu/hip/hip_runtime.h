@@ -14,6 +14,7 @@
 #define __device__
 #define __host__
 #define __shared__ static
+#define CZ_DYNAMIC_LDS(name) static uint32_t name[2048]   /* stand-in for `extern __shared__` dynamic LDS */
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 

@@ -250,3 +250,21 @@ def test_chain_prepass_matches_oracle(cz, arena_mb):
         assert not bad, bad[:10]
     finally:
         c.close()
+
+
+def test_more_frames_than_resident_workgroups_with_prepass(cz):
+    """Grid-size regression: both launches of the two-pass pipeline index per-workgroup scratch."""
+    from cairo_zstd_amd import synth
+    n = 9000
+    b = synth.generate("mix", n, first_index=100000)
+    c = cz.Context(0)
+    c.set_chain_arena(int(b.length.sum()) * 8 + (16 << 20))
+    try:
+        out_off, out_cap, total = b.out_layout()
+        out, res = c.decode_batch_host(b.base, b.off, b.length, out_off, out_cap, total)
+        assert (res["status"] == 0).all() and (res["bytes_produced"] == b.regen).all()
+        for i in range(0, n, 331):
+            st, ref, _ = oracle.decode_frame(b.frame(i), cap=int(b.regen[i]) + 16)
+            assert st == 0 and out[int(out_off[i]): int(out_off[i] + b.regen[i])].tobytes() == ref, i
+    finally:
+        c.close()
