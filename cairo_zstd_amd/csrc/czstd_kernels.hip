@@ -616,6 +616,117 @@ __device__ static void cz_huf_streams_lds(CzShared& sh, const uint8_t* blk, uint
     __syncthreads();
 }
 
+/* ---- self-synchronising parallel huff0 decode ---------------------------------------------
+ * A huff0 stream is a prefix code read in one direction, and prefix codes resynchronise: a
+ * decoder started in the middle of a codeword falls back onto true codeword boundaries after a
+ * few symbols.  Each stream is cut into up to 16 bit ranges, one lane per range (4 streams x 16
+ * = the whole wave instead of 4 lanes):
+ *   1. every lane decodes its range speculatively from the range boundary, without output, and
+ *      notes where it first crosses into the next range (end position) and how many symbols it saw;
+ *   2. the true start of range i+1 is the end position of range i: lanes whose start was wrong
+ *      redo their range from the corrected start; repeated until no start changes (lane 0 of a
+ *      stream starts at the true start, so this is exact after at most 16 rounds; ranges of
+ *      >= 256 bits make it 1 round in practice);
+ *   3. a segmented prefix sum of the symbol counts gives every range its output offset, and a
+ *      last pass decodes and writes.
+ * Same results as decoding the stream in one go (literals_section_decoder.cairo:183-243): the
+ * count, the exact-end test of the last range and ExtraPadding are reported as before.
+ * Every lane reads its own part of the bitstream straight from global memory, 16 bytes at a
+ * time, with the next 16 bytes always in flight. */
+struct CzGBits {
+    uintptr_t S, E;            /* stream bytes [S, E) */
+    uintptr_t next;            /* the chunk in flight is [next-16, next) ... see cz_gb_start */
+    uint4 cur, nxt;            /* chunk being consumed (high word first) / chunk in flight */
+    uint32_t left;             /* unread 32-bit words in cur */
+    uint64_t buf; int32_t avail;
+    int32_t p;                 /* bits of the stream still unread (may go <= 0: zero-extension) */
+};
+__device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E) {
+    uint4 v;
+    if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (const void*)a, 16); return v; }
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (a + 16 > S && a < E)
+        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+}
+__device__ static inline uint32_t cz_gb_word(CzGBits& g) {
+    if (g.left == 0) { g.cur = g.nxt; g.next -= 16; g.nxt = cz_gb_load(g.next - 16, g.S, g.E); g.left = 4; }
+    g.left--;
+    return g.left == 3 ? g.cur.w : (g.left == 2 ? g.cur.z : (g.left == 1 ? g.cur.y : g.cur.x));
+}
+/* position the reader so that the next bit read is stream bit p-1 */
+__device__ static inline void cz_gb_start(CzGBits& g, const uint8_t* S, const uint8_t* E, int32_t p) {
+    g.S = (uintptr_t)S; g.E = (uintptr_t)E; g.p = p;
+    const uintptr_t top = (uintptr_t)S + (uintptr_t)((p + 7) >> 3);     /* exclusive end of the byte holding bit p-1 */
+    const uint32_t drop = (uint32_t)((8 - (p & 7)) & 7);                /* bits of that byte above bit p-1 */
+    g.cur = cz_gb_load(top - 16, g.S, g.E); g.next = top - 16; g.nxt = cz_gb_load(g.next - 16, g.S, g.E); g.left = 4;
+    const uint32_t hi = cz_gb_word(g), lo = cz_gb_word(g);
+    g.buf = (((uint64_t)hi << 32) | lo) << drop; g.avail = 64 - (int32_t)drop;
+}
+/* decode from the current position while p > stop; writes at most `cap` symbols to out (may be
+ * null) but counts all of them */
+__device__ static inline uint32_t cz_gb_decode(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, uint8_t* out, uint32_t cap) {
+    uint32_t n = 0;
+    while (g.p > stop) {
+        if (g.avail <= 32) { g.buf |= (uint64_t)cz_gb_word(g) << (32 - g.avail); g.avail += 32; }
+        const uint32_t e = sh.a.huf[(uint32_t)(g.buf >> (64 - mb))];
+        const uint32_t nb = e >> 8;
+        if (out && n < cap) out[n] = (uint8_t)e;
+        n++;
+        g.buf <<= nb; g.avail -= (int32_t)nb; g.p -= (int32_t)nb;
+    }
+    return n;
+}
+
+/* All huff0 streams of a block; same contract as the sequential decoder: out_k = target + k*seg,
+ * at most cap_k bytes written, bc.st_count[k] / bc.st_flags[k] (1 ExtraPadding, 2 stream did not
+ * end exactly, 4 count != cap_k). */
+__device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint8_t* target, uint32_t nstreams, uint32_t seg, uint32_t cap_last, int fits) {
+    CzBroadcast& bc = sh.bc;
+    const uint32_t mb = cz_uni(sh.huf_max_bits);
+    const uint32_t k = nstreams == 4 ? (uint32_t)LANE >> 4 : 0, i = (uint32_t)LANE & 15;   /* stream, range */
+    const int mine = nstreams == 4 || LANE < 16;
+    const uint8_t* S = blk + bc.stream_off[k]; const uint32_t len = bc.stream_len[k]; const uint8_t* E = S + len;
+    const uint32_t cap = fits ? (k < 3 && nstreams == 4 ? seg : cap_last) : 0;
+    const uint32_t lastb = len ? E[-1] : 0;
+    const int padbad = lastb == 0;                                      /* > 8 padding reads: ExtraPadding (:190-207) */
+    const int32_t P0 = padbad ? 0 : (int32_t)len * 8 - (int32_t)(__clz((int)lastb) - 24 + 1);
+    /* ranges of >= 256 bits, at most 16 */
+    uint32_t m = (uint32_t)P0 >> 8; m = m < 1 ? 1 : (m > 16 ? 16 : m);
+    const int32_t C = (P0 + (int32_t)m - 1) / (int32_t)m;
+    const int live = mine && !padbad && i < m && P0 > 0;
+    const int32_t top_b = P0 - (int32_t)i * C;                          /* nominal start of my range */
+    const int32_t stop = (i + 1 == m) ? 0 : P0 - (int32_t)(i + 1) * C;  /* decode while p > stop */
+    CzGBits g; g.p = 0;
+    int32_t s = top_b, e = stop; uint32_t n = 0;
+    if (live) { cz_gb_start(g, S, E, s); n = cz_gb_decode(sh, g, mb, stop, nullptr, 0); e = g.p; }
+    /* 2. fix the starts until nothing moves */
+    for (int round = 0; round < 17; round++) {
+        const int32_t pe = __shfl_up(e, 1u);
+        const int changed = live && i > 0 && pe != s;
+        if (!__ballot(changed)) break;
+        if (changed) { s = pe; if (s > stop) { cz_gb_start(g, S, E, s); n = cz_gb_decode(sh, g, mb, stop, nullptr, 0); e = g.p; } else { n = 0; e = s; } }
+    }
+    /* 3. output offsets (segmented scan over the 16 lanes of a stream) and the writing pass */
+    uint32_t incl = live ? n : 0;
+    for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(incl, (unsigned)d); if ((int)i >= d) incl += t; }
+    const uint32_t total = __shfl(incl, (int)((LANE & ~15) | 15)), off = incl - (live ? n : 0);
+    const int32_t e_last = __shfl(e, (int)((LANE & ~15) + (m - 1)));
+    if (live && s > stop) {
+        cz_gb_start(g, S, E, s);
+        const uint32_t room = off < cap ? cap - off : 0;
+        cz_gb_decode(sh, g, mb, stop, target + (uint64_t)k * seg + off, room);
+    }
+    if (mine && i == 0) {
+        uint32_t fl = padbad ? 1u : 0u;
+        if (!padbad && e_last != 0) fl |= 2u;                           /* :234-241 */
+        const uint32_t cnt = padbad ? 0 : total;
+        bc.st_count[k] = cnt; bc.st_flags[k] = fl | ((cnt != cap) ? 4u : 0u);
+    }
+    __syncthreads();
+}
+
 /* Huffman literal streams -> `target` (regen bytes).  All lanes enter; returns status
  * (uniform).  literals_section_decoder.cairo:91-178. */
 __device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, uint8_t* target) {
@@ -624,7 +735,7 @@ __device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared&
     if (streams == 4) {
         const uint32_t seg = (regen + 3) >> 2;
         const int fits = 3 * seg <= regen;
-        cz_huf_streams_lds(sh, blk, target, 4, seg, fits ? regen - 3 * seg : 0, fits);
+        cz_huf_streams_par(sh, blk, target, 4, seg, fits ? regen - 3 * seg : 0, fits);
         const uint32_t f0 = cz_uni(bc.st_flags[0]), f1 = cz_uni(bc.st_flags[1]), f2 = cz_uni(bc.st_flags[2]), f3 = cz_uni(bc.st_flags[3]);
         const uint32_t total = cz_uni(bc.st_count[0] + bc.st_count[1] + bc.st_count[2] + bc.st_count[3]);
         __syncthreads();
@@ -647,7 +758,7 @@ __device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared&
         }
         return 0;
     }
-    cz_huf_streams_lds(sh, blk, target, 1, 0, regen, 1);               /* :118-170, no end-of-stream test */
+    cz_huf_streams_par(sh, blk, target, 1, 0, regen, 1);               /* :118-170, no end-of-stream test */
     const uint32_t sf = cz_uni(bc.st_flags[0]), sc = cz_uni(bc.st_count[0]);
     __syncthreads();
     if (sf & 1u) return CZ_E_LIT_EXTRA_PADDING;

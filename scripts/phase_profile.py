@@ -27,6 +27,8 @@ def main():
     t_out = torch.empty(total, dtype=torch.uint8, device=dev)
     t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
+    if len(sys.argv) > 3 and sys.argv[3] == "prepass":
+        ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
     buf = (C.c_uint64 * 64)()
     for it in range(2):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
