@@ -46,7 +46,8 @@ __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_un
 #define CZ_PROF_T0() do { } while (0)
 #define CZ_PROF_ACC(sh_, idx) do { } while (0)
 #endif
-enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER, CZ_P_COUNT };
+enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER,
+       CZ_P_HUF_SPEC, CZ_P_HUF_SYNC, CZ_P_HUF_WRITE, CZ_P_COUNT };   /* the last three are sub-phases of CZ_P_HUFDEC (counted in both) */
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
@@ -633,48 +634,85 @@ __device__ static void cz_huf_streams_lds(CzShared& sh, const uint8_t* blk, uint
  * count, the exact-end test of the last range and ExtraPadding are reported as before.
  * Every lane reads its own part of the bitstream straight from global memory, 16 bytes at a
  * time, with the next 16 bytes always in flight. */
+/* Per-lane reader: a 32-byte register window reloaded by ALL lanes at the same loop iteration
+ * (one overlapped HBM/L2 round trip per CZ_GB_SYMS symbols for the whole wave; per-lane refills at
+ * data-dependent iterations would stall the wave on nearly every symbol). */
+#define CZ_GB_SYMS 20u         /* 20 symbols x 11 bits + 11 bits of lookahead <= 256 - 7 */
 struct CzGBits {
     uintptr_t S, E;            /* stream bytes [S, E) */
-    uintptr_t next;            /* the chunk in flight is [next-16, next) ... see cz_gb_start */
-    uint4 cur, nxt;            /* chunk being consumed (high word first) / chunk in flight */
-    uint32_t left;             /* unread 32-bit words in cur */
-    uint64_t buf; int32_t avail;
+    uintptr_t LB;              /* lowest address that is safe to read (start of the block): bytes in [LB, S) are
+                                  loaded with the stream and masked to zero instead of being fetched one by one */
     int32_t p;                 /* bits of the stream still unread (may go <= 0: zero-extension) */
 };
-__device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E) {
+__device__ static inline uint32_t cz_mask_low_bytes(uint32_t w, uint32_t word_lo, uint32_t nbytes) {
+    return nbytes >= word_lo + 4 ? 0u : (nbytes > word_lo ? w & (0xFFFFFFFFu << (8 * (nbytes - word_lo))) : w);
+}
+__device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E, uintptr_t LB) {
     uint4 v;
-    if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (const void*)a, 16); return v; }
+    if (a >= LB && a + 16 <= E) {
+        __builtin_memcpy(&v, (const void*)a, 16);
+        if (a < S) {                                                    /* zero the bytes below the stream start */
+            const uint32_t nb = (uint32_t)(S - a) > 16 ? 16u : (uint32_t)(S - a);
+            v.x = cz_mask_low_bytes(v.x, 0, nb); v.y = cz_mask_low_bytes(v.y, 4, nb); v.z = cz_mask_low_bytes(v.z, 8, nb); v.w = cz_mask_low_bytes(v.w, 12, nb);
+        }
+        return v;
+    }
     uint32_t w[4] = {0, 0, 0, 0};
     if (a + 16 > S && a < E)
         for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
-__device__ static inline uint32_t cz_gb_word(CzGBits& g) {
-    if (g.left == 0) { g.cur = g.nxt; g.next -= 16; g.nxt = cz_gb_load(g.next - 16, g.S, g.E); g.left = 4; }
-    g.left--;
-    return g.left == 3 ? g.cur.w : (g.left == 2 ? g.cur.z : (g.left == 1 ? g.cur.y : g.cur.x));
-}
-/* position the reader so that the next bit read is stream bit p-1 */
-__device__ static inline void cz_gb_start(CzGBits& g, const uint8_t* S, const uint8_t* E, int32_t p) {
-    g.S = (uintptr_t)S; g.E = (uintptr_t)E; g.p = p;
-    const uintptr_t top = (uintptr_t)S + (uintptr_t)((p + 7) >> 3);     /* exclusive end of the byte holding bit p-1 */
-    const uint32_t drop = (uint32_t)((8 - (p & 7)) & 7);                /* bits of that byte above bit p-1 */
-    g.cur = cz_gb_load(top - 16, g.S, g.E); g.next = top - 16; g.nxt = cz_gb_load(g.next - 16, g.S, g.E); g.left = 4;
-    const uint32_t hi = cz_gb_word(g), lo = cz_gb_word(g);
-    g.buf = (((uint64_t)hi << 32) | lo) << drop; g.avail = 64 - (int32_t)drop;
-}
-/* decode from the current position while p > stop; writes at most `cap` symbols to out (may be
- * null) but counts all of them */
-__device__ static inline uint32_t cz_gb_decode(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, uint8_t* out, uint32_t cap) {
+/* One interval: reload the window at the current position, then decode up to CZ_GB_SYMS symbols
+ * while p > stop.  `run` = this lane still has work.  Returns symbols decoded. */
+__device__ static inline uint32_t cz_gb_interval(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, int run, uint8_t* out, uint32_t cap, uint32_t n0) {
     uint32_t n = 0;
-    while (g.p > stop) {
-        if (g.avail <= 32) { g.buf |= (uint64_t)cz_gb_word(g) << (32 - g.avail); g.avail += 32; }
-        const uint32_t e = sh.a.huf[(uint32_t)(g.buf >> (64 - mb))];
-        const uint32_t nb = e >> 8;
-        if (out && n < cap) out[n] = (uint8_t)e;
-        n++;
-        g.buf <<= nb; g.avail -= (int32_t)nb; g.p -= (int32_t)nb;
+    if (run) {
+        const int32_t p = g.p;
+        const uintptr_t top = g.S + (uintptr_t)((p + 7) >> 3);          /* exclusive end of the byte holding bit p-1 */
+        const uint32_t drop = (uint32_t)((8 - (p & 7)) & 7);            /* bits of that byte above bit p-1 */
+        const uint4 hi4 = cz_gb_load(top - 16, g.S, g.E, g.LB), lo4 = cz_gb_load(top - 32, g.S, g.E, g.LB);
+        uint64_t buf = ((((uint64_t)hi4.w) << 32) | hi4.z) << drop; int32_t avail = 64 - (int32_t)drop;
+        uint32_t q5 = hi4.y, q4 = hi4.x, q3 = lo4.w, q2 = lo4.z, q1 = lo4.y, q0 = lo4.x;   /* unread words, q5 next */
+        /* CZ_GB_SYMS symbols in five groups of four, collected in registers: a full interval is
+           written with one 16-byte and one 4-byte store (unaligned), a partial one byte by byte */
+        uint32_t word[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t grp = 0; grp < CZ_GB_SYMS / 4; grp++) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (g.p > stop) {
+                    if (avail <= 32) { buf |= (uint64_t)q5 << (32 - avail); avail += 32; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = q0; q0 = 0; }
+                    const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
+                    const uint32_t nb = e >> 8;
+                    word[grp] |= (e & 0xFFu) << (8 * j); n++;
+                    buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
+                }
+            }
+        }
+        if (out) {
+            if (n == CZ_GB_SYMS && n0 + CZ_GB_SYMS <= cap) {
+                uint4 v; v.x = word[0]; v.y = word[1]; v.z = word[2]; v.w = word[3];
+                __builtin_memcpy(out + n0, &v, 16); __builtin_memcpy(out + n0 + 16, &word[4], 4);
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < CZ_GB_SYMS; t++) if (t < n && n0 + t < cap) out[n0 + t] = (uint8_t)(word[t >> 2] >> (8 * (t & 3)));
+            }
+        }
+    }
+    return n;
+}
+/* decode from position g.p while p > stop (all 64 lanes call this together; `live` lanes work) */
+__device__ static inline uint32_t cz_gb_decode(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, int live, uint8_t* out, uint32_t cap,
+                                            int32_t* ck = nullptr) {
+    uint32_t n = 0, it = 0;
+    for (;;) {
+        const int run = live && g.p > stop;
+        if (!__ballot(run)) break;
+        const uint32_t got = cz_gb_interval(sh, g, mb, stop, run, out, cap, n);
+        n += got; it++;
+        /* checkpoints of the speculative pass: position after 1, 2, 4 and 8 FULL intervals */
+        if (ck && run && got == CZ_GB_SYMS) { if (it == 1) ck[0] = g.p; else if (it == 2) ck[1] = g.p; else if (it == 4) ck[2] = g.p; else if (it == 8) ck[3] = g.p; }
     }
     return n;
 }
@@ -698,26 +736,48 @@ __device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint
     const int live = mine && !padbad && i < m && P0 > 0;
     const int32_t top_b = P0 - (int32_t)i * C;                          /* nominal start of my range */
     const int32_t stop = (i + 1 == m) ? 0 : P0 - (int32_t)(i + 1) * C;  /* decode while p > stop */
-    CzGBits g; g.p = 0;
+    CzGBits g; g.S = (uintptr_t)S; g.E = (uintptr_t)E; g.LB = (uintptr_t)blk; g.p = top_b;
     int32_t s = top_b, e = stop; uint32_t n = 0;
-    if (live) { cz_gb_start(g, S, E, s); n = cz_gb_decode(sh, g, mb, stop, nullptr, 0); e = g.p; }
+    CZ_PROF_DECL; CZ_PROF_T0();
+    const int32_t CK_NONE = (int32_t)0x80000000;
+    int32_t ck[4] = { CK_NONE, CK_NONE, CK_NONE, CK_NONE };            /* positions the speculative pass went through */
+    n = cz_gb_decode(sh, g, mb, stop, live, nullptr, 0, ck);           /* 1. speculative pass */
+    if (live) e = g.p;
+    CZ_PROF_ACC(sh, CZ_P_HUF_SPEC);
     /* 2. fix the starts until nothing moves */
     for (int round = 0; round < 17; round++) {
         const int32_t pe = __shfl_up(e, 1u);
         const int changed = live && i > 0 && pe != s;
         if (!__ballot(changed)) break;
-        if (changed) { s = pe; if (s > stop) { cz_gb_start(g, S, E, s); n = cz_gb_decode(sh, g, mb, stop, nullptr, 0); e = g.p; } else { n = 0; e = s; } }
+        /* A corrected lane rarely has to redo its whole range: as soon as it lands exactly on a
+           position its speculative pass went through, the rest of that pass (end position, symbol
+           count) is already the truth.  Checkpoint j was taken after 20 << j symbols. */
+        if (changed) { s = pe; g.p = s; }
+        uint32_t nred = 0; int state = changed ? 0 : 2;                 /* 0 redoing, 1 merged into the old trajectory, 2 done */
+        for (int j = 0; j < 4; j++) {
+            const int try_ck = state == 0 && ck[j] != CK_NONE && ck[j] > stop;
+            nred += cz_gb_decode(sh, g, mb, try_ck ? ck[j] : stop, try_ck, nullptr, 0);
+            if (try_ck) {
+                if (g.p == ck[j]) { n = nred + (n - (CZ_GB_SYMS << j)); state = 1; }   /* e stays */
+                else if (g.p <= stop) { n = nred; e = g.p; state = 2; ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE; }
+            }
+        }
+        nred += cz_gb_decode(sh, g, mb, stop, state == 0, nullptr, 0);
+        if (state == 0) { n = nred; e = g.p; }
+        if (changed) ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE;           /* counts no longer line up with the checkpoints */
     }
+    CZ_PROF_ACC(sh, CZ_P_HUF_SYNC);
     /* 3. output offsets (segmented scan over the 16 lanes of a stream) and the writing pass */
     uint32_t incl = live ? n : 0;
     for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(incl, (unsigned)d); if ((int)i >= d) incl += t; }
     const uint32_t total = __shfl(incl, (int)((LANE & ~15) | 15)), off = incl - (live ? n : 0);
     const int32_t e_last = __shfl(e, (int)((LANE & ~15) + (m - 1)));
-    if (live && s > stop) {
-        cz_gb_start(g, S, E, s);
+    {
+        g.p = s;
         const uint32_t room = off < cap ? cap - off : 0;
-        cz_gb_decode(sh, g, mb, stop, target + (uint64_t)k * seg + off, room);
+        cz_gb_decode(sh, g, mb, stop, live, target + (uint64_t)k * seg + off, room);
     }
+    CZ_PROF_ACC(sh, CZ_P_HUF_WRITE);
     if (mine && i == 0) {
         uint32_t fl = padbad ? 1u : 0u;
         if (!padbad && e_last != 0) fl |= 2u;                           /* :234-241 */

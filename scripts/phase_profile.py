@@ -14,7 +14,8 @@ import torch
 import cairo_zstd_amd as cz
 from cairo_zstd_amd import synth
 
-PHASES = ["hdr", "huf_build", "huf_decode", "seq_tables", "ring", "chain", "extract", "lit_copy", "match", "raw_rle", "other"]
+PHASES = ["hdr", "huf_build", "huf_decode", "seq_tables", "ring", "chain", "extract", "lit_copy", "match", "raw_rle", "other",
+          "(huf_spec)", "(huf_sync)", "(huf_write)"]
 
 
 def main():
@@ -36,7 +37,7 @@ def main():
         k = cz.lib().cz_context_read_profile(ctx._h, buf, 64)
     ms = ctx.last_kernel_ms()
     vals = [buf[i] for i in range(k)]
-    tot = sum(vals) or 1
+    tot = sum(vals[:11]) or 1
     res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
     print(f"{kind} n={n} kernel {ms:.3f} ms (instrumented), status ok={bool((res['status'] == 0).all())}, launch={ctx.launch_info()}")
     for name, v in zip(PHASES, vals):
