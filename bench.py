@@ -100,7 +100,9 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
-    chain_prepass = not args.no_chain_prepass and args.workload not in ("raw_rle", "huf_literals")   # no sequences there
+    # the FSE-chain pre-pass pays for long chains in large blocks (configs 4a/4b); on short, irregular
+    # blocks (mix) and on blocks without sequences it is measured slower than in-kernel chains
+    chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b")
     if chain_prepass:
         ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20))      # 8 B per sequence + 32 B per block
 
@@ -180,7 +182,7 @@ def main():
             if wl == args.workload:
                 continue
             # the chain pre-pass only pays for frames that have sequences sections
-            ctx.set_chain_arena(0 if wl in ("raw_rle", "huf_literals") or not chain_prepass else int(batch.length.sum()) * 6 + (64 << 20))
+            ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20) if wl in ("full_4a", "full_4b") and not args.no_chain_prepass else 0)
             ob = synth.generate(wl, F, nthreads=max(1, min(32, ncpu)))
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)

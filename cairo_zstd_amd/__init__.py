@@ -60,8 +60,10 @@ class Context:
         lib().cz_context_launch_info(self._h, C.byref(wg), C.byref(th), C.byref(cu))
         return dict(workgroups=wg.value, threads_per_workgroup=th.value, compute_units=cu.value)
 
-    def set_chain_arena(self, nbytes: int):
+    def set_chain_arena(self, nbytes: int, min_sequences: int | None = None):
         """Enable (nbytes > 0) / disable (0) the FSE-chain pre-pass (cz_chain_kernel) for batch decodes."""
+        if min_sequences is not None:
+            lib().cz_context_set_chain_min_sequences(self._h, min_sequences)
         st = lib().cz_context_set_chain_arena(self._h, nbytes)
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")

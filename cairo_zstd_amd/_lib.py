@@ -33,7 +33,7 @@ class BlockHeader(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the library in-tree with hipcc for gfx950 (csrc/Makefile)."""
-    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_types.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_types.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("cairo_zstd_amd.h", "cairo_zstd_amd_status.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     L.cz_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_set_chain_arena.restype = C.c_int
     L.cz_context_set_chain_arena.argtypes = [vp, sz]
+    L.cz_context_set_chain_min_sequences.restype = C.c_int
+    L.cz_context_set_chain_min_sequences.argtypes = [vp, C.c_uint32]
     L.cz_context_read_profile.restype = C.c_int
     L.cz_context_read_profile.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.cz_decode_batch_device.restype = C.c_int

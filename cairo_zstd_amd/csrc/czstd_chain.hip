@@ -14,7 +14,8 @@
  *
  * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
  * table error, invalid code, overrun, left-over bits, more than 32 extra bits in a sequence,
- * arena overflow, > 64 symbols in a table description) it marks the whole frame "no chain info"
+ * arena overflow, > 64 symbols in a table description) — and for frames whose first sequences
+ * section is short (chain_min_nseq), where it would not pay — it marks the whole frame "no chain info"
  * (frame_first[f] = 0) and the main kernel decodes that frame entirely by itself, producing the
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
@@ -25,6 +26,8 @@
 #define CZC_BLOCK 128u
 #define CZC_NEED 96u        /* >= 8 steps x 89 bits */
 #define CZC_STEPS 8u
+/* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
+   main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
 
 struct CzChainSlot {
     uint32_t fse_ll[512], fse_ml[512], fse_of[256];
@@ -168,6 +171,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     else if (s0 <= 254) { if (sl_ < 3) { punt = 1; break; } n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
                     else { if (sl_ < 4) { punt = 1; break; } n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
                     if (n == 0) { pos = body + content; if (blast) break; continue; }   /* 128,0: sequences = 0 but a modes byte */
+                    if (first_hdr == 0 && n < a.chain_min_nseq) { punt = 1; break; }
                     blk = p; bsize = size; nseq = n; modes = p[so + hb]; sbody = so + hb + 1;
                     pos = body + content; have = 1;
                     break;

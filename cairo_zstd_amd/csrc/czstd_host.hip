@@ -41,7 +41,7 @@ struct cz_context {
     uint64_t* chain_arena = nullptr; uint64_t chain_capacity = 0;   /* 8-byte units */
     unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
-    int chain_grid = 0;
+    int chain_grid = 0; uint32_t chain_min_nseq = 2048;
 };
 
 #define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
@@ -151,6 +151,9 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
+/* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
+CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
+
 /* ------------------------------------------------------------------ launch */
 static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n == 0) return CZ_OK;
@@ -170,7 +173,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         }
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
-        a.frame_first = c->frame_first; a.chain_counter = c->chain_counter;
+        a.frame_first = c->frame_first; a.chain_counter = c->chain_counter; a.chain_min_nseq = c->chain_min_nseq;
         const size_t waves = (n + CZC_SLOTS - 1) / CZC_SLOTS;
         const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);

@@ -77,7 +77,8 @@ struct CzBroadcast {
  * three FSE tables, RLE symbols, offset history.  Everything else is phase-local and shares
  * region `a`:
  *   T1 parse literals section / Huffman weights   (stage, probs0, counters0, wtab)
- *   T2 Huffman table, live while the literal streams decode        (huf)
+ *   T2 Huffman table, live while the literal streams decode        (huf; the streams themselves are read
+ *      straight from global memory into per-lane register windows)
  *   T3 parse + build the sequence tables                           (stage, probs, counters)
  *   T4 sequence decode                                             (bit ring, chain records)
  * The Huffman table is the only carried item that does not stay in LDS: when a block that
@@ -92,9 +93,8 @@ struct CzShared {
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
         struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64]; } t4;   /* mirror[8..15] == ring[2040..2047] */
     } a;
-    union {
+    struct {
         struct { uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
-        struct { __attribute__((aligned(16))) uint8_t win[4][256]; uint8_t out[4][32]; } h;   /* T2: per-stream bit windows + output staging */
     } b;
     CzBroadcast bc;
     uint32_t frame_idx;
@@ -517,104 +517,6 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(CzShared& sh, 
 __device__ static inline void cz_init_llml(CzShared& sh) {
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.b.c.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.b.c.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
-}
-
-/* The huff0 streams of one block, decoded from LDS (literals_section_decoder.cairo:183-243).
- * Lanes 0..nstreams-1 each own one backward bit reader; the bytes they consume are staged by
- * all lanes with coalesced 16-byte loads into a 256-byte ring per stream (indexed by absolute
- * address, zero outside the stream = the reference reader's zero-extension), and the symbols
- * they produce are staged in LDS and flushed by all lanes, 32 symbols per stream per round.
- * out_k = target + k*seg, at most cap_k bytes are written but every symbol is counted.
- * Results: bc.st_count[k], bc.st_flags[k] (1 ExtraPadding, 2 stream did not end exactly). */
-__device__ static void cz_huf_streams_lds(CzShared& sh, const uint8_t* blk, uint8_t* target, uint32_t nstreams, uint32_t seg, uint32_t cap_last, int fits) {
-    CzBroadcast& bc = sh.bc;
-    const uint32_t mb = cz_uni(sh.huf_max_bits);
-    /* per-stream constants, computed by every lane for the stream it helps staging (lane>>3) and,
-       for lanes < nstreams, the stream it decodes */
-    const uint32_t ks = (uint32_t)LANE >> 3;                            /* staging role: stream of lanes 0..31 */
-    const uint32_t kd = (uint32_t)LANE < nstreams ? (uint32_t)LANE : 0; /* decoding role */
-    const uint8_t* Sd = blk + bc.stream_off[kd]; const uint32_t lend = bc.stream_len[kd]; const uint8_t* Ed = Sd + lend;
-    const uint8_t* Ss = blk + bc.stream_off[ks & 3]; const uint8_t* Es = Ss + bc.stream_len[ks & 3];
-    const int decoder = (uint32_t)LANE < nstreams;
-    /* decoder state */
-    uint64_t buf = 0; int32_t avail = 0, rem = 0; uint32_t n = 0, flags = 0, cap = 0;
-    uintptr_t next = 0;                                                 /* absolute address of the next dword to take */
-    intptr_t loaded_lo = 0;                                             /* lowest staged address of my stream (128-aligned) */
-    int active = 0;
-    if (decoder) {
-        cap = fits ? (kd < 3 && nstreams == 4 ? seg : cap_last) : 0;
-        const uint32_t lastb = lend ? Ed[-1] : 0;
-        if (lastb == 0) flags = 1;                                      /* > 8 padding reads: ExtraPadding (:190-207) */
-        else { rem = (int32_t)lend * 8 - (int32_t)(__clz((int)lastb) - 24 + 1); active = 1; }
-        next = ((uintptr_t)Ed - 1) & ~(uintptr_t)3;
-        loaded_lo = (intptr_t)(((uintptr_t)Ed - 1) & ~(uintptr_t)127) + 128;   /* nothing staged yet */
-    }
-    int first = 1;
-    uint32_t round = 0;
-    for (;;) {
-        if (!__ballot(active && rem > 0)) break;
-        /* 1. staging: keep >= 64 bytes below every live cursor in the ring (two blocks the first time) */
-        for (int pass = 0; pass < 2; pass++) {
-            const int need = decoder && active && rem > 0 && ((intptr_t)next - 64 < loaded_lo);
-            const unsigned long long nm = __ballot(need);
-            if (!nm) break;
-            if (need) loaded_lo -= 128;
-            const uint32_t lo32 = (uint32_t)(uintptr_t)loaded_lo, hi32 = (uint32_t)((uint64_t)(uintptr_t)loaded_lo >> 32);
-            const uintptr_t blkaddr = ((uintptr_t)__shfl(hi32, (int)(ks & 3)) << 32) | __shfl(lo32, (int)(ks & 3));
-            if (LANE < 32 && ((nm >> (ks & 3)) & 1ull)) {
-                const uintptr_t a = blkaddr + 16u * ((uint32_t)LANE & 7);
-                uint4 v;
-                if (a >= (uintptr_t)Ss && a + 16 <= (uintptr_t)Es) v = *(const uint4*)a;
-                else {
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (uint32_t bb = 0; bb < 16; bb++) { const uintptr_t q = a + bb; if (q >= (uintptr_t)Ss && q < (uintptr_t)Es) w[bb >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (bb & 3)); }
-                    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-                }
-                *(uint4*)&sh.b.h.win[ks & 3][a & 255] = v;
-            }
-            if (!first) break;                                          /* steady state: one block per round is enough */
-        }
-        first = 0;
-        __syncthreads();
-        /* 2. decode up to 32 symbols per stream */
-        uint32_t c = 0;
-        if (decoder && active && rem > 0) {
-            const uint32_t* wr = (const uint32_t*)sh.b.h.win[kd];
-            if (round == 0) {                                           /* the partial top dword: bytes [next, Ed) */
-                const uint32_t nb8 = (uint32_t)((uintptr_t)Ed - next) * 8;          /* 8..32 */
-                uint32_t w = wr[(next & 255) >> 2];
-                if (nb8 < 32) w &= (1u << nb8) - 1u;
-                buf = (uint64_t)w << (64 - nb8); avail = (int32_t)nb8; next -= 4;
-                const uint32_t pad = (uint32_t)lend * 8 - (uint32_t)rem;            /* padding + marker bits */
-                buf <<= pad; avail -= (int32_t)pad;
-            }
-            uint8_t* o = sh.b.h.out[kd];
-            while (c < 32 && rem > 0) {
-                if (avail <= 32) { const uint32_t w = wr[(next & 255) >> 2]; next -= 4; buf |= (uint64_t)w << (32 - avail); avail += 32; }
-                const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
-                const uint32_t nb = e >> 8;
-                o[c++] = (uint8_t)e;
-                buf <<= nb; avail -= (int32_t)nb; rem -= (int32_t)nb;
-            }
-            if (rem <= 0) { active = 0; if (rem != 0) flags |= 2; }     /* :234-241 */
-        }
-        if (decoder) bc.st_count[kd] = c;
-        __syncthreads();
-        /* 3. flush: 4 x 32 staged symbols, two byte stores per lane */
-        for (uint32_t i = (uint32_t)LANE; i < 128; i += 64) {
-            const uint32_t k = i >> 5, j = i & 31;
-            if (k < nstreams) {
-                const uint32_t ck = bc.st_count[k], at = round * 32 + j;
-                const uint32_t capk = fits ? (k < 3 && nstreams == 4 ? seg : cap_last) : 0;
-                if (j < ck && at < capk) target[(uint64_t)k * seg + at] = sh.b.h.out[k][j];
-            }
-        }
-        n += c;
-        round++;
-        __syncthreads();
-    }
-    if (decoder) { bc.st_count[kd] = n; bc.st_flags[kd] = flags | ((n != cap) ? 4u : 0u); }
-    __syncthreads();
 }
 
 /* ---- self-synchronising parallel huff0 decode ---------------------------------------------
@@ -1332,8 +1234,6 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
         if (e) return e;
         lit.p = target;
         __syncthreads();
-        cz_init_llml(sh);                                               /* region b held the stream windows */
-        __syncthreads();
     }
     CZ_PROF_ACC(sh, CZ_P_HUFDEC);
     if (seq_hdr_err) return seq_hdr_err;                                /* block_decoder.cairo:198-204 */
@@ -1488,7 +1388,6 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         __syncthreads();
         const uint32_t f = cz_uni(sh.frame_idx);
         if (f >= a.n) break;
-        cz_init_llml(sh);                                               /* region b may hold a failed frame's stream windows */
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];

@@ -53,7 +53,7 @@ typedef struct cz_batch_args {
        (bit position | LL,ML,OF codes << 32); frame_first[f] = index of frame f's first header, 0 = the
        frame has no chain info and cz_decode_frames_kernel runs the chains itself */
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
-    uint32_t* chain_counter;
+    uint32_t* chain_counter; uint32_t chain_min_nseq;
 } cz_batch_args;
 
 #endif

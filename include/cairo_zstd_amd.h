@@ -92,9 +92,12 @@ int cz_decode_batch_host(cz_context* ctx,
  * and sizes its record arena (8 bytes per sequence + 32 per block; ~6x the compressed bytes
  * covers BASELINE config 4a).  With the pre-pass a batch decode is two launches:
  * cz_chain_kernel (eight frames per wave, one FSE state-machine chain per lane) writes
- * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, or
- * that are irregular in any way, are decoded entirely by cz_decode_frames_kernel as without it. */
+ * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, that are
+ * irregular in any way, or whose chains are short, are decoded entirely by cz_decode_frames_kernel. */
 int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
+/* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 2048:
+ * the pre-pass only pays for long chains). */
+int cz_context_set_chain_min_sequences(cz_context* ctx, uint32_t n);
 
 /* Duration in milliseconds of the most recent decode launch on this context, measured with
  * hipEvents recorded on the context stream around the kernel (bench.py's roofline leg).

@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
         size_t bytes = (size_t)atoll(ce);
         arena = (uint64_t*)malloc(bytes); a.chain_arena = arena; a.chain_capacity = bytes / 8; a.chain_top = chain_top;
         a.frame_first = frame_first.data(); a.chain_counter = &chain_counter;
+        a.chain_min_nseq = getenv("EMU_CHAIN_MIN") ? (uint32_t)atoi(getenv("EMU_CHAIN_MIN")) : 0;
     }
     pthread_barrier_init(&emu_barrier, nullptr, 64);
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }

@@ -227,7 +227,7 @@ def test_chain_prepass_matches_oracle(cz, arena_mb):
     arena is far too small (frames fall back to in-kernel chains) and on malformed frames."""
     from cairo_zstd_amd import synth
     c = cz.Context(0)
-    c.set_chain_arena(int(arena_mb * (1 << 20)))
+    c.set_chain_arena(int(arena_mb * (1 << 20)), min_sequences=0)      # pre-pass every frame, however short its chains
     try:
         frames, caps = [], []
         for kind, n in (("full_4a", 12), ("full_4b", 4), ("mix", 800), ("huf_literals", 4), ("raw_rle", 4)):
