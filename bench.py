@@ -227,6 +227,13 @@ def main():
                          "kernel_ms_all": [round(float(x), 4) for x in kernel_ms], **ctx.launch_info()},
             "synth_seconds": round(gen_s, 2),
         }
+        # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE,
+        # WRITE_SIZE) of this same command and committed under profiles/: bench.py cannot read PMCs itself
+        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic_full_4a_prepass.json")
+        if args.workload == "full_4a" and chain_prepass and F == 10000 and os.path.exists(pmc):
+            t = json.load(open(pmc))
+            line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
+            line["roofline"]["traffic_source"] = "profiles/r1/pmc_hbm_traffic_full_4a_prepass.json (FETCH_SIZE uncorrected: narrow reads; + WRITE_SIZE), bytes per step"
         if copy_ceiling is not None:
             line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling

@@ -7,8 +7,8 @@
  * cz_decode_frames_kernel that chain runs on lane 0 of a 64-lane wave (1/64 of the issue
  * bandwidth used) and the frames in flight per CU are capped by that kernel's 10.6 KB of LDS.
  * Here the chain is all a lane does: EIGHT frames per wave, one per lane 0..7, each with its own
- * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.9 KB per chain, 24 chains per CU in three
- * waves; 12 slots x 2 waves measured no faster); the other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
+ * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.6 KB per chain, 24 chains per CU in three
+ * waves; 9 and 12 slots per wave measured slower); the other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
  * (bit position | LL,ML,OF codes) to the chain arena; cz_decode_frames_kernel then extracts the
  * extra bits, resolves offsets and executes the sequences without running any chain itself.
  *
@@ -32,9 +32,13 @@
 struct CzChainSlot {
     uint32_t fse_ll[512], fse_ml[512], fse_of[256];
     int16_t  probs[CZC_MAXSYM]; uint16_t counters[CZC_MAXSYM];
-    __attribute__((aligned(16))) uint8_t stage[256];     /* head of the sequences section, linear */
-    __attribute__((aligned(16))) uint8_t mirror[16];     /* mirror[8..15] == ring[248..255] */
-    uint8_t ring[CZC_RING];                              /* reversed bitstream, indexed by absolute address & 255 */
+    union {                                              /* table-build time | chain time */
+        __attribute__((aligned(16))) uint8_t stage[256]; /* head of the sequences section, linear */
+        struct {
+            __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == ring[248..255] */
+            uint8_t ring[CZC_RING];                      /* reversed bitstream, indexed by absolute address & 255 */
+        };
+    };
 };
 struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; };
 
