@@ -203,6 +203,43 @@ def main():
                           "all_frames_ok": okw}
             del ti, td, to, tr
 
+    # ---- the same batch with a content checksum on every frame, XXH64 computed and
+    # compared inside cz_decode_frames_kernel (N=1 only, after the timed region)
+    cksum_leg = None
+    if world == 1 and not args.no_other_workloads:
+        try:
+            import xxhash
+        except ImportError:
+            xxhash = None
+        if xxhash is not None:
+            out_host = t_out.cpu().numpy()
+            n_len = batch.length.astype(np.int64) + 4
+            n_off = np.concatenate(([0], np.cumsum((n_len + 15) & ~15)[:-1])).astype(np.int64)
+            nb = np.zeros(int(n_off[-1] + n_len[-1]) + 16, dtype=np.uint8)
+            for i in range(F):
+                o, l, d = int(batch.off[i]), int(batch.length[i]), int(n_off[i])
+                nb[d:d + l] = batch.base[o:o + l]
+                nb[d + 4] |= 4                                            # Content_Checksum_flag
+                h = xxhash.xxh64_intdigest(out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])]) & 0xFFFFFFFF
+                nb[d + l:d + l + 4] = np.frombuffer(h.to_bytes(4, "little"), np.uint8)
+            del out_host
+            ti = torch.from_numpy(nb).to(dev)
+            tno, tnl = torch.from_numpy(n_off).to(dev), torch.from_numpy(n_len).to(dev)
+            ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20) if chain_prepass else 0)
+            ctx.set_verify_checksum(True)
+            ms = []
+            for it in range(4):
+                ctx.decode_batch_device(ti.data_ptr(), tno.data_ptr(), tnl.data_ptr(), F, t_out.data_ptr(), t_ooff.data_ptr(),
+                                        t_ocap.data_ptr(), t_res.data_ptr())
+                ms.append(ctx.last_kernel_ms())
+            ctx.set_verify_checksum(False)
+            r2 = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+            want = cz.RESULT_FINISHED | cz.RESULT_HAS_CHECKSUM | cz.RESULT_CHECKSUM_COMPUTED | cz.RESULT_CHECKSUM_MATCH
+            k = float(np.mean(ms[1:]))
+            cksum_leg = {"kernel_ms": k, "decompressed_MBps": regen_bytes / (k * 1e-3) / 1e6,
+                         "all_frames_ok_and_checksums_match": bool((r2["status"] == 0).all() and ((r2["flags"] & want) == want).all())}
+            del ti, tno, tnl, nb
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
@@ -239,6 +276,8 @@ def main():
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling
         if others:
             line["other_workloads"] = others
+        if cksum_leg:
+            line["with_content_checksum_verified_on_device"] = cksum_leg
         if world == 1 and not args.no_cpu_baseline:
             import oracle
             threads = ncpu

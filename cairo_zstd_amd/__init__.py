@@ -15,11 +15,13 @@ import weakref
 import numpy as np
 
 from . import status
-from ._lib import RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM, BlockHeader, FrameHeader, build, lib
+from ._lib import (RESULT_CHECKSUM_COMPUTED, RESULT_CHECKSUM_MATCH, RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM,
+                   BlockHeader, FrameHeader, build, lib)
 from .status import CzError
 
 __all__ = ["Context", "FrameDecoder", "BlockDecodingStrategy", "decode_batch_host", "read_frame_header",
-           "read_block_header", "RESULT_DTYPE", "status", "CzError", "build", "lib"]
+           "read_block_header", "RESULT_DTYPE", "RESULT_FINISHED", "RESULT_HAS_CHECKSUM", "RESULT_CHECKSUM_COMPUTED",
+           "RESULT_CHECKSUM_MATCH", "status", "CzError", "build", "lib"]
 
 
 def _as_u8(b) -> np.ndarray:
@@ -67,6 +69,10 @@ class Context:
         st = lib().cz_context_set_chain_arena(self._h, nbytes)
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+
+    def set_verify_checksum(self, on: bool = True):
+        """Compute and compare the XXH64 content checksum of every checksummed frame on the device."""
+        lib().cz_context_set_verify_checksum(self._h, 1 if on else 0)
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

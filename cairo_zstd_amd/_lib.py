@@ -16,8 +16,8 @@ LIB_PATH = os.environ.get("CAIRO_ZSTD_AMD_LIB") or os.path.join(CSRC, "libcairo_
 
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("blocks_decoded", "<u4"), ("bytes_consumed", "<u8"),
                          ("bytes_produced", "<u8"), ("checksum_from_data", "<u4"), ("flags", "<u4"),
-                         ("detail", "<u8", (2,))])
-RESULT_FINISHED, RESULT_HAS_CHECKSUM = 1, 2
+                         ("detail", "<u8", (2,)), ("calculated_checksum", "<u4"), ("reserved", "<u4")])
+RESULT_FINISHED, RESULT_HAS_CHECKSUM, RESULT_CHECKSUM_COMPUTED, RESULT_CHECKSUM_MATCH = 1, 2, 4, 8
 
 
 class FrameHeader(C.Structure):
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     L.cz_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_set_chain_arena.restype = C.c_int
     L.cz_context_set_chain_arena.argtypes = [vp, sz]
+    L.cz_context_set_verify_checksum.restype = C.c_int
+    L.cz_context_set_verify_checksum.argtypes = [vp, C.c_int]
     L.cz_context_set_chain_min_sequences.restype = C.c_int
     L.cz_context_set_chain_min_sequences.argtypes = [vp, C.c_uint32]
     L.cz_context_read_profile.restype = C.c_int

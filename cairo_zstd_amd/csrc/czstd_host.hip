@@ -42,6 +42,7 @@ struct cz_context {
     unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
     int chain_grid = 0; uint32_t chain_min_nseq = 2048;
+    uint32_t verify_checksum = 0;
 };
 
 #define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
@@ -151,6 +152,8 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
+CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
+
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
 
@@ -160,7 +163,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
-    a.prof = c->d_prof;
+    a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum;
     const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));

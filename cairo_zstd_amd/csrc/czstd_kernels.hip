@@ -1277,12 +1277,64 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     return cz_sequences(sh, blk, bsize, x, lit);
 }
 
+/* ------------------------------------------------------------------ XXH64 content checksum */
+/* src/utils/xxhash64.cairo:20-163 (seed 0).  The reference hashes the decoded frame as it is
+ * drained (decode_buffer.cairo:162,181) and compares the low 32 bits with the 4 bytes after the
+ * last block (frame_decoder.cairo:133-138).  XXH64 has four independent accumulators, each eating
+ * 8 bytes of every 32-byte stripe: lanes 0..3 run them; all 64 lanes stage 512 bytes (16 stripes)
+ * at a time into LDS with coalesced 8-byte loads, one block ahead. */
+#define CZ_XP1 0x9E3779B185EBCA87ull
+#define CZ_XP2 0xC2B2AE3D27D4EB4Full
+#define CZ_XP3 0x165667B19E3779F9ull
+#define CZ_XP4 0x85EBCA77C2B2AE63ull
+#define CZ_XP5 0x27D4EB2F165667C5ull
+__device__ static inline uint64_t cz_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ static inline uint64_t cz_xxh_round(uint64_t acc, uint64_t in) { acc += in * CZ_XP2; acc = cz_rotl64(acc, 31); return acc * CZ_XP1; }
+__device__ static inline uint64_t cz_xxh_merge(uint64_t h, uint64_t v) { v = cz_xxh_round(0, v); h ^= v; return h * CZ_XP1 + CZ_XP4; }
+__device__ static inline uint64_t cz_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+/* all lanes; returns the digest in every lane */
+__device__ static uint64_t cz_xxh64_frame(CzShared& sh, const uint8_t* p, uint64_t len) {
+    uint64_t* stage = (uint64_t*)sh.a.huf;                              /* 2 x 512 B of the (now idle) phase region */
+    uint64_t acc = LANE == 0 ? CZ_XP1 + CZ_XP2 : (LANE == 1 ? CZ_XP2 : (LANE == 2 ? 0ull : 0ull - CZ_XP1));
+    const uint64_t nblk = len >> 9;                                     /* full 512-byte blocks */
+    __syncthreads();
+    uint64_t nxt = nblk ? cz_ld64(p + 8 * (uint64_t)LANE) : 0;
+    for (uint64_t b = 0; b < nblk; b++) {
+        stage[(b & 1) * 64 + (uint32_t)LANE] = nxt;
+        if (b + 1 < nblk) nxt = cz_ld64(p + ((b + 1) << 9) + 8 * (uint64_t)LANE);     /* in flight during the rounds below */
+        __syncthreads();
+        if (LANE < 4) { const uint64_t* q = stage + (b & 1) * 64 + LANE; for (int k = 0; k < 16; k++) acc = cz_xxh_round(acc, q[4 * k]); }
+    }
+    __syncthreads();
+    /* remaining whole stripes (< 16) and the tail, read directly */
+    uint64_t off = nblk << 9;
+    if (LANE < 4) for (uint64_t o = off; o + 32 <= len; o += 32) acc = cz_xxh_round(acc, cz_ld64(p + o + 8 * (uint64_t)LANE));
+    off += ((len - off) >> 5) << 5;
+    const uint64_t v1 = (uint64_t)__shfl((uint32_t)acc, 0) | ((uint64_t)__shfl((uint32_t)(acc >> 32), 0) << 32);
+    const uint64_t v2 = (uint64_t)__shfl((uint32_t)acc, 1) | ((uint64_t)__shfl((uint32_t)(acc >> 32), 1) << 32);
+    const uint64_t v3 = (uint64_t)__shfl((uint32_t)acc, 2) | ((uint64_t)__shfl((uint32_t)(acc >> 32), 2) << 32);
+    const uint64_t v4 = (uint64_t)__shfl((uint32_t)acc, 3) | ((uint64_t)__shfl((uint32_t)(acc >> 32), 3) << 32);
+    uint64_t h;
+    if (len >= 32) {
+        h = cz_rotl64(v1, 1) + cz_rotl64(v2, 7) + cz_rotl64(v3, 12) + cz_rotl64(v4, 18);
+        h = cz_xxh_merge(h, v1); h = cz_xxh_merge(h, v2); h = cz_xxh_merge(h, v3); h = cz_xxh_merge(h, v4);
+    } else h = CZ_XP5;
+    h += len;
+    const uint8_t* q = p + off; const uint8_t* end = p + len;          /* < 32 bytes, every lane redundantly */
+    while (q + 8 <= end) { h ^= cz_xxh_round(0, cz_ld64(q)); h = cz_rotl64(h, 27) * CZ_XP1 + CZ_XP4; q += 8; }
+    if (q + 4 <= end) { uint32_t w; __builtin_memcpy(&w, q, 4); h ^= (uint64_t)w * CZ_XP1; h = cz_rotl64(h, 23) * CZ_XP2 + CZ_XP3; q += 4; }
+    while (q < end) { h ^= (uint64_t)(*q) * CZ_XP5; h = cz_rotl64(h, 11) * CZ_XP1; q++; }
+    h ^= h >> 33; h *= CZ_XP2; h ^= h >> 29; h *= CZ_XP3; h ^= h >> 32;
+    return h;
+}
+
 /* ------------------------------------------------------------------ one frame */
 struct CzFrameIO {
     const uint8_t* src; uint64_t src_len;
     uint8_t* dst; uint64_t dst_cap;
     uint64_t produced, drained, window;
     uint32_t parse_header, has_checksum, strategy, streaming; uint64_t strategy_n;
+    uint32_t verify;          /* compute XXH64 of the decoded frame and compare with the frame's checksum */
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
@@ -1355,9 +1407,15 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
         if (io.strategy == 1 && blocks >= io.strategy_n) break;         /* :204-208 */
         if (io.strategy == 2 && x.produced - produced0 >= io.strategy_n) break;         /* :209-213 */
     }
+    uint32_t calc = 0;
+    if (io.verify && !err && (flags & CZ_RESULT_HAS_CHECKSUM) && io.produced == 0) {
+        /* get_calculated_checksum == get_checksum_from_data (src/tests/decoding.cairo:16-19), on the device */
+        calc = (uint32_t)cz_xxh64_frame(sh, x.out, x.produced);
+        flags |= CZ_RESULT_CHECKSUM_COMPUTED | (calc == cksum ? CZ_RESULT_CHECKSUM_MATCH : 0u);
+    }
     if (LANE == 0) {
         res->status = err; res->blocks_decoded = blocks; res->bytes_consumed = pos; res->bytes_produced = x.produced;
-        res->checksum_from_data = cksum; res->flags = flags;
+        res->checksum_from_data = cksum; res->flags = flags; res->calculated_checksum = calc; res->reserved = 0;
         res->detail[0] = io.parse_header && (err == CZ_E_FH_SKIP_FRAME || err == CZ_E_FH_BAD_MAGIC) ? bc.d0 : blocks;
         res->detail[1] = io.parse_header && err == CZ_E_FH_SKIP_FRAME ? bc.d1 : pos;
     }
@@ -1393,7 +1451,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
             const cz_device_task t = a.tasks[f];
             io.src = t.src; io.src_len = t.src_len; io.dst = t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
             io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
-            io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming;
+            io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming; io.verify = 0;
             /* restore carried state (the Huffman table stays in t.state->huf until a Treeless block asks for it) */
             cz_device_frame_state* gs = t.state;
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { sh.fse_ll[i] = gs->fse[0][i]; sh.fse_ml[i] = gs->fse[2][i]; }
@@ -1413,7 +1471,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         } else {
             io.src = a.in_base + a.in_off[f]; io.src_len = a.in_len[f]; io.dst = a.out_base + a.out_off[f]; io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
-            io.strategy = 0; io.strategy_n = 0; io.streaming = 0;
+            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum;
             cz_state_reset(sh);
             __syncthreads();
             cz_run_frame(sh, io, lit_scratch, (uint16_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES), &a.results[f], a.chain_arena,

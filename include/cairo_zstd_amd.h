@@ -47,9 +47,14 @@ typedef struct cz_frame_result {
     uint32_t flags;
     uint64_t detail[2];         /* error payload (e.g. magic / skip length for CZ_E_FH_SKIP_FRAME,
                                    block index and byte position for decode errors) */
+    uint32_t calculated_checksum; /* low 32 bits of XXH64(decoded frame), valid when flags & CZ_RESULT_CHECKSUM_COMPUTED
+                                   (get_calculated_checksum, frame_decoder.cairo:133-138) */
+    uint32_t reserved;
 } cz_frame_result;
 #define CZ_RESULT_FINISHED     1u   /* last block seen (frame_finished, frame_decoder.cairo:190) */
 #define CZ_RESULT_HAS_CHECKSUM 2u
+#define CZ_RESULT_CHECKSUM_COMPUTED 4u  /* cz_context_set_verify_checksum(ctx, 1): XXH64 was computed on the device */
+#define CZ_RESULT_CHECKSUM_MATCH    8u  /* ... and equals checksum_from_data */
 
 /* ---------------------------------------------------------------- 1. context */
 typedef struct cz_context cz_context;
@@ -98,6 +103,12 @@ int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
 /* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 2048:
  * the pre-pass only pays for long chains). */
 int cz_context_set_chain_min_sequences(cz_context* ctx, uint32_t n);
+
+/* Batch decodes also compute the XXH64 content checksum of every frame that carries one, on the
+ * device, and compare it with the stored value (what `_test_decode` asserts,
+ * src/tests/decoding.cairo:16-19).  A mismatch is reported in the result flags, not as a status:
+ * the reference leaves the comparison to the caller too.  Off by default. */
+int cz_context_set_verify_checksum(cz_context* ctx, int on);
 
 /* Duration in milliseconds of the most recent decode launch on this context, measured with
  * hipEvents recorded on the context stream around the kernel (bench.py's roofline leg).

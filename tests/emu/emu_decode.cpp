@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     a.in_base = in_exact; a.in_off = in_off.data(); a.in_len = in_len.data();
     a.out_base = out; a.out_off = out_off.data(); a.out_cap = out_cap.data();
     a.results = res.data(); a.tasks = nullptr; a.n = (uint32_t)n; a.work_counter = &counter;
-    a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
+    a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES; a.verify_checksum = 1;
     /* EMU_CHAIN=<bytes>: run the FSE-chain pre-pass first, with an arena of that many bytes */
     const char* ce = getenv("EMU_CHAIN");
     unsigned long long chain_top[4] = {0, 0, 0, 0}; uint32_t chain_counter = 0;

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EMU_DIR = os.path.join(HERE, "emu")
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("blocks_decoded", "<u4"), ("bytes_consumed", "<u8"),
                          ("bytes_produced", "<u8"), ("checksum_from_data", "<u4"), ("flags", "<u4"),
-                         ("detail", "<u8", (2,))])
+                         ("detail", "<u8", (2,)), ("calculated_checksum", "<u4"), ("reserved", "<u4")])
 
 
 def build(target="emu_decode"):

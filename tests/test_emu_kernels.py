@@ -8,7 +8,7 @@ import pytest
 import emu_runner
 import oracle
 from cairo_zstd_amd import status, synth
-from conftest import corpus_pairs
+from conftest import corpus_pairs, raw_frame_with_checksum
 
 
 def _run_and_compare(frames, caps):
@@ -20,6 +20,11 @@ def _run_and_compare(frames, caps):
             bad.append((i, status.name(r["status"]), status.name(st)))
         elif st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"]):
             bad.append((i, "DATA"))
+        elif st == 0 and info["has_checksum"]:
+            # the emulator always runs with content-checksum verification on
+            want = oracle.xxh64(ref) & 0xFFFFFFFF
+            if not (r["flags"] & 4) or int(r["calculated_checksum"]) != want or bool(r["flags"] & 8) != (want == info["checksum"]):
+                bad.append((i, "XXH64", hex(int(r["calculated_checksum"])), hex(want)))
     assert not bad, bad[:10]
 
 
@@ -45,4 +50,17 @@ def test_emu_malformed_inputs():
             muts.append(bytes(a))
         frames += muts
         caps += [len(orig) * 2 + 4096] * len(muts)
+    _run_and_compare(frames, caps)
+
+
+def test_emu_content_checksum_lengths():
+    """XXH64 on the device (src/utils/xxhash64.cairo:31-163): every tail length class, block
+    boundaries of the 512-byte staging, one wrong stored checksum."""
+    rng = np.random.default_rng(7)
+    frames, caps = [], []
+    for n in [0, 1, 3, 4, 5, 7, 8, 9, 31, 32, 33, 40, 63, 64, 95, 511, 512, 513, 543, 544, 545, 1023, 1024, 1025, 1536, 5000, 70001]:
+        frames.append(raw_frame_with_checksum(rng.integers(0, 256, n, dtype=np.uint8).tobytes()))
+        caps.append(n + 8)
+    frames.append(raw_frame_with_checksum(b"abc" * 400, corrupt=True))
+    caps.append(1300)
     _run_and_compare(frames, caps)

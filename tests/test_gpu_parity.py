@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, corpus_pairs
+from conftest import GOLDEN, add_checksum, corpus_pairs, raw_frame_with_checksum
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +68,43 @@ def test_corpus_golden_batch(cz, ctx):
         assert int(r["bytes_consumed"]) == len(z)
         assert r["flags"] & 1 and r["flags"] & 2
         assert int(r["checksum_from_data"]) == oracle.xxh64(orig) & 0xFFFFFFFF, name
+
+
+def test_content_checksum_on_device(cz, ctx):
+    """get_calculated_checksum == get_checksum_from_data (src/tests/decoding.cairo:16-19) computed
+    by the decode kernel: the corpus (every frame carries one), synthetic frames patched to carry
+    one, every tail-length class, and a corrupted stored value."""
+    from cairo_zstd_amd import synth
+    pairs = corpus_pairs()
+    frames = [z for _, z, _ in pairs]
+    origs = [o for _, _, o in pairs]
+    b = synth.generate("mix", 300, first_index=77)
+    for i in range(b.n):
+        st, ref, _ = oracle.decode_frame(b.frame(i), cap=int(b.regen[i]))
+        assert st == 0
+        frames.append(add_checksum(b.frame(i), ref))
+        origs.append(ref)
+    rng = np.random.default_rng(3)
+    for n in [0, 1, 4, 7, 8, 31, 32, 33, 511, 512, 513, 544, 1025, 131072, 300000]:
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        frames.append(raw_frame_with_checksum(d))
+        origs.append(d)
+    bad_at = len(frames)
+    frames.append(raw_frame_with_checksum(origs[0], corrupt=True))
+    origs.append(origs[0])
+    ctx.set_verify_checksum(True)
+    try:
+        got = cz.decode_batch_host(frames, [len(o) + 8 for o in origs], ctx)
+    finally:
+        ctx.set_verify_checksum(False)
+    for i, ((r, out), o) in enumerate(zip(got, origs)):
+        assert int(r["status"]) == 0 and out == o, i
+        assert r["flags"] & cz.RESULT_CHECKSUM_COMPUTED, i
+        assert int(r["calculated_checksum"]) == oracle.xxh64(o) & 0xFFFFFFFF, i
+        assert bool(r["flags"] & cz.RESULT_CHECKSUM_MATCH) == (i != bad_at), i
+    # off again: the flag must not be set
+    got = cz.decode_batch_host(frames[:4], [len(o) + 8 for o in origs[:4]], ctx)
+    assert all(not (r["flags"] & cz.RESULT_CHECKSUM_COMPUTED) for r, _ in got)
 
 
 @pytest.mark.parametrize("kind,n", [("raw_rle", 64), ("huf_literals", 48), ("full_4a", 24), ("full_4b", 8), ("mix", 1500)])
