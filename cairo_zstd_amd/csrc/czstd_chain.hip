@@ -19,21 +19,35 @@
  * (frame_first[f] = 0) and the main kernel decodes that frame entirely by itself, producing the
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
-#define CZC_SLOTS 8
+#ifndef CZC_SLOTS
+#define CZC_SLOTS 16
+#endif
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 #define CZC_MAXSYM 64
 #define CZC_RING 256u
 #define CZC_BLOCK 128u
 #define CZC_NEED 96u        /* >= 8 steps x 89 bits */
 #define CZC_STEPS 8u
+#define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
    main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
 
+/* Chain-time decoding tables are 16 bits per state so that more chains fit in a CU's LDS (the number
+ * of chains in flight is what bounds this kernel).  An entry holds only what the serial core needs:
+ *   [15:6] v = (1 << (9 - num_bits)) | (base_line >> num_bits)     [5:1] extra bits of the code
+ * base_line is always a multiple of 2^num_bits (fse_decoder.cairo:231-255: it is a multiple of the
+ * slice width), so num_bits = clz10(v) and next state = ((v << num_bits) | bits) & 511.  The symbol
+ * itself is not stored: the record carries the STATE and cz_decode_frames_kernel maps it to the code
+ * with the per-block state->code byte maps this kernel leaves in the arena. */
+#define CZC_E16(nb, base, xb) ((uint16_t)(((((1u << (9u - (nb))) | ((base) >> (nb))) << 6) | ((xb) << 1))))
+
 struct CzChainSlot {
-    uint32_t fse_ll[512], fse_ml[512], fse_of[256];
-    int16_t  probs[CZC_MAXSYM]; uint16_t counters[CZC_MAXSYM];
+    uint16_t t_ll[512], t_ml[512], t_of[256];
     union {                                              /* table-build time | chain time */
-        __attribute__((aligned(16))) uint8_t stage[256]; /* head of the sequences section, linear */
+        struct {
+            __attribute__((aligned(16))) uint8_t stage[256]; /* head of the sequences section, linear */
+            int16_t probs[CZC_MAXSYM]; uint16_t counters[CZC_MAXSYM];
+        };
         struct {
             __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == ring[248..255] */
             uint8_t ring[CZC_RING];                      /* reversed bitstream, indexed by absolute address & 255 */
@@ -41,6 +55,47 @@ struct CzChainSlot {
     };
 };
 struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; };
+
+/* build_decoding_table (fse_decoder.cairo:156-256) into 16-bit chain entries + the state->code map
+ * (global, bytes).  kind 0 LL, 1 OF, 2 ML.  Returns 1 if the table holds a code the sequence decoder
+ * rejects (LL >= 36, OF >= 32, ML >= 53): such frames are left to the main kernel. */
+__device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log,
+                                                                uint16_t* counters, const uint32_t* llml, uint32_t kind, uint8_t* map) {
+    const uint32_t size = 1u << log, lim = kind == 0 ? 36u : (kind == 1 ? 32u : 53u);
+    uint32_t neg = size; int bad = 0;
+    for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
+        counters[s] = 0;
+        if (probs[s] != 0 && s >= lim) bad = 1;
+        if (probs[s] == -1) { neg--; table[neg] = (uint16_t)s; }
+    }
+    if (bad) return 1;
+    uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    for (uint32_t s = 0; s < nprobs; s++) {                             /* :190-226 */
+        const int32_t p = probs[s];
+        for (int32_t j = 0; j < p; j++) {
+            table[pos] = (uint16_t)s;
+            do { pos = (pos + step) & mask; } while (pos >= neg);
+        }
+    }
+    for (uint32_t i = 0; i < size; i++) {                               /* :231-255, :377-400 */
+        const uint32_t s = table[i];
+        const uint32_t xb = kind == 1 ? s : (llml[(kind == 2 ? 40u : 0u) + s] >> 24);
+        uint32_t nb, bl;
+        if (i >= neg) { nb = log; bl = 0; }
+        else {
+            const uint32_t n = (uint32_t)probs[s], k = counters[s];
+            counters[s] = (uint16_t)(k + 1);
+            const uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
+            const uint32_t dbl = slices - n, single = n - dbl, width = size / slices;
+            nb = cz_hbs(width) - 1;
+            if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
+            else bl = (k - dbl) * width;
+        }
+        table[i] = CZC_E16(nb, bl, xb);
+        if (map) map[i] = (uint8_t)s;
+    }
+    return 0;
+}
 
 /* 16 bytes at absolute address a, zero outside [S, E) */
 __device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E) {
@@ -78,31 +133,29 @@ __device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
 }
 
 /* `steps` chain steps of one lane (sequence_section_decoder.cairo:223-286, serial core).
- * RLE: some table of this wave is in RLE mode (entries are then selected per lane);
- * TAIL: the group may contain the block's last sequence (which updates no state, :258). */
-template <bool RLE, bool TAIL>
+ * TAIL: the group may contain the block's last sequence (which updates no state, :258).
+ * Record per sequence: low word = the 32 stream bits below the cursor (they hold the sequence's
+ * extra bits, read first, :239-256), high word = LL state | ML state << 9 | OF code << 18. */
+template <bool TAIL>
 __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, uint32_t steps, uint32_t nseq, uint32_t done, uint32_t sbits,
-                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& bad, uint32_t& slow, int32_t& neg,
-                                        int rLLf, int rOFf, int rMLf, uint32_t fLL, uint32_t fOF, uint32_t fML) {
+                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& slow, int32_t& neg) {
     for (uint32_t i = 0; i < steps; i++) {
         const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
         const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
-        uint32_t eLL = sl.fse_ll[sLL], eOF = sl.fse_of[sOF], eML = sl.fse_ml[sML];
-        if (RLE) { eLL = rLLf ? fLL : eLL; eOF = rOFf ? fOF : eOF; eML = rMLf ? fML : eML; }
-        /* record: bit position | LL, ML, OF codes (the symbol is the top byte of each entry) */
-        const uint32_t codes = (eLL >> 24) | ((eML >> 24) << 8) | ((eOF >> 24) << 16);
-        rec[done + i] = (uint64_t)(uint32_t)(u - (int32_t)sbits) | ((uint64_t)codes << 32);
-        const uint32_t sum = eLL + eOF + eML, a_ = sum & 0x7F, nbs = (sum >> 7) & 0x3F;
-        bad |= eLL | eOF | eML;
+        const uint32_t eLL = sl.t_ll[sLL], eOF = sl.t_of[sOF], eML = sl.t_ml[sML];
+        const uint32_t xl = (eLL >> 1) & 31, xm = (eML >> 1) & 31, xo = (eOF >> 1) & 31, a_ = xl + xm + xo;
+        const uint32_t ph = (uint32_t)u & 31;
+        rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
         slow |= a_ > 32;
-        const uint32_t ph = (uint32_t)u & 31, sel = ph >= a_;
+        const uint32_t sel = ph >= a_;
         const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
-        const uint32_t nl = CZ_FSE_NB(eLL), nm_ = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF);
-        sLL = (CZ_FSE_BASE(eLL) + __builtin_amdgcn_ubfe(xh, 32 - nl, nl)) & 511;
-        sML = (CZ_FSE_BASE(eML) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_)) & 511;
-        sOF = (CZ_FSE_BASE(eOF) + __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
-        if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nbs);
-        else u -= (int32_t)(a_ + nbs);
+        const uint32_t vl = eLL >> 6, vm = eML >> 6, vo = eOF >> 6;
+        const uint32_t nl = (uint32_t)__builtin_clz(vl) - 22, nm_ = (uint32_t)__builtin_clz(vm) - 22, no = (uint32_t)__builtin_clz(vo) - 22;   /* v != 0 in a built table */
+        sLL = ((vl << nl) | __builtin_amdgcn_ubfe(xh, 32 - nl, nl)) & 511;       /* update order LL, ML, OF (:258-277) */
+        sML = ((vm << nm_) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_)) & 511;
+        sOF = ((vo << no) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
+        if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nl + nm_ + no);
+        else u -= (int32_t)(a_ + nl + nm_ + no);
         neg |= u - (int32_t)sbits;
     }
 }
@@ -122,7 +175,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
         if (!__ballot(frame_live)) break;
         const uint8_t* src = nullptr; uint64_t len = 0, pos = 0;
         int punt = 0;
-        uint32_t logs[3] = {0, 0, 0}; int32_t rles[3] = {-1, -1, -1};
+        uint32_t logs[3] = {0, 0, 0}; int32_t rles[3] = {-1, -1, -1};       /* carried across the frame's blocks (Repeat mode) */
         uint64_t first_hdr = 0, prev_hdr = 0;
         if (frame_live) {
             src = a.in_base + a.in_off[f]; len = a.in_len[f];
@@ -197,45 +250,47 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
             }
             /* ---- tables (sequence_section_decoder.cairo:405-647), serial per lane */
-            uint32_t bitoff = 0; uint64_t hdr = 0;
-            uint32_t fLL = 0, fOF = 0, fML = 0;
+            uint32_t bitoff = 0, mapflags = 0; uint64_t hdr = 0;
+            if (have) {                                                 /* arena: 4-word header + code maps + nseq records */
+                const unsigned long long units = 4ull + CZC_MAP_WORDS + nseq;
+                hdr = 8ull + atomicAdd(a.chain_top, units);          /* indices 0..7 are reserved (0 = none) */
+                if (hdr + units > a.chain_capacity) { punt = 1; have = 0; frame_done = 1; }
+            }
             if (have) {
                 uint32_t off = sbody;
+                uint8_t* maps = (uint8_t*)(a.chain_arena + hdr + 4);
                 const uint32_t md[3] = { (modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3 };
                 const uint32_t max_log[3] = { 9, 8, 9 };
                 for (int t = 0; t < 3 && !punt; t++) {
-                    uint32_t* table = t == 0 ? sl.fse_ll : (t == 1 ? sl.fse_of : sl.fse_ml);
+                    uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
+                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : nullptr);   /* the OF code travels in the record */
+                    if (md[t] != 3) mapflags |= 1u << t;
                     if (md[t] == 0) {
                         const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
                         const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u, lg = t == 1 ? 5u : 6u;
                         for (uint32_t s = 0; s < n; s++) sl.probs[s] = d[s];
-                        cz_fse_build(table, sl.probs, n, lg, sl.counters, cs.llml, (uint32_t)t);
+                        (void)czc_fse_build16(table, sl.probs, n, lg, sl.counters, cs.llml, (uint32_t)t, map);
                         logs[t] = lg; rles[t] = -1;
                     } else if (md[t] == 1) {
+                        /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                         if (off >= bsize) { punt = 1; break; }
-                        rles[t] = blk[off]; off += 1;
+                        const uint32_t sym = blk[off]; off += 1;
+                        if (sym >= (t == 0 ? 36u : (t == 1 ? 32u : 53u))) { punt = 1; break; }
+                        table[0] = CZC_E16(0u, 0u, t == 1 ? sym : (cs.llml[(t == 2 ? 40u : 0u) + sym] >> 24));
+                        if (map) map[0] = (uint8_t)sym;
+                        rles[t] = (int32_t)sym;
                     } else if (md[t] == 2) {
                         CzFBits br; br.g = blk + off; br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
                         if (off - sbody < 256) { br.stage = sl.stage + (off - sbody); br.stage_hi = 256 - (off - sbody); }
                         uint32_t np, lg, used;
                         if (cz_fse_read_probs(br, max_log[t], sl.probs, &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }
-                        cz_fse_build(table, sl.probs, np, lg, sl.counters, cs.llml, (uint32_t)t);
+                        if (czc_fse_build16(table, sl.probs, np, lg, sl.counters, cs.llml, (uint32_t)t, map)) { punt = 1; break; }
                         logs[t] = lg; rles[t] = -1; off += used;
                         if (off > bsize) { punt = 1; break; }
                     } else if (rles[t] < 0 && logs[t] == 0) { punt = 1; break; }     /* Repeat of nothing */
                 }
                 bitoff = off;
-                if (!punt) {                                            /* arena: 4-word header + nseq records */
-                    const unsigned long long units = 4ull + nseq;
-                    hdr = 8ull + atomicAdd(a.chain_top, units);      /* indices 0..7 are reserved (0 = none) */
-                    if (hdr + units > a.chain_capacity) punt = 1;
-                }
                 if (punt) { have = 0; frame_done = 1; }
-                else {
-                    fLL = rles[0] >= 0 ? (CZ_FSE_PACK(rles[0], 0, 0) | cz_fse_code_bits(cs.llml, 0, (uint32_t)rles[0])) : 0;
-                    fOF = rles[1] >= 0 ? (CZ_FSE_PACK(rles[1], 0, 0) | cz_fse_code_bits(cs.llml, 1, (uint32_t)rles[1])) : 0;
-                    fML = rles[2] >= 0 ? (CZ_FSE_PACK(rles[2], 0, 0) | cz_fse_code_bits(cs.llml, 2, (uint32_t)rles[2])) : 0;
-                }
             }
             /* ---- bit ring: stage the top two 128-byte blocks of every live stream */
             const uintptr_t S = have ? (uintptr_t)blk + bitoff : 0, E = have ? (uintptr_t)blk + bsize : 0;
@@ -253,7 +308,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
             }
             /* ---- chain */
-            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, bad = 0, slow = 0; int32_t neg = 0;
+            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0; int32_t neg = 0;
             int chain_live = have;
             if (have) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
@@ -271,8 +326,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 if (p < 0) slow = 1;
                 u = (int32_t)sbits + p;
             }
-            uint64_t* rec = a.chain_arena + hdr + 4;
-            const int rLLf = rles[0] >= 0, rOFf = rles[1] >= 0, rMLf = rles[2] >= 0;
+            uint64_t* rec = a.chain_arena + hdr + 4 + CZC_MAP_WORDS;
             while (__ballot(chain_live)) {
                 /* keep CZC_NEED bytes below every live cursor staged */
                 {
@@ -290,11 +344,10 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     /* uniform choice of the loop flavour for this group of CZC_STEPS steps */
                     const uint32_t left = nseq - done;
                     const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
-                    const int rle = __ballot(chain_live && (rLLf | rOFf | rMLf)) != 0;
                     if (chain_live) {
                         const uint32_t steps = left < CZC_STEPS ? left : CZC_STEPS;
-                        if (!tail && !rle) czc_group<false, false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, bad, slow, neg, 0, 0, 0, 0, 0, 0);
-                        else czc_group<true, true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, bad, slow, neg, rLLf, rOFf, rMLf, fLL, fOF, fML);
+                        if (!tail) czc_group<false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, slow, neg);
+                        else czc_group<true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, slow, neg);
                         done += steps;
                         if (done >= nseq) chain_live = 0;
                     }
@@ -302,10 +355,10 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             }
             /* ---- finalize the block */
             if (have) {
-                if (((bad >> 13) & 1) || slow || neg < 0 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* invalid code / > 32 extra bits / overrun / ExtraBits */
+                if (slow || neg < 0 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
                 else {
                     uint64_t* h = a.chain_arena + hdr;
-                    h[0] = ((uint64_t)nseq << 32); h[1] = bitoff; h[2] = 0; h[3] = 0;
+                    h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;
                     if (prev_hdr) a.chain_arena[prev_hdr + 2] = hdr; else first_hdr = hdr;
                     prev_hdr = hdr;
                     if (blast) frame_done = 1;

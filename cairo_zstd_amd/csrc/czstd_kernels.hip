@@ -1134,48 +1134,39 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     return 0;
 }
 
-/* Same as cz_sequences, for a block whose FSE chain was already run by cz_chain_kernel: the
- * per-sequence records (bit position, LL/ML/OF codes) come from the chain arena, so this pass
- * needs neither the decoding tables nor the serial core — only the bit ring for the extra bits. */
-__device__ static int cz_sequences_rec(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit,
-                                       const uint64_t* rec, uint32_t nseq, uint32_t bitstream_off) {
-    const uint8_t* S = blk + bitstream_off; const uint8_t* E = blk + bsize;
-    const uint32_t sbits = (uint32_t)((uintptr_t)S & (CZ_RING_BYTES - 1)) * 8u;
+/* Same as cz_sequences, for a block whose FSE chain was already run by cz_chain_kernel: every
+ * sequence has an 8-byte record in the chain arena — low word = the 32 stream bits that start with
+ * the sequence's extra bits (OF, ML, LL; sequence_section_decoder.cairo:239-256), high word = LL state |
+ * ML state << 9 | OF code << 18 — and the block header carries the state->code byte maps of its LL
+ * and ML tables.  This pass needs neither decoding tables nor the bitstream, only the maps (kept in
+ * the LDS that holds the FSE tables otherwise; they persist over Repeat-mode blocks). */
+#define CZ_CHAIN_MAP_WORDS 128u
+__device__ static int cz_sequences_rec(CzShared& sh, CzExecCtx& x, const CzLit& lit, const uint64_t* maps, const uint64_t* rec,
+                                       uint32_t nseq, uint32_t mapflags) {
+    uint8_t* mapll = (uint8_t*)sh.fse_ll; uint8_t* mapml = mapll + 512;
     CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
-    uintptr_t loaded_lo;
     {
-        const uintptr_t top = (((uintptr_t)E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZ_RING_BLOCK - 1));
-        cz_ring_load_block(sh, S, E, top); cz_ring_load_block(sh, S, E, top - CZ_RING_BLOCK);
-        loaded_lo = top - CZ_RING_BLOCK;
+        const uint32_t half = (uint32_t)LANE >> 5, j = (uint32_t)LANE & 31;           /* 32 lanes x 16 B per map */
+        if ((mapflags >> (half ? 2 : 0)) & 1u) { uint4 v; __builtin_memcpy(&v, (const uint8_t*)maps + 512u * half + 16u * j, 16); *(uint4*)(mapll + 512u * half + 16u * j) = v; }
     }
     __syncthreads();
     int exec_err = 0;
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
+    CZ_PROF_ACC(sh, CZ_P_RING);
     for (uint32_t done = 0; done < nseq; done += 64) {
         const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
         const int active = (uint32_t)LANE < cnt;
         const uint64_t r = active ? rec[done + (uint32_t)LANE] : 0;     /* coalesced 8-byte loads */
-        const int32_t p = (int32_t)(uint32_t)r; const uint32_t codes = (uint32_t)(r >> 32);
-        {
-            const int32_t p0 = cz_unii(__shfl(p, 0));
-            const intptr_t cur = (intptr_t)S + ((p0 > 0 ? p0 - 1 : 0) >> 3);
-            if (cur - (intptr_t)CZ_RING_NEED < (intptr_t)loaded_lo) {
-                __syncthreads();
-                loaded_lo -= CZ_RING_BLOCK;
-                cz_ring_load_block(sh, S, E, loaded_lo);
-                __syncthreads();
-            }
-        }
-        CZ_PROF_ACC(sh, CZ_P_RING);
         uint32_t ll = 0, ml = 0, ov = 4;
         if (active) {
-            const uint32_t llc = codes & 0xFF, mlc = (codes >> 8) & 0xFF, oc = (codes >> 16) & 0xFF;
-            const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
-            const uint32_t tl = sh.b.c.llml[llc], tm = sh.b.c.llml[40 + mlc];
-            ov = (1u << oc) + cz_field(W, 0, oc);                       /* sequence_section_decoder.cairo:243 */
-            ml = (tm & 0xFFFFFFu) + cz_field(W, oc, tm >> 24);          /* :249-256 */
-            ll = (tl & 0xFFFFFFu) + cz_field(W, oc + (tm >> 24), tl >> 24);
+            const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
+            const uint32_t oc = (st >> 18) & 31;
+            const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
+            const uint32_t mx = tm >> 24, lx = tl >> 24;                /* <= 32 in total (the pre-pass leaves other frames alone) */
+            ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */
+            ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);         /* :249-256 */
+            ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
         }
         exec_err = cz_history_and_execute(sh, x, lit, cnt, ll, ml, ov, h0, h1, h2);
         CZ_PROF_T0();
@@ -1247,15 +1238,16 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
         return 0;
     }
     if (chain_cursor) {
-        /* cz_chain_kernel already ran this block's FSE chain: header = {status|nseq, bitstream_off, next} */
-        const uint64_t w0 = arena[chain_cursor], w1 = arena[chain_cursor + 1], w2 = arena[chain_cursor + 2];
-        const uint64_t* rec = arena + chain_cursor + 4;
+        /* cz_chain_kernel already ran this block's FSE chain: header = {nseq|map flags, bitstream_off, next}, code maps, records */
+        const uint64_t w0 = arena[chain_cursor], w2 = arena[chain_cursor + 2];
+        const uint64_t* maps = arena + chain_cursor + 4;
+        const uint64_t* rec = maps + CZ_CHAIN_MAP_WORDS;
         chain_cursor = cz_uni64(w2);
-        const uint32_t rn = cz_uni((uint32_t)(w0 >> 32)), boff = cz_uni((uint32_t)w1);
+        const uint32_t rn = cz_uni((uint32_t)(w0 >> 32)), mapflags = cz_uni((uint32_t)w0);
         if (rn != nseq) return CZ_E_INVALID_ARG;                        /* cannot happen: both passes walk the same bytes */
         x.lit_used = 0;
         CZ_PROF_ACC(sh, CZ_P_SEQTAB);
-        return cz_sequences_rec(sh, blk, bsize, x, lit, rec, nseq, boff);
+        return cz_sequences_rec(sh, x, lit, maps, rec, nseq, mapflags);
     }
     /* sequence tables */
     const uint32_t so = cz_uni(bc.seq_body_off);
