@@ -74,6 +74,14 @@ class Context:
         """Compute and compare the XXH64 content checksum of every checksummed frame on the device."""
         lib().cz_context_set_verify_checksum(self._h, 1 if on else 0)
 
+    def last_chain_ms(self) -> float:
+        """Milliseconds of the last launch spent in the FSE-chain pre-pass kernel (0 when it is off)."""
+        ms = C.c_float(0)
+        st = lib().cz_context_last_chain_ms(self._h, C.byref(ms))
+        if st:
+            raise CzError(st, "cz_context_last_chain_ms")
+        return float(ms.value)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         st = lib().cz_context_last_kernel_ms(self._h, C.byref(ms))

@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
     L.cz_context_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cz_context_last_kernel_ms.restype = C.c_int
     L.cz_context_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cz_context_last_chain_ms.restype = C.c_int
+    L.cz_context_last_chain_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_set_chain_arena.restype = C.c_int
     L.cz_context_set_chain_arena.argtypes = [vp, sz]
     L.cz_context_set_verify_checksum.restype = C.c_int

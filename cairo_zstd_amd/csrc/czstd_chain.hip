@@ -25,7 +25,6 @@
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 #define CZC_MAXSYM 64
 #define CZC_RING 256u
-#define CZC_BLOCK 128u
 #define CZC_NEED 96u        /* >= 8 steps x 89 bits */
 #define CZC_STEPS 8u
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
@@ -101,25 +100,35 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
 __device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E) {
     uint4 v;
     if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (const void*)a, 16); return v; }
+    if (a + 16 <= S || a >= E) { v.x = v.y = v.z = v.w = 0; return v; }
     uint32_t w[4] = {0, 0, 0, 0};
     for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
-/* lanes k*LPS .. k*LPS+LPS-1 stage one 128-byte block (128-aligned absolute address) of slot k's bitstream */
-__device__ static inline void czc_stage_ring(CzChainShared& cs, unsigned long long needmask, uintptr_t block, uintptr_t S, uintptr_t E) {
-    const uint32_t k = (uint32_t)LANE / CZC_LPS < CZC_SLOTS ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
+/* Ring top-up.  The 256-byte ring of slot k holds stream bytes [lo_k, lo_k + 256), indexed by absolute
+ * address & 255.  Lanes k*LPS .. k*LPS+LPS-1 extend it downwards from old_lo to new_lo (both 16-aligned,
+ * old_lo - new_lo <= 256) with 16-byte loads, all issued before the first LDS write.  Sk/Ek are the
+ * helper lane's copy of its slot's stream bounds; old_lo/new_lo are the OWNER lane's values.
+ * A wave stalls on global-memory latency here, so the caller tops up EVERY slot to the brim whenever
+ * any slot runs low: one stall per ~50 chain steps instead of one per slot per block. */
+#define CZC_PF ((16 + CZC_LPS - 1) / CZC_LPS)
+__device__ static inline void czc_topup(CzChainShared& cs, intptr_t old_lo, intptr_t new_lo, uintptr_t Sk, uintptr_t Ek) {
     const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
-    /* block / S / E are the OWNER lane's values: fetch them from lane k */
-    const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)block >> 32), (int)k) << 32) | __shfl((uint32_t)block, (int)k);
-    const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)S >> 32), (int)k) << 32) | __shfl((uint32_t)S, (int)k);
-    const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)E >> 32), (int)k) << 32) | __shfl((uint32_t)E, (int)k);
-    if (helper && ((needmask >> k) & 1ull)) for (uint32_t c = j; c < CZC_BLOCK / 16; c += CZC_LPS) {
-        const uintptr_t a = bk + 16u * c;
-        const uint4 v = czc_load16(a, Sk, Ek);
-        const uint32_t slot = (uint32_t)(a & (CZC_RING - 1));
-        *(uint4*)&cs.slot[k].ring[slot] = v;
-        if (slot == CZC_RING - 16) { *(uint32_t*)&cs.slot[k].mirror[8] = v.z; *(uint32_t*)&cs.slot[k].mirror[12] = v.w; }
+    const uint32_t k = helper ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
+    const uintptr_t ok = ((uintptr_t)__shfl((uint32_t)((uint64_t)old_lo >> 32), (int)k) << 32) | __shfl((uint32_t)old_lo, (int)k);
+    const uint32_t cnt = helper ? (uint32_t)__shfl((uint32_t)(old_lo - new_lo), (int)k) >> 4 : 0;
+    uint4 v[CZC_PF];
+#pragma unroll
+    for (uint32_t r = 0; r < CZC_PF; r++) { const uint32_t c = j + r * CZC_LPS; if (c < cnt) v[r] = czc_load16(ok - 16u * (c + 1), Sk, Ek); }
+#pragma unroll
+    for (uint32_t r = 0; r < CZC_PF; r++) {
+        const uint32_t c = j + r * CZC_LPS;
+        if (c < cnt) {
+            const uint32_t slot = (uint32_t)((ok - 16u * (c + 1)) & (CZC_RING - 1));
+            *(uint4*)&cs.slot[k].ring[slot] = v[r];
+            if (slot == CZC_RING - 16) { *(uint32_t*)&cs.slot[k].mirror[8] = v[r].z; *(uint32_t*)&cs.slot[k].mirror[12] = v[r].w; }
+        }
     }
 }
 /* 64 stream bits below ring-space bit address u (exclusive); see cz_ring_window */
@@ -145,7 +154,11 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
         const uint32_t eLL = sl.t_ll[sLL], eOF = sl.t_of[sOF], eML = sl.t_ml[sML];
         const uint32_t xl = (eLL >> 1) & 31, xm = (eML >> 1) & 31, xo = (eOF >> 1) & 31, a_ = xl + xm + xo;
         const uint32_t ph = (uint32_t)u & 31;
+#ifndef CZC_EXP_NOSTORE
         rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
+#else
+        if (u == 0x7FFFFFF) rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
+#endif
         slow |= a_ > 32;
         const uint32_t sel = ph >= a_;
         const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
@@ -160,6 +173,16 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
     }
 }
 
+/* Diagnostic build only: wave-level s_memtime sums per phase of this kernel, in args.prof[32..39]:
+ * 32 block parse + table build, 33 ring fill + state init, 34 top-up events, 35 chain groups, 36 finalize,
+ * 37 number of top-up events, 38 number of groups. */
+#ifdef CZ_PROFILE
+#define CZC_PROF_ACC(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); cprof[i] += n_ - ct_; ct_ = n_; } while (0)
+#define CZC_PROF_CNT(i) do { cprof[i] += 1; } while (0)
+#else
+#define CZC_PROF_ACC(i) do { } while (0)
+#define CZC_PROF_CNT(i) do { } while (0)
+#endif
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
     __shared__ CzChainShared cs;
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) cs.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
@@ -167,6 +190,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
     __syncthreads();
     const int owner = LANE < CZC_SLOTS;
     CzChainSlot& sl = cs.slot[owner ? LANE : 0];
+#ifdef CZ_PROFILE
+    unsigned long long cprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
         /* ---- one frame per slot */
         uint32_t f = 0xFFFFFFFFu;
@@ -292,18 +318,24 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 bitoff = off;
                 if (punt) { have = 0; frame_done = 1; }
             }
-            /* ---- bit ring: stage the top two 128-byte blocks of every live stream */
+            CZC_PROF_ACC(0);
+            /* ---- bit ring: fill every live slot's ring with the top 256 bytes of its stream */
             const uintptr_t S = have ? (uintptr_t)blk + bitoff : 0, E = have ? (uintptr_t)blk + bsize : 0;
             const uint32_t sbits = (uint32_t)(S & (CZC_RING - 1)) * 8u;
+            const intptr_t ring_base = (intptr_t)(S & ~(uintptr_t)(CZC_RING - 1));          /* ring-space bit u <-> byte ring_base + (u >> 3) */
             intptr_t loaded_lo = 0;
+            uintptr_t Sk, Ek;                                           /* helper lanes: bounds of their slot's stream */
             {
+                const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
+                const int k = helper ? (int)((uint32_t)LANE / CZC_LPS) : 0;
+                Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)S >> 32), k) << 32) | __shfl((uint32_t)S, k);
+                Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)E >> 32), k) << 32) | __shfl((uint32_t)E, k);
                 const unsigned long long hm = __ballot(have);
                 __syncthreads();
                 if (hm) {
-                    const uintptr_t top = (E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZC_BLOCK - 1);
-                    czc_stage_ring(cs, hm, top, S, E);
-                    czc_stage_ring(cs, hm, top - CZC_BLOCK, S, E);
-                    loaded_lo = (intptr_t)(top - CZC_BLOCK);
+                    const intptr_t hi = (intptr_t)((E + 15) & ~(uintptr_t)15);
+                    loaded_lo = have ? hi - (intptr_t)CZC_RING : 0;
+                    czc_topup(cs, have ? hi : 0, loaded_lo, Sk, Ek);
                     __syncthreads();
                 }
             }
@@ -327,17 +359,21 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 u = (int32_t)sbits + p;
             }
             uint64_t* rec = a.chain_arena + hdr + 4 + CZC_MAP_WORDS;
+            CZC_PROF_ACC(1);
             while (__ballot(chain_live)) {
-                /* keep CZC_NEED bytes below every live cursor staged */
+                /* keep CZC_NEED bytes below every live cursor staged; when one slot runs low, all top up */
                 {
-                    const intptr_t cur = (intptr_t)S + ((u - (int32_t)sbits > 0 ? u - (int32_t)sbits - 1 : 0) >> 3);
-                    const int need = chain_live && (cur - (intptr_t)CZC_NEED < loaded_lo);
-                    const unsigned long long nm = __ballot(need);
-                    if (nm) {
-                        if (need) loaded_lo -= (intptr_t)CZC_BLOCK;
+                    const intptr_t curb = ring_base + ((u > 0 ? u - 1 : 0) >> 3);       /* byte that holds the next unread bit */
+                    const int need = chain_live && (curb - (intptr_t)CZC_NEED < loaded_lo);
+                    if (__ballot(need)) {
+                        /* lowest start whose 256 bytes still cover the word at the cursor */
+                        intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
+                        if (new_lo > loaded_lo) new_lo = loaded_lo;
                         __syncthreads();
-                        czc_stage_ring(cs, nm, (uintptr_t)loaded_lo, S, E);
+                        czc_topup(cs, loaded_lo, new_lo, Sk, Ek);
+                        loaded_lo = new_lo;
                         __syncthreads();
+                        CZC_PROF_ACC(2); CZC_PROF_CNT(5);
                     }
                 }
                 {
@@ -351,6 +387,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         done += steps;
                         if (done >= nseq) chain_live = 0;
                     }
+                    CZC_PROF_ACC(3); CZC_PROF_CNT(6);
                 }
             }
             /* ---- finalize the block */
@@ -367,5 +404,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             __syncthreads();
         }
         if (owner && f < a.n) a.frame_first[f] = punt ? 0 : first_hdr;
+        CZC_PROF_ACC(4);
     }
+#ifdef CZ_PROFILE
+    if (LANE == 0 && a.prof) for (int i = 0; i < 8; i++) atomicAdd(&a.prof[32 + i], cprof[i]);
+#endif
 }

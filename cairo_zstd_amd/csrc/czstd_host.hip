@@ -31,7 +31,7 @@ struct cz_context {
     hipStream_t stream = nullptr; bool own_stream = false;
     int num_cu = 0, occupancy = 0, grid_max = 0;
     uint8_t* lit_scratch = nullptr; uint32_t* work_counter = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr; bool timed = false;
+    hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false;
     int last_grid = 0;
     int last_hip_error = 0;
     /* staging for cz_decode_batch_host */
@@ -70,7 +70,7 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     const int scratch_slots = c->grid_max;   /* one scratch region per resident workgroup */
     if (hipMalloc((void**)&c->lit_scratch, (size_t)scratch_slots * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
         hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
-        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         if (c->lit_scratch) (void)hipFree(c->lit_scratch);
         if (c->work_counter) (void)hipFree(c->work_counter);
         delete c; return CZ_E_HIP;
@@ -92,6 +92,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
     (void)hipMemset(c->d_prof, 0, sizeof tmp);
     int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
     for (int i = 0; i < n; i++) out[i] = tmp[i];
+    for (int i = 32; i < 40 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_* */
     return n;
 }
 
@@ -107,6 +108,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->chain_top) (void)hipFree(c->chain_top);
     if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -131,6 +133,15 @@ CZ_EXPORT int cz_context_last_kernel_ms(cz_context* c, float* ms) {
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipEventSynchronize(c->ev_stop));
     CZ_HIP(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return CZ_OK;
+}
+/* Part of that launch spent in cz_chain_kernel (0 when the pre-pass is off). */
+CZ_EXPORT int cz_context_last_chain_ms(cz_context* c, float* ms) {
+    if (!c || !ms) return CZ_E_INVALID_ARG;
+    *ms = 0.0f;
+    if (!c->timed || !c->timed_chain) return CZ_OK;
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_start, c->ev_mid));
     return CZ_OK;
 }
 
@@ -181,7 +192,9 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
-    }
+        CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
+        c->timed_chain = true;
+    } else c->timed_chain = false;
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, a);

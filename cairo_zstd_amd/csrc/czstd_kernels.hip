@@ -51,6 +51,8 @@ enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CH
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
+#define CZ_OBUF_BYTES 1024u /* chunk output assembled in LDS when it is at most this long (cz_execute_chunk) */
+#define CZ_OBUF_MAXLEN 64u  /* ... and no literal run or match of the chunk is longer than this */
 
 
 /* ------------------------------------------------------------------ LDS layout */
@@ -91,7 +93,8 @@ struct CzShared {
         uint16_t huf[2048];
         struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; } t1;
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
-        struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64]; } t4;   /* mirror[8..15] == ring[2040..2047] */
+        struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64];
+                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16]; } t4;   /* mirror[8..15] == ring[2040..2047] */
     } a;
     struct {
         struct { uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
@@ -119,10 +122,26 @@ __device__ static inline uint32_t cz_hbs(uint32_t v) { return v ? 32u - (uint32_
 
 __device__ static inline void cz_init_llml(CzShared& sh);
 /* ------------------------------------------------------------------ wave helpers */
+/* Cross-lane moves on the VALU (DPP) instead of the LDS crossbar: row_shr:n within rows of 16 lanes,
+ * then row_bcast:15 / row_bcast:31 carry the row totals upwards — the gfx9 wave64 scan idiom.  A lane
+ * without a source (or outside the row mask) gets `old`. */
+template <int CTRL, int ROWMASK> __device__ static inline uint32_t cz_dpp(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+#define CZ_DPP_SHR1 0x111
+#define CZ_DPP_SHR2 0x112
+#define CZ_DPP_SHR4 0x114
+#define CZ_DPP_SHR8 0x118
+#define CZ_DPP_WAVE_SHR1 0x138
+#define CZ_DPP_BCAST15 0x142
+#define CZ_DPP_BCAST31 0x143
 __device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, (unsigned)d); if (LANE >= d) v += t; }
+    v += cz_dpp<CZ_DPP_SHR1, 0xF>(0, v); v += cz_dpp<CZ_DPP_SHR2, 0xF>(0, v);
+    v += cz_dpp<CZ_DPP_SHR4, 0xF>(0, v); v += cz_dpp<CZ_DPP_SHR8, 0xF>(0, v);
+    v += cz_dpp<CZ_DPP_BCAST15, 0xA>(0, v); v += cz_dpp<CZ_DPP_BCAST31, 0xC>(0, v);
     return v;
 }
+__device__ static inline uint32_t cz_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
 /* all-lane copy, 16 B per lane per step once dst is 16-byte aligned.  Both pointers are
  * global memory: say so, so that the loop uses global_load / global_store (not flat_*). */
@@ -799,7 +818,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
     const int active = (uint32_t)LANE < cnt;
     if (!active) { ll = 0; ml = 0; off = 1; }
     const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
-    const uint32_t sum_ll = cz_uni(__shfl(incl_ll, 63)), sum_tot = cz_uni(__shfl(incl_tot, 63));
+    const uint32_t sum_ll = cz_readlane(incl_ll, 63), sum_tot = cz_readlane(incl_tot, 63);
     const uint32_t lit_start = x.lit_used + (incl_ll - ll);
     const uint64_t out_start = x.produced + (uint64_t)(incl_tot - tot);
     const uint64_t dst = out_start + ll;                                /* where the match goes */
@@ -813,6 +832,89 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
     }
     const unsigned long long emask = __ballot(e != 0);
     if (emask) { const int first = __ffsll((long long)emask) - 1; return cz_unii(__shfl(e, first)); }
+
+    /* Fast path for chunks of short sequences: the chunk's output is assembled in LDS and written out
+     * with coalesced stores.  Literal bytes and match bytes whose source lies before the chunk are
+     * fetched from global memory with every load of a lane issued before its first use (one memory
+     * round trip per phase instead of one per byte); matches that read the chunk's own output are
+     * resolved by dependency rounds inside LDS. */
+    if (sum_tot <= CZ_OBUF_BYTES && !__ballot(ll > CZ_OBUF_MAXLEN || ml > CZ_OBUF_MAXLEN)) {
+        uint8_t* ob = sh.a.t4.obuf;
+        const uint32_t orel = incl_tot - tot, drel = orel + ll;
+        uint8_t* const cout = x.out + x.produced;                       /* chunk output base */
+        if (ll > 0) {
+            if (lit.rle) { for (uint32_t k = 0; k < ll; k++) ob[orel + k] = lit.byte; }
+            else {
+                const uint8_t* s = lit.p + lit_start;
+                for (uint32_t k = 0; k < ll; k += 8) {
+                    const uint32_t n = ll - k; uint8_t t[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) if (j < n) t[j] = s[k + j];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) if (j < n) ob[orel + k + j] = t[j];
+                }
+            }
+        }
+        /* source range relative to the chunk base: [srel, srel + span) with span = min(off, ml) */
+        const int32_t srel = (int32_t)drel - (int32_t)(off < 0x40000000u ? off : 0x40000000u);
+        const uint32_t span = off < ml ? off : ml;
+        int near = 0;
+        if (ml > 0) {
+            if (srel + (int32_t)span <= 0) {                            /* every source byte precedes the chunk */
+                const uint8_t* s = cout + (drel - (uint64_t)off);
+                if (off >= ml) {
+                    /* no overlap: 4-byte loads; the over-read stays below dst + 3 <= cap */
+                    for (uint32_t k = 0; k < ml; k += 16) {
+                        const uint32_t n = ml - k; uint32_t w[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) if (4 * j < n) __builtin_memcpy(&w[j], s + k + 4 * j, 4);
+#pragma unroll
+                        for (uint32_t j = 0; j < 16; j++) if (j < n) ob[drel + k + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                    }
+                } else {
+                    uint32_t idx = 0;                                   /* period-off pattern (decode_buffer.cairo:101-120) */
+                    for (uint32_t k = 0; k < ml; k += 8) {
+                        const uint32_t n = ml - k; uint8_t t[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) if (j < n) { t[j] = s[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) if (j < n) ob[drel + k + j] = t[j];
+                    }
+                }
+            } else near = 1;
+        }
+        __syncthreads();
+        CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+        /* matches that read this chunk's output: rounds.  W = destination of the first undone match;
+           a match may go once its source range (clipped to its own destination) lies below W. */
+        int done = !near;
+        const int32_t send = srel + (int32_t)span;                      /* <= drel */
+        for (;;) {
+            const unsigned long long pend = __ballot(!done);
+            if (!pend) break;
+            const int f = __ffsll((long long)pend) - 1;
+            const int32_t W = (int32_t)__shfl(drel, f);
+            if (!done && send <= W) {
+                uint32_t idx = 0;
+                for (uint32_t k = 0; k < ml; k++) {
+                    const int32_t q = srel + (int32_t)idx;
+                    ob[drel + k] = q < 0 ? cout[q] : ob[q];
+                    idx = idx + 1 == off ? 0 : idx + 1;
+                }
+                done = 1;
+            }
+            __syncthreads();
+        }
+        /* write the assembled chunk: 4 bytes per lane per pass (the global address need not be aligned) */
+        for (uint32_t i = 4u * (uint32_t)LANE; i < sum_tot; i += 256) {
+            if (i + 4 <= sum_tot) { uint32_t w = *(const uint32_t*)(ob + i); __builtin_memcpy(cout + i, &w, 4); }
+            else for (uint32_t j = i; j < sum_tot; j++) cout[j] = ob[j];
+        }
+        __syncthreads();
+        CZ_PROF_ACC(sh, CZ_P_MATCH);
+        x.produced += sum_tot; x.lit_used += sum_ll;
+        return 0;
+    }
 
     /* literals: short runs per lane, long runs cooperatively */
     const int long_lit = ll > 32;
@@ -905,6 +1007,7 @@ __device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) {
 /* offset-history transforms (sequence_execution.cairo:85-129) as composable maps: each of the
  * three slots is either a constant (src 3) or old[src] + val.  s packs the three srcs. */
 struct CzHist { uint32_t s, v0, v1, v2; };
+#define CZ_HIST_ID (0u | (1u << 2) | (2u << 4))
 __device__ static inline uint32_t cz_hist_pick(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
 /* apply P, then Q */
 __device__ static inline CzHist cz_hist_compose(const CzHist& P, const CzHist& Q) {
@@ -931,7 +1034,7 @@ __device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const C
     const int active = (uint32_t)LANE < cnt;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
-    CzHist T; T.s = 0 | (1 << 2) | (2 << 4); T.v0 = T.v1 = T.v2 = 0;              /* identity */
+    CzHist T; T.s = CZ_HIST_ID; T.v0 = T.v1 = T.v2 = 0;                            /* identity */
     if (active) {
         if (ov > 3) { T.s = 3 | (0 << 2) | (1 << 4); T.v0 = ov - 3; }             /* push */
         else if (ll > 0) {
@@ -943,20 +1046,22 @@ __device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const C
             else { T.s = 0 | (0 << 2) | (1 << 4); T.v0 = 0xFFFFFFFFu; }           /* (h0 - 1, h0, h1) */
         }
     }
-    for (int d = 1; d < 64; d <<= 1) {
-        CzHist P; P.s = __shfl_up(T.s, (unsigned)d); P.v0 = __shfl_up(T.v0, (unsigned)d); P.v1 = __shfl_up(T.v1, (unsigned)d); P.v2 = __shfl_up(T.v2, (unsigned)d);
-        if (LANE >= d) T = cz_hist_compose(P, T);
-    }
-    CzHist X; X.s = __shfl_up(T.s, 1u); X.v0 = __shfl_up(T.v0, 1u); X.v1 = __shfl_up(T.v1, 1u); X.v2 = __shfl_up(T.v2, 1u);
-    if (LANE == 0) { X.s = 0 | (1 << 2) | (2 << 4); X.v0 = X.v1 = X.v2 = 0; }
+    /* inclusive scan; a lane without a predecessor in a step composes with the identity */
+#define CZ_HIST_STEP(CTRL, RM) do { CzHist P; P.s = cz_dpp<CTRL, RM>(CZ_HIST_ID, T.s); P.v0 = cz_dpp<CTRL, RM>(0, T.v0); \
+        P.v1 = cz_dpp<CTRL, RM>(0, T.v1); P.v2 = cz_dpp<CTRL, RM>(0, T.v2); T = cz_hist_compose(P, T); } while (0)
+    CZ_HIST_STEP(CZ_DPP_SHR1, 0xF); CZ_HIST_STEP(CZ_DPP_SHR2, 0xF); CZ_HIST_STEP(CZ_DPP_SHR4, 0xF); CZ_HIST_STEP(CZ_DPP_SHR8, 0xF);
+    CZ_HIST_STEP(CZ_DPP_BCAST15, 0xA); CZ_HIST_STEP(CZ_DPP_BCAST31, 0xC);
+#undef CZ_HIST_STEP
+    CzHist X; X.s = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_HIST_ID, T.s); X.v0 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v0);
+    X.v1 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v1); X.v2 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v2);
     const uint32_t b0 = cz_hist_eval(X.s & 3, X.v0, h0, h1, h2), b1 = cz_hist_eval((X.s >> 2) & 3, X.v1, h0, h1, h2),
                    b2 = cz_hist_eval((X.s >> 4) & 3, X.v2, h0, h1, h2);          /* history before this sequence */
     uint32_t actual;
     if (ov > 3) actual = ov - 3;
     else if (ll > 0) actual = ov == 1 ? b0 : (ov == 2 ? b1 : b2);
     else actual = ov == 1 ? b1 : (ov == 2 ? b2 : b0 - 1);
-    const int lastl = (int)cnt - 1;
-    const uint32_t ts = __shfl(T.s, lastl), t0 = __shfl(T.v0, lastl), t1 = __shfl(T.v1, lastl), t2 = __shfl(T.v2, lastl);
+    const int lastl = cz_unii((int)cnt - 1);
+    const uint32_t ts = cz_readlane(T.s, lastl), t0 = cz_readlane(T.v0, lastl), t1 = cz_readlane(T.v1, lastl), t2 = cz_readlane(T.v2, lastl);
     const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
     h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
     CZ_PROF_ACC(sh, CZ_P_EXTRACT);

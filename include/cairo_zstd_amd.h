@@ -114,6 +114,8 @@ int cz_context_set_verify_checksum(cz_context* ctx, int on);
  * hipEvents recorded on the context stream around the kernel (bench.py's roofline leg).
  * Blocks until that launch has finished. */
 int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
+/* The part of it spent in the FSE-chain pre-pass kernel (0 when the pre-pass is off). */
+int cz_context_last_chain_ms(cz_context* ctx, float* ms);
 
 /* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the
  * per-phase shader-cycle sums accumulated by the kernels; returns the number of phases written

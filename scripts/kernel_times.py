@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-kernel time of one batch decode for a list of library builds.
+
+    python scripts/kernel_times.py <kind> <frames> <lib.so> [<lib.so> ...]
+
+Each library is loaded in a child process (one HIP runtime per process); prints chain-kernel and
+total milliseconds (hipEvents inside the library) and whether all frames decoded."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(kind, n):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import cairo_zstd_amd as cz
+    from cairo_zstd_amd import synth
+    b = synth.generate(kind, n, nthreads=16)
+    out_off, out_cap, total = b.out_layout(256)
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(x).to(dev) for x in (b.base, b.off.astype(np.int64), b.length.astype(np.int64), out_off.astype(np.int64), out_cap.astype(np.int64))]
+    t_out = torch.empty(total, dtype=torch.uint8, device=dev)
+    t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("CZ_PREPASS", "1") == "1":
+        ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
+    tot, ch = [], []
+    for it in range(5):
+        ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
+        tot.append(ctx.last_kernel_ms())
+        ch.append(ctx.last_chain_ms())
+    res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+    ok = bool((res["status"] == 0).all() and (res["bytes_produced"] == b.regen).all())
+    print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
+          f"main {np.mean(tot[2:]) - np.mean(ch[2:]):8.3f} ms  ok={ok}", flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "--child":
+        child(sys.argv[2], int(sys.argv[3]))
+    else:
+        kind, n = sys.argv[1], sys.argv[2]
+        for lib in sys.argv[3:]:
+            env = dict(os.environ, CAIRO_ZSTD_AMD_LIB=os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind, n], env=env, timeout=300)

@@ -43,6 +43,13 @@ def main():
     for name, v in zip(PHASES, vals):
         print(f"  {name:11s} {v / n:14.0f} cycles/frame  {100.0 * v / tot:5.1f} %")
     print(f"  total       {tot / n:14.0f} cycles/frame")
+    cv = [buf[32 + i] for i in range(8)]
+    if sum(cv[:5]):
+        ct = sum(cv[:5])
+        print(f"cz_chain_kernel wave-time shares (s_memtime ticks summed over waves; {ctx.last_chain_ms():.3f} ms of the launch):")
+        for name, v in zip(["parse+tables", "ring fill+init", "top-up events", "chain groups", "finalize"], cv[:5]):
+            print(f"  {name:15s} {100.0 * v / ct:5.1f} %")
+        print(f"  top-up events {cv[5]}  ({cv[2] / max(cv[5], 1):.0f} ticks each), groups {cv[6]} ({cv[3] / max(cv[6], 1):.1f} ticks each; 1 tick = 10 ns)")
 
 
 if __name__ == "__main__":

@@ -42,6 +42,28 @@ template <class T> __attribute__((noinline)) static T __shfl_up(T v, unsigned d)
     uint64_t raw = 0; memcpy(&raw, &v, sizeof(T)); emu_xchg[threadIdx.x] = raw; emu_sync();
     uint64_t r = threadIdx.x >= d ? emu_xchg[threadIdx.x - d] : raw; emu_sync(); T out; memcpy(&out, &r, sizeof(T)); return out;
 }
+/* DPP (data-parallel primitives) as the kernels use them: row_shr:n (0x110+n), wave_shr:1 (0x138),
+ * row_bcast:15 (0x142), row_bcast:31 (0x143); rows are 16 lanes, banks 4 lanes.  A lane whose row or
+ * bank is masked off, or whose source lane does not exist, keeps `old` (bound_ctrl:0 semantics). */
+__attribute__((noinline)) static int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    emu_note(__builtin_return_address(0));
+    emu_xchg[threadIdx.x] = (uint32_t)src; emu_sync();
+    const int l = (int)threadIdx.x, row = l >> 4, pos = l & 15;
+    int from = -1;
+    if (ctrl > 0x110 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = pos - n >= 0 ? l - n : -1; }
+    else if (ctrl == 0x138) from = l - 1;
+    else if (ctrl == 0x142) from = row >= 1 ? row * 16 - 1 : -1;
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    else __builtin_trap();
+    int out = old;
+    if (((row_mask >> row) & 1) && ((bank_mask >> (pos >> 2)) & 1)) out = from >= 0 ? (int)(uint32_t)emu_xchg[from] : (bound_ctrl ? 0 : old);
+    emu_sync(); return out;
+}
+__attribute__((noinline)) static int __builtin_amdgcn_readlane(int v, int lane) {
+    emu_note(__builtin_return_address(0));
+    emu_xchg[threadIdx.x] = (uint32_t)v; emu_sync();
+    const int r = (int)(uint32_t)emu_xchg[lane & 63]; emu_sync(); return r;
+}
 __attribute__((noinline)) static unsigned long long __ballot(int pred) {
     emu_note(__builtin_return_address(0));
     emu_xchg[threadIdx.x] = pred ? 1 : 0; emu_sync();
