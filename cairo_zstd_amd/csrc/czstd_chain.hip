@@ -99,10 +99,10 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
 /* 16 bytes at absolute address a, zero outside [S, E) */
 __device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E) {
     uint4 v;
-    if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (const void*)a, 16); return v; }
+    if (a >= S && a + 16 <= E) { __builtin_memcpy(&v, (CZ_GLOBAL const void*)a, 16); return v; }
     if (a + 16 <= S || a >= E) { v.x = v.y = v.z = v.w = 0; return v; }
     uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+    for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(cz_gcptr)q) << (8 * (b & 3)); }
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
@@ -306,7 +306,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         if (map) map[0] = (uint8_t)sym;
                         rles[t] = (int32_t)sym;
                     } else if (md[t] == 2) {
-                        CzFBits br; br.g = blk + off; br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
+                        CzFBits br; br.g = (cz_gcptr)(blk + off); br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
                         if (off - sbody < 256) { br.stage = sl.stage + (off - sbody); br.stage_hi = 256 - (off - sbody); }
                         uint32_t np, lg, used;
                         if (cz_fse_read_probs(br, max_log[t], sl.probs, &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }

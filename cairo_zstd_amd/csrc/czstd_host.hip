@@ -10,6 +10,7 @@
  *                         block_decoder.cairo:237-278)
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -175,7 +176,10 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
     a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum;
-    const int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
+    int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
+#ifdef CZ_EXPERIMENT
+    if (const char* e = getenv("CZ_GRID_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < grid) grid = g; }
+#endif
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;

@@ -28,6 +28,19 @@
 
 #define LANE ((int)threadIdx.x)
 #define CZ_NOINLINE __attribute__((noinline))
+/* Pointers to global memory say so in their type.  A generic pointer that crosses a function that is
+ * not inlined (or sits in a struct) makes the compiler emit flat_* instructions, which count against
+ * BOTH vmcnt and lgkmcnt: every LDS wait then also waits for all global loads in flight. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CZ_GLOBAL __attribute__((address_space(1)))
+#else
+#define CZ_GLOBAL            /* host pass of the same translation unit (and the CPU emulator): the device code is only parsed */
+#endif
+typedef CZ_GLOBAL const uint8_t* cz_gcptr;
+typedef CZ_GLOBAL uint8_t* cz_gptr;
+typedef CZ_GLOBAL uint4* cz_gptr4;
+typedef CZ_GLOBAL const uint64_t* cz_gcptr64;
+typedef CZ_GLOBAL uint16_t* cz_gptr16;
 /* Values that are the same in every lane (read from the LDS broadcast slots, or produced by a
  * cross-lane broadcast) are pinned to scalar registers: keeps the VGPR budget for per-lane work
  * and lets the scalar unit do the uniform arithmetic. */
@@ -40,11 +53,11 @@ __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_un
 #ifdef CZ_PROFILE
 #define CZ_PROF_DECL unsigned long long cz_t_ = 0
 #define CZ_PROF_T0() do { if (LANE == 0) cz_t_ = __builtin_amdgcn_s_memtime(); } while (0)
-#define CZ_PROF_ACC(sh_, idx) do { if (LANE == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); (sh_).prof[idx] += n_ - cz_t_; cz_t_ = n_; } } while (0)
+#define CZ_PROF_ACC(idx) do { if (LANE == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); sh.prof[idx] += n_ - cz_t_; cz_t_ = n_; } } while (0)
 #else
 #define CZ_PROF_DECL
 #define CZ_PROF_T0() do { } while (0)
-#define CZ_PROF_ACC(sh_, idx) do { } while (0)
+#define CZ_PROF_ACC(idx) do { } while (0)
 #endif
 enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER,
        CZ_P_HUF_SPEC, CZ_P_HUF_SYNC, CZ_P_HUF_WRITE, CZ_P_COUNT };   /* the last three are sub-phases of CZ_P_HUFDEC (counted in both) */
@@ -87,7 +100,6 @@ struct CzBroadcast {
  * created one is not the last block it is spilled to a 4 KiB global slot and re-read by
  * Treeless blocks (literals_section_decoder.cairo:82-86). */
 struct CzShared {
-    uint32_t *fse_ll, *fse_ml, *fse_of;   /* 512 + 512 + 256 entries, in the dynamic part of LDS (CZ_FSE_LDS_BYTES) */
     uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
     union {
         uint16_t huf[2048];
@@ -105,7 +117,16 @@ struct CzShared {
     unsigned long long prof[CZ_P_COUNT];
 #endif
 };
-__device__ static inline uint32_t* cz_fse_table(CzShared& sh, int t) { return t == 0 ? sh.fse_ll : (t == 1 ? sh.fse_of : sh.fse_ml); }
+/* The workgroup's LDS lives at module scope: every function, inlined or not, then addresses it in the
+ * LDS address space (ds_* instructions, lgkmcnt only).  Passing it by reference through a function
+ * that is not inlined turns the accesses into flat_* instructions, whose waits also cover every
+ * outstanding global load. */
+__shared__ CzShared sh;
+CZ_DYNAMIC_LDS(cz_dyn_lds);                                             /* CZ_FSE_LDS_BYTES: the three FSE decoding tables */
+#define CZ_FSE_LL (cz_dyn_lds)          /* 512 entries */
+#define CZ_FSE_ML (cz_dyn_lds + 512)    /* 512 entries */
+#define CZ_FSE_OF (cz_dyn_lds + 1024)   /* 256 entries */
+__device__ static inline uint32_t* cz_fse_table(int t) { return t == 0 ? CZ_FSE_LL : (t == 1 ? CZ_FSE_OF : CZ_FSE_ML); }
 
 /* sequence_section_decoder.cairo:299-345 / :347-395 */
 __device__ static const uint32_t CZ_LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
@@ -120,7 +141,7 @@ __device__ static const int8_t CZ_ML_DEFAULT[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,
 /* math.cairo:266-271: 1-based index of the highest set bit */
 __device__ static inline uint32_t cz_hbs(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
 
-__device__ static inline void cz_init_llml(CzShared& sh);
+__device__ static inline void cz_init_llml();
 /* ------------------------------------------------------------------ wave helpers */
 /* Cross-lane moves on the VALU (DPP) instead of the LDS crossbar: row_shr:n within rows of 16 lanes,
  * then row_bcast:15 / row_bcast:31 carry the row totals upwards — the gfx9 wave64 scan idiom.  A lane
@@ -142,12 +163,13 @@ __device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
     return v;
 }
 __device__ static inline uint32_t cz_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+/* A workgroup is ONE wave (CZ_WG_THREADS == 64): its LDS and vector-memory instructions execute in
+ * program order, so making one lane's write visible to another lane's later read needs no wait and
+ * no s_barrier — only that the compiler keeps the order. */
+__device__ static inline void cz_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 /* all-lane copy, 16 B per lane per step once dst is 16-byte aligned.  Both pointers are
  * global memory: say so, so that the loop uses global_load / global_store (not flat_*). */
-typedef __attribute__((address_space(1))) const uint8_t* cz_gcptr;
-typedef __attribute__((address_space(1))) uint8_t* cz_gptr;
-typedef __attribute__((address_space(1))) uint4* cz_gptr4;
 __device__ static void cz_coop_copy(uint8_t* dst_, const uint8_t* src_, uint64_t n) {
     cz_gptr dst = (cz_gptr)dst_; cz_gcptr src = (cz_gcptr)src_;
     uint32_t head = (uint32_t)((16u - ((uintptr_t)dst_ & 15u)) & 15u);
@@ -223,7 +245,7 @@ __device__ static inline int cz_rb_skip_padding(CzRBits& r) {
 
 /* Forward LSB-first reader (bit_reader.cairo:18-110) used by ONE lane for table
  * descriptions.  Bytes come from the LDS stage when inside it, else from global memory. */
-struct CzFBits { const uint8_t* g; uint32_t len; const uint8_t* stage; uint32_t stage_lo, stage_hi; uint32_t idx; };
+struct CzFBits { cz_gcptr g; uint32_t len; const uint8_t* stage; uint32_t stage_lo, stage_hi; uint32_t idx; };
 __device__ static inline uint32_t cz_fb_byte(const CzFBits& f, uint32_t i) {
     return (i >= f.stage_lo && i < f.stage_hi) ? f.stage[i - f.stage_lo] : f.g[i];
 }
@@ -322,7 +344,7 @@ __device__ static __attribute__((noinline)) void cz_fse_build(uint32_t* table, c
  * (huff0_decoder.cairo:159-319, :321-431).  Lane 0.  Leaves per-symbol code lengths in
  * sh.b.c.hbits[0..nsym) and first-cell indices in sh.b.c.sym_base[]; the table itself is filled by
  * all lanes afterwards (cz_huf_fill).  *bytes_used per :313-318. */
-__device__ static __attribute__((noinline)) int cz_huf_read_and_rank(CzShared& sh, const uint8_t* g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
+__device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
                                            uint32_t goff, uint32_t* bytes_used, uint32_t* nsym_out) {
     /* g = block start, the tree description begins at block offset goff, len bytes available */
     if (len == 0) return CZ_E_HUF_SOURCE_EMPTY;                         /* :162 */
@@ -393,7 +415,7 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(CzShared& s
     return 0;
 }
 /* all lanes: the cell-filling half (huff0_decoder.cairo:451-463).  entry = symbol | bits<<8 */
-__device__ static __attribute__((noinline)) void cz_huf_fill(CzShared& sh, uint32_t nsym) {
+__device__ static __attribute__((noinline)) void cz_huf_fill(uint32_t nsym) {
     const uint32_t max_bits = sh.huf_max_bits;
     for (uint32_t s = 0; s < nsym; s++) {
         const uint32_t b = sh.b.c.hbits[s];
@@ -405,7 +427,7 @@ __device__ static __attribute__((noinline)) void cz_huf_fill(CzShared& sh, uint3
 }
 /* One huff0 stream, one lane (literals_section_decoder.cairo:183-243).  Writes at most `cap`
  * bytes to out but keeps counting.  flags: 1 ExtraPadding, 2 stream did not end exactly. */
-__device__ static __attribute__((noinline)) void cz_huf_stream(const CzShared& sh, const uint8_t* src, uint32_t len, uint8_t* out, uint32_t cap,
+__device__ static __attribute__((noinline)) void cz_huf_stream(cz_gcptr src, uint32_t len, cz_gptr out, uint32_t cap,
                                      uint32_t* count, uint32_t* flags) {
     CzRBits rb; cz_rb_init(rb, src, len);
     if (cz_rb_skip_padding(rb)) { *count = 0; *flags = 1; return; }    /* :190-207 */
@@ -426,7 +448,7 @@ __device__ static __attribute__((noinline)) void cz_huf_stream(const CzShared& s
 
 /* ------------------------------------------------------------------ frame / block headers */
 /* read_frame_header + window_size (frame.cairo:152-284, :106-129).  Lane 0. */
-__device__ static __attribute__((noinline)) int cz_parse_frame_header(const uint8_t* p, uint64_t len, CzBroadcast& bc) {
+__device__ static __attribute__((noinline)) int cz_parse_frame_header(cz_gcptr p, uint64_t len, CzBroadcast& bc) {
     if (len < 4) return CZ_E_FH_MAGIC_READ;
     const uint32_t magic = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
     uint32_t i = 4;
@@ -462,7 +484,7 @@ __device__ static __attribute__((noinline)) int cz_parse_frame_header(const uint
 }
 
 /* ------------------------------------------------------------------ literals */
-struct CzLit { const uint8_t* p; uint32_t len; uint32_t rle; uint8_t byte; };   /* rle=1: `len` copies of byte */
+struct CzLit { cz_gcptr p; uint32_t len; uint32_t rle; uint8_t byte; };   /* rle=1: `len` copies of byte */
 
 __device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, uint32_t from, uint32_t n) {
     if (lit.rle) cz_coop_fill(dst, lit.byte, n); else cz_coop_copy(dst, lit.p + from, n);
@@ -471,7 +493,7 @@ __device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, u
 /* LiteralsSection::parse_from_header (literals_section.cairo:81-175) + the serial parts of
  * decompress_literals (literals_section_decoder.cairo:58-117) + SequencesHeader::parse_from_header
  * (sequence_section.cairo:77-114).  Lane 0; results in sh.bc. */
-__device__ static __attribute__((noinline)) int cz_parse_sections(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_hi) {
+__device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, uint32_t bsize, uint32_t stage_hi) {
     CzBroadcast& bc = sh.bc;
     CzFBits fb; fb.g = blk; fb.stage = sh.a.t1.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
     if (bsize == 0) return CZ_E_LS_GETBITS;                             /* :84-90 */
@@ -496,7 +518,7 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(CzShared& sh, 
         uint32_t off = need, left = comp;
         if (type == 2) {
             uint32_t used, nsym;
-            int e = cz_huf_read_and_rank(sh, blk, left, 0, stage_hi, off, &used, &nsym);
+            int e = cz_huf_read_and_rank(blk, left, 0, stage_hi, off, &used, &nsym);
             if (e) return e;
             bc.huf_fill = 1; bc.huf_nsym = nsym;
             if (used > left) return CZ_E_BLOCK_TRUNCATED;               /* (panic) slice(bytes_read, len) :89 */
@@ -533,7 +555,7 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(CzShared& sh, 
     return 0;
 }
 
-__device__ static inline void cz_init_llml(CzShared& sh) {
+__device__ static inline void cz_init_llml() {
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) sh.b.c.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.b.c.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
 }
@@ -571,7 +593,7 @@ __device__ static inline uint32_t cz_mask_low_bytes(uint32_t w, uint32_t word_lo
 __device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E, uintptr_t LB) {
     uint4 v;
     if (a >= LB && a + 16 <= E) {
-        __builtin_memcpy(&v, (const void*)a, 16);
+        __builtin_memcpy(&v, (CZ_GLOBAL const void*)a, 16);
         if (a < S) {                                                    /* zero the bytes below the stream start */
             const uint32_t nb = (uint32_t)(S - a) > 16 ? 16u : (uint32_t)(S - a);
             v.x = cz_mask_low_bytes(v.x, 0, nb); v.y = cz_mask_low_bytes(v.y, 4, nb); v.z = cz_mask_low_bytes(v.z, 8, nb); v.w = cz_mask_low_bytes(v.w, 12, nb);
@@ -580,13 +602,13 @@ __device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E,
     }
     uint32_t w[4] = {0, 0, 0, 0};
     if (a + 16 > S && a < E)
-        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= S && q < E) w[b >> 2] |= (uint32_t)(*(cz_gcptr)q) << (8 * (b & 3)); }
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
 /* One interval: reload the window at the current position, then decode up to CZ_GB_SYMS symbols
  * while p > stop.  `run` = this lane still has work.  Returns symbols decoded. */
-__device__ static inline uint32_t cz_gb_interval(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, int run, uint8_t* out, uint32_t cap, uint32_t n0) {
+__device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_t stop, int run, uint8_t* out, uint32_t cap, uint32_t n0) {
     uint32_t n = 0;
     if (run) {
         const int32_t p = g.p;
@@ -624,13 +646,13 @@ __device__ static inline uint32_t cz_gb_interval(const CzShared& sh, CzGBits& g,
     return n;
 }
 /* decode from position g.p while p > stop (all 64 lanes call this together; `live` lanes work) */
-__device__ static inline uint32_t cz_gb_decode(const CzShared& sh, CzGBits& g, uint32_t mb, int32_t stop, int live, uint8_t* out, uint32_t cap,
+__device__ static inline uint32_t cz_gb_decode(CzGBits& g, uint32_t mb, int32_t stop, int live, uint8_t* out, uint32_t cap,
                                             int32_t* ck = nullptr) {
     uint32_t n = 0, it = 0;
     for (;;) {
         const int run = live && g.p > stop;
         if (!__ballot(run)) break;
-        const uint32_t got = cz_gb_interval(sh, g, mb, stop, run, out, cap, n);
+        const uint32_t got = cz_gb_interval(g, mb, stop, run, out, cap, n);
         n += got; it++;
         /* checkpoints of the speculative pass: position after 1, 2, 4 and 8 FULL intervals */
         if (ck && run && got == CZ_GB_SYMS) { if (it == 1) ck[0] = g.p; else if (it == 2) ck[1] = g.p; else if (it == 4) ck[2] = g.p; else if (it == 8) ck[3] = g.p; }
@@ -641,7 +663,7 @@ __device__ static inline uint32_t cz_gb_decode(const CzShared& sh, CzGBits& g, u
 /* All huff0 streams of a block; same contract as the sequential decoder: out_k = target + k*seg,
  * at most cap_k bytes written, bc.st_count[k] / bc.st_flags[k] (1 ExtraPadding, 2 stream did not
  * end exactly, 4 count != cap_k). */
-__device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint8_t* target, uint32_t nstreams, uint32_t seg, uint32_t cap_last, int fits) {
+__device__ static void cz_huf_streams_par(cz_gcptr blk, cz_gptr target, uint32_t nstreams, uint32_t seg, uint32_t cap_last, int fits) {
     CzBroadcast& bc = sh.bc;
     const uint32_t mb = cz_uni(sh.huf_max_bits);
     const uint32_t k = nstreams == 4 ? (uint32_t)LANE >> 4 : 0, i = (uint32_t)LANE & 15;   /* stream, range */
@@ -662,9 +684,9 @@ __device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint
     CZ_PROF_DECL; CZ_PROF_T0();
     const int32_t CK_NONE = (int32_t)0x80000000;
     int32_t ck[4] = { CK_NONE, CK_NONE, CK_NONE, CK_NONE };            /* positions the speculative pass went through */
-    n = cz_gb_decode(sh, g, mb, stop, live, nullptr, 0, ck);           /* 1. speculative pass */
+    n = cz_gb_decode(g, mb, stop, live, nullptr, 0, ck);           /* 1. speculative pass */
     if (live) e = g.p;
-    CZ_PROF_ACC(sh, CZ_P_HUF_SPEC);
+    CZ_PROF_ACC(CZ_P_HUF_SPEC);
     /* 2. fix the starts until nothing moves */
     for (int round = 0; round < 17; round++) {
         const int32_t pe = __shfl_up(e, 1u);
@@ -677,17 +699,17 @@ __device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint
         uint32_t nred = 0; int state = changed ? 0 : 2;                 /* 0 redoing, 1 merged into the old trajectory, 2 done */
         for (int j = 0; j < 4; j++) {
             const int try_ck = state == 0 && ck[j] != CK_NONE && ck[j] > stop;
-            nred += cz_gb_decode(sh, g, mb, try_ck ? ck[j] : stop, try_ck, nullptr, 0);
+            nred += cz_gb_decode(g, mb, try_ck ? ck[j] : stop, try_ck, nullptr, 0);
             if (try_ck) {
                 if (g.p == ck[j]) { n = nred + (n - (CZ_GB_SYMS << j)); state = 1; }   /* e stays */
                 else if (g.p <= stop) { n = nred; e = g.p; state = 2; ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE; }
             }
         }
-        nred += cz_gb_decode(sh, g, mb, stop, state == 0, nullptr, 0);
+        nred += cz_gb_decode(g, mb, stop, state == 0, nullptr, 0);
         if (state == 0) { n = nred; e = g.p; }
         if (changed) ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE;           /* counts no longer line up with the checkpoints */
     }
-    CZ_PROF_ACC(sh, CZ_P_HUF_SYNC);
+    CZ_PROF_ACC(CZ_P_HUF_SYNC);
     /* 3. output offsets (segmented scan over the 16 lanes of a stream) and the writing pass */
     uint32_t incl = live ? n : 0;
     for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(incl, (unsigned)d); if ((int)i >= d) incl += t; }
@@ -696,9 +718,9 @@ __device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint
     {
         g.p = s;
         const uint32_t room = off < cap ? cap - off : 0;
-        cz_gb_decode(sh, g, mb, stop, live, target + (uint64_t)k * seg + off, room);
+        cz_gb_decode(g, mb, stop, live, target + (uint64_t)k * seg + off, room);
     }
-    CZ_PROF_ACC(sh, CZ_P_HUF_WRITE);
+    CZ_PROF_ACC(CZ_P_HUF_WRITE);
     if (mine && i == 0) {
         uint32_t fl = padbad ? 1u : 0u;
         if (!padbad && e_last != 0) fl |= 2u;                           /* :234-241 */
@@ -710,13 +732,13 @@ __device__ static void cz_huf_streams_par(CzShared& sh, const uint8_t* blk, uint
 
 /* Huffman literal streams -> `target` (regen bytes).  All lanes enter; returns status
  * (uniform).  literals_section_decoder.cairo:91-178. */
-__device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared& sh, const uint8_t* blk, uint8_t* target) {
+__device__ static __attribute__((noinline)) int cz_decode_huf_literals(cz_gcptr blk, cz_gptr target) {
     CzBroadcast& bc = sh.bc;
     const uint32_t regen = cz_uni(bc.regen), streams = cz_uni(bc.nstreams);
     if (streams == 4) {
         const uint32_t seg = (regen + 3) >> 2;
         const int fits = 3 * seg <= regen;
-        cz_huf_streams_par(sh, blk, target, 4, seg, fits ? regen - 3 * seg : 0, fits);
+        cz_huf_streams_par(blk, target, 4, seg, fits ? regen - 3 * seg : 0, fits);
         const uint32_t f0 = cz_uni(bc.st_flags[0]), f1 = cz_uni(bc.st_flags[1]), f2 = cz_uni(bc.st_flags[2]), f3 = cz_uni(bc.st_flags[3]);
         const uint32_t total = cz_uni(bc.st_count[0] + bc.st_count[1] + bc.st_count[2] + bc.st_count[3]);
         __syncthreads();
@@ -733,13 +755,13 @@ __device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared&
             __syncthreads();
             if (LANE == 0) {
                 uint32_t at = 0;
-                for (int k = 0; k < 4; k++) { uint32_t c, f; cz_huf_stream(sh, blk + bc.stream_off[k], bc.stream_len[k], target + at, regen - at, &c, &f); at += c; }
+                for (int k = 0; k < 4; k++) { uint32_t c, f; cz_huf_stream(blk + bc.stream_off[k], bc.stream_len[k], target + at, regen - at, &c, &f); at += c; }
             }
             __syncthreads();
         }
         return 0;
     }
-    cz_huf_streams_par(sh, blk, target, 1, 0, regen, 1);               /* :118-170, no end-of-stream test */
+    cz_huf_streams_par(blk, target, 1, 0, regen, 1);               /* :118-170, no end-of-stream test */
     const uint32_t sf = cz_uni(bc.st_flags[0]), sc = cz_uni(bc.st_count[0]);
     __syncthreads();
     if (sf & 1u) return CZ_E_LIT_EXTRA_PADDING;
@@ -750,7 +772,7 @@ __device__ static __attribute__((noinline)) int cz_decode_huf_literals(CzShared&
 /* ------------------------------------------------------------------ sequences */
 /* maybe_update_fse_tables, serial part (sequence_section_decoder.cairo:405-647): modes,
  * RLE bytes, probability descriptions.  Lane 0.  Sets build_mask / nprobs / acc_log. */
-__device__ static __attribute__((noinline)) int cz_parse_seq_tables(CzShared& sh, const uint8_t* blk, uint32_t bsize, uint32_t stage_lo, uint32_t stage_hi) {
+__device__ static __attribute__((noinline)) int cz_parse_seq_tables(cz_gcptr blk, uint32_t bsize, uint32_t stage_lo, uint32_t stage_hi) {
     CzBroadcast& bc = sh.bc;
     uint32_t off = bc.seq_body_off;
     bc.build_mask = 0;
@@ -803,7 +825,7 @@ __device__ static inline uint32_t cz_offset_history(uint32_t ov, uint32_t ll, ui
 }
 
 struct CzExecCtx {
-    uint8_t* out;            /* frame output base */
+    cz_gptr out;             /* frame output base */
     uint64_t cap;            /* capacity of the frame output */
     uint64_t produced;       /* bytes already produced in this frame (total_output_counter) */
     uint64_t drained;        /* bytes drained by the host (buffer.len = produced - drained) */
@@ -811,27 +833,59 @@ struct CzExecCtx {
     uint32_t lit_used;
 };
 
-/* execute up to 64 decoded sequences, one per lane (ll, ml, off = resolved offset).
- * sequence_execution.cairo:12-66, decode_buffer.cairo:62-133.  Returns status (uniform). */
-__device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
-    CZ_PROF_DECL; CZ_PROF_T0();
+/* Execution of up to 64 decoded sequences, one per lane (ll, ml, off = resolved offset), in two
+ * stages so that the record-driven path can plan one chunk ahead of the data movement:
+ *   cz_chunk_plan  output/literal positions by wave scans + every check of
+ *                  sequence_execution.cairo:12-66 / decode_buffer.cairo:62-133 (no memory traffic)
+ *   cz_chunk_copy  the literal and match copies. */
+struct CzPlan { uint32_t ll, ml, off, orel, lrel, sum_ll, sum_tot; int err; };   /* orel/lrel: output / literal position relative to the chunk start */
+__device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produced, uint32_t lit_used, const CzLit& lit, uint32_t cnt,
+                                              uint32_t ll, uint32_t ml, uint32_t off) {
     const int active = (uint32_t)LANE < cnt;
     if (!active) { ll = 0; ml = 0; off = 1; }
     const uint32_t incl_ll = cz_wave_incl_scan(ll), tot = ll + ml, incl_tot = cz_wave_incl_scan(tot);
-    const uint32_t sum_ll = cz_readlane(incl_ll, 63), sum_tot = cz_readlane(incl_tot, 63);
-    const uint32_t lit_start = x.lit_used + (incl_ll - ll);
-    const uint64_t out_start = x.produced + (uint64_t)(incl_tot - tot);
-    const uint64_t dst = out_start + ll;                                /* where the match goes */
+    CzPlan p; p.ll = ll; p.ml = ml; p.off = off; p.orel = incl_tot - tot; p.lrel = incl_ll - ll;
+    p.sum_ll = cz_readlane(incl_ll, 63); p.sum_tot = cz_readlane(incl_tot, 63);
+    const uint64_t dst = produced + p.orel + ll;                        /* where the match goes */
     int e = 0;
     if (active) {
-        if (ll > 0 && (uint64_t)lit_start + ll > lit.len) e = CZ_E_EXEC_NOT_ENOUGH_LITERALS;        /* :28-36 */
+        if (ll > 0 && (uint64_t)lit_used + p.lrel + ll > lit.len) e = CZ_E_EXEC_NOT_ENOUGH_LITERALS;   /* :28-36 */
         else if (off == 0) e = CZ_E_EXEC_ZERO_OFFSET;                                               /* :47 */
         else if (ml > 0 && (uint64_t)off > dst - x.drained)                                         /* decode_buffer.cairo:65 */
             e = (dst <= x.window) ? CZ_E_EXEC_NOT_ENOUGH_DICT : CZ_E_EXEC_OFFSET_TOO_BIG;           /* :66-75 / :92 */
         else if (dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
     }
     const unsigned long long emask = __ballot(e != 0);
-    if (emask) { const int first = __ffsll((long long)emask) - 1; return cz_unii(__shfl(e, first)); }
+    p.err = 0;
+    if (emask) { const int first = __ffsll((long long)emask) - 1; p.err = cz_unii(__shfl(e, first)); }
+    return p;
+}
+/* Touches the cache lines cz_chunk_copy will read for a planned chunk that starts at output position
+ * `produced` / literal position `lit_used`: the chunk is copied one loop iteration later, so its loads
+ * then find the lines in L2 instead of paying the HBM round trip inside the dependent part of the loop.
+ * The loaded bytes are returned and must be consumed by the caller AFTER that copy (a plain load whose
+ * first use is late: the compiler waits for it there, not here). */
+struct CzWarm { uint8_t a, b, c; };
+__device__ static inline CzWarm cz_chunk_warm(const CzExecCtx& x, uint64_t produced, uint32_t lit_used, const CzLit& lit, const CzPlan& p) {
+    CzWarm w; w.a = w.b = w.c = 0;
+    if (p.err) return w;
+    if (p.ml > 0 && (uint64_t)p.off <= produced + p.orel + p.ll - x.drained) {
+        const uint8_t* s = x.out + (produced + p.orel + p.ll - p.off);
+        const uint32_t span = p.off < p.ml ? p.off : p.ml;
+        w.a = s[0]; w.b = s[span - 1];
+    }
+    if (!lit.rle && 64u * (uint32_t)LANE < p.sum_ll + 64u && (uint64_t)lit_used + 64u * (uint32_t)LANE < lit.len)
+        w.c = lit.p[lit_used + 64u * (uint32_t)LANE];
+    return w;
+}
+__device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan& p) {
+    CZ_PROF_DECL; CZ_PROF_T0();
+    const uint32_t ll = p.ll, ml = p.ml, off = p.off, tot = ll + ml, incl_tot = p.orel + tot;
+    const uint32_t sum_ll = p.sum_ll, sum_tot = p.sum_tot;
+    const int active = tot > 0;
+    const uint32_t lit_start = x.lit_used + p.lrel;
+    const uint64_t out_start = x.produced + (uint64_t)p.orel;
+    const uint64_t dst = out_start + ll;                                /* where the match goes */
 
     /* Fast path for chunks of short sequences: the chunk's output is assembled in LDS and written out
      * with coalesced stores.  Literal bytes and match bytes whose source lies before the chunk are
@@ -842,49 +896,39 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
         uint8_t* ob = sh.a.t4.obuf;
         const uint32_t orel = incl_tot - tot, drel = orel + ll;
         uint8_t* const cout = x.out + x.produced;                       /* chunk output base */
-        if (ll > 0) {
-            if (lit.rle) { for (uint32_t k = 0; k < ll; k++) ob[orel + k] = lit.byte; }
-            else {
-                const uint8_t* s = lit.p + lit_start;
-                for (uint32_t k = 0; k < ll; k += 8) {
-                    const uint32_t n = ll - k; uint8_t t[8];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) if (j < n) t[j] = s[k + j];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; j++) if (j < n) ob[orel + k + j] = t[j];
-                }
-            }
-        }
         /* source range relative to the chunk base: [srel, srel + span) with span = min(off, ml) */
         const int32_t srel = (int32_t)drel - (int32_t)(off < 0x40000000u ? off : 0x40000000u);
         const uint32_t span = off < ml ? off : ml;
-        int near = 0;
-        if (ml > 0) {
-            if (srel + (int32_t)span <= 0) {                            /* every source byte precedes the chunk */
-                const uint8_t* s = cout + (drel - (uint64_t)off);
-                if (off >= ml) {
-                    /* no overlap: 4-byte loads; the over-read stays below dst + 3 <= cap */
-                    for (uint32_t k = 0; k < ml; k += 16) {
-                        const uint32_t n = ml - k; uint32_t w[4];
+        const int far = ml > 0 && srel + (int32_t)span <= 0;            /* every source byte precedes the chunk */
+        const int near = ml > 0 && !far;
+        const int far_plain = far && off >= ml, far_period = far && off < ml;
+        const uint8_t* ls = lit.p + lit_start;
+        const uint8_t* ms = cout + (drel - (uint64_t)off);
+        /* first group of every lane: all loads, then all LDS writes */
+        {
+            uint8_t lt[8], mt[8]; uint32_t mw[4]; uint32_t idx = 0;
+            const int lg = ll > 0 && !lit.rle;
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) if (4 * j < n) __builtin_memcpy(&w[j], s + k + 4 * j, 4);
+            for (uint32_t j = 0; j < 8; j++) if (lg && j < ll) lt[j] = ls[j];
+            /* no overlap: 4-byte loads; the over-read stays below dst + 3 <= dst + ml <= cap */
 #pragma unroll
-                        for (uint32_t j = 0; j < 16; j++) if (j < n) ob[drel + k + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-                    }
-                } else {
-                    uint32_t idx = 0;                                   /* period-off pattern (decode_buffer.cairo:101-120) */
-                    for (uint32_t k = 0; k < ml; k += 8) {
-                        const uint32_t n = ml - k; uint8_t t[8];
+            for (uint32_t j = 0; j < 4; j++) if (far_plain && 4 * j < ml) __builtin_memcpy(&mw[j], ms + 4 * j, 4);
+            /* period-off pattern (decode_buffer.cairo:101-120) */
 #pragma unroll
-                        for (uint32_t j = 0; j < 8; j++) if (j < n) { t[j] = s[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
+            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) { mt[j] = ms[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
 #pragma unroll
-                        for (uint32_t j = 0; j < 8; j++) if (j < n) ob[drel + k + j] = t[j];
-                    }
-                }
-            } else near = 1;
+            for (uint32_t j = 0; j < 8; j++) if (j < ll) ob[orel + j] = lit.rle ? lit.byte : lt[j];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) if (far_plain && j < ml) ob[drel + j] = (uint8_t)(mw[j >> 2] >> (8 * (j & 3)));
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) ob[drel + j] = mt[j];
+            /* the rest of long runs (rare in a chunk this small) */
+            for (uint32_t k = 8; k < ll; k++) ob[orel + k] = lit.rle ? lit.byte : ls[k];
+            if (far_plain) for (uint32_t k = 16; k < ml; k++) ob[drel + k] = ms[k];
+            if (far_period) for (uint32_t k = 8; k < ml; k++) { ob[drel + k] = ms[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
         }
-        __syncthreads();
-        CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+        cz_wave_sync();
+        CZ_PROF_ACC(CZ_P_LITCOPY);
         /* matches that read this chunk's output: rounds.  W = destination of the first undone match;
            a match may go once its source range (clipped to its own destination) lies below W. */
         int done = !near;
@@ -893,7 +937,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
             const unsigned long long pend = __ballot(!done);
             if (!pend) break;
             const int f = __ffsll((long long)pend) - 1;
-            const int32_t W = (int32_t)__shfl(drel, f);
+            const int32_t W = (int32_t)cz_readlane(drel, cz_unii(f));
             if (!done && send <= W) {
                 uint32_t idx = 0;
                 for (uint32_t k = 0; k < ml; k++) {
@@ -903,15 +947,16 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
                 }
                 done = 1;
             }
-            __syncthreads();
+            cz_wave_sync();
         }
-        /* write the assembled chunk: 4 bytes per lane per pass (the global address need not be aligned) */
+        /* write the assembled chunk: 4 bytes per lane per pass (the global address need not be aligned).
+           Later loads of these bytes by this wave are ordered behind the stores by the memory pipeline. */
         for (uint32_t i = 4u * (uint32_t)LANE; i < sum_tot; i += 256) {
             if (i + 4 <= sum_tot) { uint32_t w = *(const uint32_t*)(ob + i); __builtin_memcpy(cout + i, &w, 4); }
             else for (uint32_t j = i; j < sum_tot; j++) cout[j] = ob[j];
         }
-        __syncthreads();
-        CZ_PROF_ACC(sh, CZ_P_MATCH);
+        cz_wave_sync();
+        CZ_PROF_ACC(CZ_P_MATCH);
         x.produced += sum_tot; x.lit_used += sum_ll;
         return 0;
     }
@@ -931,7 +976,7 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
         cz_lit_coop_copy(x.out + os, lit, ls, n);
     }
     __syncthreads();
-    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+    CZ_PROF_ACC(CZ_P_LITCOPY);
 
     /* matches: dependency rounds.  W = first byte not yet guaranteed written = match
        destination of the first undone sequence; a sequence may go once its source range
@@ -969,9 +1014,15 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
         if (ready) done = 1;
         __syncthreads();
     }
-    CZ_PROF_ACC(sh, CZ_P_MATCH);
+    CZ_PROF_ACC(CZ_P_MATCH);
     x.produced += sum_tot; x.lit_used += sum_ll;
     return 0;
+}
+
+__device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
+    const CzPlan p = cz_chunk_plan(x, x.produced, x.lit_used, lit, cnt, ll, ml, off);
+    if (p.err) return p.err;
+    return cz_chunk_copy(x, lit, p);
 }
 
 /* ---- sequences bitstream ring (LDS) ------------------------------------------------------
@@ -979,13 +1030,13 @@ __device__ static int cz_execute_chunk(CzShared& sh, CzExecCtx& x, const CzLit& 
  * ABSOLUTE address (ring[a & 2047]) so that global and LDS accesses are both 16-byte aligned.
  * Bytes outside [S, E) are written as zero, which is exactly the reference reader's
  * zero-extension below bit 0 (bit_reader_reverse.cairo:147-159). */
-__device__ static void cz_ring_load_block(CzShared& sh, const uint8_t* S, const uint8_t* E, uintptr_t block) {
+__device__ static void cz_ring_load_block(const uint8_t* S, const uint8_t* E, uintptr_t block) {
     const uintptr_t a = block + 16u * (uintptr_t)LANE;
     uint4 v;
-    if (a >= (uintptr_t)S && a + 16 <= (uintptr_t)E) v = *(const uint4*)a;
+    if (a >= (uintptr_t)S && a + 16 <= (uintptr_t)E) v = *(CZ_GLOBAL const uint4*)a;
     else {
         uint32_t w[4] = {0, 0, 0, 0};
-        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= (uintptr_t)S && q < (uintptr_t)E) w[b >> 2] |= (uint32_t)(*(const uint8_t*)q) << (8 * (b & 3)); }
+        for (uint32_t b = 0; b < 16; b++) { const uintptr_t q = a + b; if (q >= (uintptr_t)S && q < (uintptr_t)E) w[b >> 2] |= (uint32_t)(*(cz_gcptr)q) << (8 * (b & 3)); }
         v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     }
     const uint32_t slot = (uint32_t)(a & (CZ_RING_BYTES - 1));
@@ -993,7 +1044,7 @@ __device__ static void cz_ring_load_block(CzShared& sh, const uint8_t* S, const 
     if (slot == CZ_RING_BYTES - 16) { *(uint32_t*)&sh.a.t4.mirror[8] = v.z; *(uint32_t*)&sh.a.t4.mirror[12] = v.w; }
 }
 /* 64 stream bits whose most significant bit is stream bit t (t >= 0); lower bits follow */
-__device__ static inline uint64_t cz_ring_window(const CzShared& sh, uint32_t sbits, int32_t t) {
+__device__ static inline uint64_t cz_ring_window(uint32_t sbits, int32_t t) {
     const uint32_t g = sbits + (uint32_t)t, wi = g >> 5, r = (g & 31) + 1;
     const uint32_t* rw = (const uint32_t*)sh.a.t4.ring;
     const uint32_t M = CZ_RING_BYTES / 4 - 1;
@@ -1028,11 +1079,9 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
 }
 
 /* Resolves the repeat offsets of up to 64 sequences (one per lane) with a wave scan over
- * history transforms, advances the uniform history (h0,h1,h2) and executes the chunk. */
-__device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t ov,
-                                             uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+ * history transforms and advances the uniform history (h0,h1,h2); returns the lane's actual offset. */
+__device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
-    CZ_PROF_DECL; CZ_PROF_T0();
     /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
     CzHist T; T.s = CZ_HIST_ID; T.v0 = T.v1 = T.v2 = 0;                            /* identity */
     if (active) {
@@ -1064,8 +1113,14 @@ __device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const C
     const uint32_t ts = cz_readlane(T.s, lastl), t0 = cz_readlane(T.v0, lastl), t1 = cz_readlane(T.v1, lastl), t2 = cz_readlane(T.v2, lastl);
     const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
     h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
-    CZ_PROF_ACC(sh, CZ_P_EXTRACT);
-    return cz_execute_chunk(sh, x, lit, cnt, ll, ml, actual);
+    return actual;
+}
+__device__ static int cz_history_and_execute(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t ov,
+                                             uint32_t& h0, uint32_t& h1, uint32_t& h2) {
+    CZ_PROF_DECL; CZ_PROF_T0();
+    const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
+    CZ_PROF_ACC(CZ_P_EXTRACT);
+    return cz_execute_chunk(x, lit, cnt, ll, ml, actual);
 }
 
 /* decode_sequences + execute_sequences for one block.  All lanes.
@@ -1074,7 +1129,7 @@ __device__ static int cz_history_and_execute(CzShared& sh, CzExecCtx& x, const C
  * round trip per sequence: three table entries + the bit window) and records (bit position,
  * states) per sequence; the 64 lanes then extract the extra bits, resolve repeat offsets with
  * a wave scan over history transforms and execute their sequence. */
-__device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit) {
+__device__ static int cz_sequences(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, const CzLit& lit) {
     CzBroadcast& bc = sh.bc;
     const uint32_t nseq = cz_uni(bc.nseq);
     const uint8_t* S = blk + cz_uni(bc.bitstream_off); const uint8_t* E = blk + bsize;
@@ -1087,12 +1142,12 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     const uint32_t fOF = rOF >= 0 ? (CZ_FSE_PACK(rOF, 0, 0) | cz_fse_code_bits(sh.b.c.llml, 1, (uint32_t)rOF)) : 0;
     const uint32_t fML = rML >= 0 ? (CZ_FSE_PACK(rML, 0, 0) | cz_fse_code_bits(sh.b.c.llml, 2, (uint32_t)rML)) : 0;
     const int any_rle = (rLL >= 0) | (rOF >= 0) | (rML >= 0);
-    const uint32_t* TLL = sh.fse_ll; const uint32_t* TOF = sh.fse_of; const uint32_t* TML = sh.fse_ml;
+    const uint32_t* TLL = CZ_FSE_LL; const uint32_t* TOF = CZ_FSE_OF; const uint32_t* TML = CZ_FSE_ML;
     /* stage the top two 1 KiB blocks of the stream */
     uintptr_t loaded_lo;
     {
         const uintptr_t top = (((uintptr_t)E - (E > S ? 1 : 0)) & ~(uintptr_t)(CZ_RING_BLOCK - 1));
-        cz_ring_load_block(sh, S, E, top); cz_ring_load_block(sh, S, E, top - CZ_RING_BLOCK);
+        cz_ring_load_block(S, E, top); cz_ring_load_block(S, E, top - CZ_RING_BLOCK);
         loaded_lo = top - CZ_RING_BLOCK;
     }
     __syncthreads();
@@ -1101,7 +1156,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
     if (LANE == 0) {
         int e = 0, skipped = 0;
         for (;;) {                                                      /* padding :46-64 */
-            const uint32_t b = pos > 0 ? cz_field(cz_ring_window(sh, sbits, pos - 1), 0, 1) : 0; pos -= 1; skipped++;
+            const uint32_t b = pos > 0 ? cz_field(cz_ring_window(sbits, pos - 1), 0, 1) : 0; pos -= 1; skipped++;
             if (b == 1 || skipped > 8) break;
         }
         if (skipped > 8) e = CZ_E_SEQ_EXTRA_PADDING;
@@ -1111,14 +1166,14 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         for (int t = 0; t < 3 && !e; t++) {
             if (rl[t] >= 0) continue;
             if (!logs[t]) { e = CZ_E_SEQ_TABLE_UNINIT; break; }
-            stv[t] = pos > 0 ? cz_field(cz_ring_window(sh, sbits, pos - 1), 0, logs[t]) : 0; pos -= (int32_t)logs[t];
+            stv[t] = pos > 0 ? cz_field(cz_ring_window(sbits, pos - 1), 0, logs[t]) : 0; pos -= (int32_t)logs[t];
         }
         sLL = stv[0]; sOF = stv[1]; sML = stv[2];
         bc.chunk_err = e;
     }
     __syncthreads();
     { const int e = cz_unii(bc.chunk_err); __syncthreads(); if (e) return e; }
-    CZ_PROF_ACC(sh, CZ_P_RING);
+    CZ_PROF_ACC(CZ_P_RING);
     int exec_err = 0;                                                   /* first execution error, reported only if the
                                                                            rest of the section decodes (reference order) */
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);   /* uniform copy in every lane */
@@ -1130,11 +1185,11 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             const intptr_t cur = (intptr_t)S + ((p0 > 0 ? p0 - 1 : 0) >> 3);
             if (cur - (intptr_t)CZ_RING_NEED < (intptr_t)loaded_lo) {
                 loaded_lo -= CZ_RING_BLOCK;
-                cz_ring_load_block(sh, S, E, loaded_lo);
+                cz_ring_load_block(S, E, loaded_lo);
                 __syncthreads();
             }
         }
-        CZ_PROF_ACC(sh, CZ_P_RING);
+        CZ_PROF_ACC(CZ_P_RING);
         if (LANE == 0) {
             /* Fast pass: straight-line, no per-sequence branches; any invalid code or overrun only
                sets a flag, and the chunk is then redone by the careful loop below, which finds the
@@ -1182,7 +1237,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             pos = pos_save; sLL = sLL_save; sOF = sOF_save; sML = sML_save;
             int e = 0;
             for (uint32_t i = 0; i < cnt; i++) {                        /* :223-286, serial core (careful) */
-                const uint64_t W = pos > 0 ? cz_ring_window(sh, sbits, pos - 1) : 0;
+                const uint64_t W = pos > 0 ? cz_ring_window(sbits, pos - 1) : 0;
                 const uint32_t eLL = rLL >= 0 ? fLL : TLL[sLL], eOF = rOF >= 0 ? fOF : TOF[sOF], eML = rML >= 0 ? fML : TML[sML];
                 sh.a.t4.rec_pos[i] = pos; sh.a.t4.rec_st[i] = sLL | (sOF << 9) | (sML << 18);
                 if (CZ_FSE_INV(eOF)) { e = CZ_E_SEQ_UNSUPPORTED_OFFSET; break; }          /* :235 */
@@ -1191,7 +1246,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
                 if (done + i + 1 < nseq) {                              /* :258-277 state updates, order LL, ML, OF */
                     const uint32_t nl = CZ_FSE_NB(eLL), nm = CZ_FSE_NB(eML), no = CZ_FSE_NB(eOF), tot = a + nl + nm + no;
                     uint64_t V = W; uint32_t o = a;
-                    if (tot > 64) { V = pos - (int32_t)a > 0 ? cz_ring_window(sh, sbits, pos - (int32_t)a - 1) : 0; o = 0; }
+                    if (tot > 64) { V = pos - (int32_t)a > 0 ? cz_ring_window(sbits, pos - (int32_t)a - 1) : 0; o = 0; }
                     sLL = CZ_FSE_BASE(eLL) + cz_field(V, o, nl);
                     sML = CZ_FSE_BASE(eML) + cz_field(V, o + nl, nm);
                     sOF = CZ_FSE_BASE(eOF) + cz_field(V, o + nl + nm, no);
@@ -1205,7 +1260,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         }
         __syncthreads();
         { const int e = cz_unii(bc.chunk_err); __syncthreads(); if (e) return e; }
-        CZ_PROF_ACC(sh, CZ_P_CHAIN);
+        CZ_PROF_ACC(CZ_P_CHAIN);
         if (!exec_err) {
             /* every lane finishes its own sequence: extra bits -> (ll, ml, offset_value) */
             uint32_t ll = 0, ml = 0, ov = 4;
@@ -1213,14 +1268,14 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
             if (active) {
                 const int32_t p = sh.a.t4.rec_pos[LANE]; const uint32_t st = sh.a.t4.rec_st[LANE];
                 const uint32_t eLL = rLL >= 0 ? fLL : TLL[st & 511], eOF = rOF >= 0 ? fOF : TOF[(st >> 9) & 511], eML = rML >= 0 ? fML : TML[(st >> 18) & 511];
-                const uint64_t W = p > 0 ? cz_ring_window(sh, sbits, p - 1) : 0;
+                const uint64_t W = p > 0 ? cz_ring_window(sbits, p - 1) : 0;
                 const uint32_t oc = CZ_FSE_XB(eOF), mx = CZ_FSE_XB(eML), lx = CZ_FSE_XB(eLL);
                 const uint32_t tl = sh.b.c.llml[CZ_FSE_SYM(eLL)], tm = sh.b.c.llml[40 + CZ_FSE_SYM(eML)];
                 ov = (1u << oc) + cz_field(W, 0, oc);                   /* :243 */
                 ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);            /* :249-256 */
                 ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
             }
-            exec_err = cz_history_and_execute(sh, x, lit, cnt, ll, ml, ov, h0, h1, h2);
+            exec_err = cz_history_and_execute(x, lit, cnt, ll, ml, ov, h0, h1, h2);
             CZ_PROF_T0();
         }
         __syncthreads();
@@ -1235,7 +1290,7 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
         x.produced += rest;
     }
     __syncthreads();
-    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+    CZ_PROF_ACC(CZ_P_LITCOPY);
     return 0;
 }
 
@@ -1246,25 +1301,27 @@ __device__ static int cz_sequences(CzShared& sh, const uint8_t* blk, uint32_t bs
  * and ML tables.  This pass needs neither decoding tables nor the bitstream, only the maps (kept in
  * the LDS that holds the FSE tables otherwise; they persist over Repeat-mode blocks). */
 #define CZ_CHAIN_MAP_WORDS 128u
-__device__ static int cz_sequences_rec(CzShared& sh, CzExecCtx& x, const CzLit& lit, const uint64_t* maps, const uint64_t* rec,
-                                       uint32_t nseq, uint32_t mapflags) {
-    uint8_t* mapll = (uint8_t*)sh.fse_ll; uint8_t* mapml = mapll + 512;
+__device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& lit, cz_gcptr64 maps, cz_gcptr64 rec,
+                                                   uint32_t nseq, uint32_t mapflags) {
+    uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapml = mapll + 512;
     CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
     {
         const uint32_t half = (uint32_t)LANE >> 5, j = (uint32_t)LANE & 31;           /* 32 lanes x 16 B per map */
-        if ((mapflags >> (half ? 2 : 0)) & 1u) { uint4 v; __builtin_memcpy(&v, (const uint8_t*)maps + 512u * half + 16u * j, 16); *(uint4*)(mapll + 512u * half + 16u * j) = v; }
+        if ((mapflags >> (half ? 2 : 0)) & 1u) { uint4 v; __builtin_memcpy(&v, (cz_gcptr)maps + 512u * half + 16u * j, 16); *(uint4*)(mapll + 512u * half + 16u * j) = v; }
     }
     __syncthreads();
     int exec_err = 0;
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
-    CZ_PROF_ACC(sh, CZ_P_RING);
-    for (uint32_t done = 0; done < nseq; done += 64) {
-        const uint32_t cnt = nseq - done < 64 ? nseq - done : 64;
-        const int active = (uint32_t)LANE < cnt;
-        const uint64_t r = active ? rec[done + (uint32_t)LANE] : 0;     /* coalesced 8-byte loads */
+    CZ_PROF_ACC(CZ_P_RING);
+    /* Software pipeline over chunks of 64 sequences: records are loaded two chunks ahead; a chunk is
+     * PLANNED (codes -> values, repeat offsets, positions, every check) and its source cache lines are
+     * touched one iteration before its bytes are COPIED, so the copy's loads hit L2. */
+    auto load_rec = [&](uint32_t first) -> uint64_t { return first + (uint32_t)LANE < nseq ? rec[first + (uint32_t)LANE] : 0; };   /* coalesced 8-byte loads */
+    auto plan = [&](uint64_t r, uint32_t first, uint64_t produced, uint32_t lit_used) -> CzPlan {
+        const uint32_t cnt = nseq - first < 64 ? nseq - first : 64;
         uint32_t ll = 0, ml = 0, ov = 4;
-        if (active) {
+        if ((uint32_t)LANE < cnt) {
             const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
             const uint32_t oc = (st >> 18) & 31;
             const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
@@ -1273,11 +1330,34 @@ __device__ static int cz_sequences_rec(CzShared& sh, CzExecCtx& x, const CzLit& 
             ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);         /* :249-256 */
             ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
         }
-        exec_err = cz_history_and_execute(sh, x, lit, cnt, ll, ml, ov, h0, h1, h2);
+        const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
+        return cz_chunk_plan(x, produced, lit_used, lit, cnt, ll, ml, actual);
+    };
+    uint64_t r1 = load_rec(0), r2 = load_rec(64);
+    CzPlan cur = plan(r1, 0, x.produced, x.lit_used);
+    r1 = r2; r2 = load_rec(128);
+    CZ_PROF_ACC(CZ_P_EXTRACT);
+    CzWarm warm; warm.a = warm.b = warm.c = 0; uint32_t sink = 0;
+    for (uint32_t done = 0; done < nseq; done += 64) {
+        if (cur.err) return cur.err;
+        CzPlan nxt; nxt.err = 0;
+        const int more = done + 64 < nseq;
+        const CzWarm warmed = warm;                                     /* issued one iteration ago, for `cur` */
+        if (more) {
+            const uint64_t produced = x.produced + cur.sum_tot; const uint32_t lit_used = x.lit_used + cur.sum_ll;
+            nxt = plan(r1, done + 64, produced, lit_used);
+            warm = cz_chunk_warm(x, produced, lit_used, lit, nxt);
+            r1 = r2; r2 = load_rec(done + 192);
+        }
+        CZ_PROF_ACC(CZ_P_EXTRACT);
+        exec_err = cz_chunk_copy(x, lit, cur);
         CZ_PROF_T0();
         if (exec_err) return exec_err;
-        __syncthreads();
+        sink |= (uint32_t)warmed.a | (uint32_t)warmed.b | (uint32_t)warmed.c;
+        cz_wave_sync();
+        if (more) cur = nxt;
     }
+    if (sink == 0xFFFFFFFFu && nseq == 0xFFFFFFFFu) sh.bc.detail = sink;   /* keeps the warming loads alive; never true (nseq < 2^17) */
     if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
     if (x.lit_used < lit.len) {                                         /* sequence_execution.cairo:72-78 */
         const uint32_t rest = lit.len - x.lit_used;
@@ -1286,33 +1366,45 @@ __device__ static int cz_sequences_rec(CzShared& sh, CzExecCtx& x, const CzLit& 
         x.produced += rest;
     }
     __syncthreads();
-    CZ_PROF_ACC(sh, CZ_P_LITCOPY);
+    CZ_PROF_ACC(CZ_P_LITCOPY);
     return 0;
+}
+
+/* Not inlined: the chunk loop gets the whole register budget to itself.  The execution context is
+ * worked on in registers (wave-uniform) and written back once. */
+__device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec,
+                                                                 uint32_t nseq, uint32_t mapflags) {
+    CzExecCtx x = xref;
+    x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
+    x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
+    const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags);
+    xref.produced = x.produced; xref.lit_used = x.lit_used;
+    return e;
 }
 
 /* ------------------------------------------------------------------ one compressed block */
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
-__device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint32_t bsize, CzExecCtx& x, uint8_t* lit_scratch,
-                                           uint16_t* huf_global, int last_block, const uint64_t* arena, uint64_t& chain_cursor) {
+__device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, cz_gptr lit_scratch,
+                                           cz_gptr16 huf_global, int last_block, cz_gcptr64 arena, uint64_t& chain_cursor) {
     CzBroadcast& bc = sh.bc;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
     const uint32_t stage_hi = bsize < 512 ? bsize : 512;
     for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.a.t1.stage[i] = blk[i];
     __syncthreads();
-    if (LANE == 0) bc.err = cz_parse_sections(sh, blk, bsize, stage_hi);
+    if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi);
     __syncthreads();
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
     if (bc.huf_fill) {
-        cz_huf_fill(sh, bc.huf_nsym); __syncthreads();
+        cz_huf_fill(bc.huf_nsym); __syncthreads();
         if (!last_block) {                                              /* carried for later Treeless blocks */
-            for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)huf_global)[i] = ((const uint32_t*)sh.a.huf)[i];
+            for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)huf_global)[i] = ((const uint32_t*)sh.a.huf)[i];
         }
     } else if (bc.lit_type == 3) {                                      /* Treeless: bring the carried table back */
-        for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)sh.a.huf)[i] = ((const uint32_t*)huf_global)[i];
+        for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)sh.a.huf)[i] = ((CZ_GLOBAL const uint32_t*)huf_global)[i];
         __syncthreads();
     }
-    CZ_PROF_ACC(sh, CZ_P_HUFBUILD);
+    CZ_PROF_ACC(CZ_P_HUFBUILD);
     /* literals */
     const uint32_t regen = cz_uni(bc.regen), lit_total = cz_uni(bc.lit_total), nseq = cz_uni(bc.nseq);
     const int seq_hdr_err = cz_unii(bc.seq_hdr_err);
@@ -1321,17 +1413,17 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     if (lt == 0) { lit.p = blk + (lit_total - regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
     else if (lt == 1) { lit.rle = 1; lit.byte = blk[lit_total - 1]; } /* RLE :43-46 */
     else {
-        uint8_t* target = lit_scratch;
+        cz_gptr target = lit_scratch;
         if (nseq_early == 0) {                                          /* no sequences: decode straight into the output */
             if (x.produced + regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
             target = x.out + x.produced;
         } else if (regen > CZ_LIT_SCRATCH_BYTES) return CZ_E_UNSUPPORTED;
-        const int e = cz_decode_huf_literals(sh, blk, target);
+        const int e = cz_decode_huf_literals(blk, target);
         if (e) return e;
         lit.p = target;
         __syncthreads();
     }
-    CZ_PROF_ACC(sh, CZ_P_HUFDEC);
+    CZ_PROF_ACC(CZ_P_HUFDEC);
     if (seq_hdr_err) return seq_hdr_err;                                /* block_decoder.cairo:198-204 */
     if (nseq == 0) {                                                 /* :229-232 */
         if (lt < 2) {
@@ -1345,14 +1437,14 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     if (chain_cursor) {
         /* cz_chain_kernel already ran this block's FSE chain: header = {nseq|map flags, bitstream_off, next}, code maps, records */
         const uint64_t w0 = arena[chain_cursor], w2 = arena[chain_cursor + 2];
-        const uint64_t* maps = arena + chain_cursor + 4;
-        const uint64_t* rec = maps + CZ_CHAIN_MAP_WORDS;
+        cz_gcptr64 maps = arena + chain_cursor + 4;
+        cz_gcptr64 rec = maps + CZ_CHAIN_MAP_WORDS;
         chain_cursor = cz_uni64(w2);
         const uint32_t rn = cz_uni((uint32_t)(w0 >> 32)), mapflags = cz_uni((uint32_t)w0);
         if (rn != nseq) return CZ_E_INVALID_ARG;                        /* cannot happen: both passes walk the same bytes */
         x.lit_used = 0;
-        CZ_PROF_ACC(sh, CZ_P_SEQTAB);
-        return cz_sequences_rec(sh, x, lit, maps, rec, nseq, mapflags);
+        CZ_PROF_ACC(CZ_P_SEQTAB);
+        return cz_sequences_rec(x, lit, maps, rec, nseq, mapflags);
     }
     /* sequence tables */
     const uint32_t so = cz_uni(bc.seq_body_off);
@@ -1361,17 +1453,17 @@ __device__ static int cz_decompress_block(CzShared& sh, const uint8_t* blk, uint
     const uint32_t st_lo = so < bsize ? so : bsize, st_hi = bsize - st_lo < 512 ? bsize : st_lo + 512;
     for (uint32_t i = st_lo + (uint32_t)LANE; i < st_hi; i += 64) sh.a.t3.stage[i - st_lo] = blk[i];
     __syncthreads();
-    if (LANE == 0) bc.err = cz_parse_seq_tables(sh, blk, bsize, st_lo, st_hi);
+    if (LANE == 0) bc.err = cz_parse_seq_tables(blk, bsize, st_lo, st_hi);
     __syncthreads();
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }
     if (LANE < 3 && ((bc.build_mask >> LANE) & 1u)) {
-        cz_fse_build(cz_fse_table(sh, LANE), sh.a.t3.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.a.t3.counters[LANE], sh.b.c.llml, (uint32_t)LANE);
+        cz_fse_build(cz_fse_table(LANE), sh.a.t3.probs[LANE], bc.nprobs[LANE], bc.acc_log[LANE], sh.a.t3.counters[LANE], sh.b.c.llml, (uint32_t)LANE);
         sh.fse_log[LANE] = (uint8_t)bc.acc_log[LANE];
     }
     __syncthreads();
     x.lit_used = 0;
-    CZ_PROF_ACC(sh, CZ_P_SEQTAB);
-    return cz_sequences(sh, blk, bsize, x, lit);
+    CZ_PROF_ACC(CZ_P_SEQTAB);
+    return cz_sequences(blk, bsize, x, lit);
 }
 
 /* ------------------------------------------------------------------ XXH64 content checksum */
@@ -1390,7 +1482,7 @@ __device__ static inline uint64_t cz_xxh_round(uint64_t acc, uint64_t in) { acc 
 __device__ static inline uint64_t cz_xxh_merge(uint64_t h, uint64_t v) { v = cz_xxh_round(0, v); h ^= v; return h * CZ_XP1 + CZ_XP4; }
 __device__ static inline uint64_t cz_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 /* all lanes; returns the digest in every lane */
-__device__ static uint64_t cz_xxh64_frame(CzShared& sh, const uint8_t* p, uint64_t len) {
+__device__ static uint64_t cz_xxh64_frame(const uint8_t* p, uint64_t len) {
     uint64_t* stage = (uint64_t*)sh.a.huf;                              /* 2 x 512 B of the (now idle) phase region */
     uint64_t acc = LANE == 0 ? CZ_XP1 + CZ_XP2 : (LANE == 1 ? CZ_XP2 : (LANE == 2 ? 0ull : 0ull - CZ_XP1));
     const uint64_t nblk = len >> 9;                                     /* full 512-byte blocks */
@@ -1427,16 +1519,16 @@ __device__ static uint64_t cz_xxh64_frame(CzShared& sh, const uint8_t* p, uint64
 
 /* ------------------------------------------------------------------ one frame */
 struct CzFrameIO {
-    const uint8_t* src; uint64_t src_len;
-    uint8_t* dst; uint64_t dst_cap;
+    cz_gcptr src; uint64_t src_len;
+    cz_gptr dst; uint64_t dst_cap;
     uint64_t produced, drained, window;
     uint32_t parse_header, has_checksum, strategy, streaming; uint64_t strategy_n;
     uint32_t verify;          /* compute XXH64 of the decoded frame and compare with the frame's checksum */
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
-__device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scratch, uint16_t* huf_global, cz_frame_result* res,
-                                    const uint64_t* arena, uint64_t chain_cursor) {
+__device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 huf_global, CZ_GLOBAL cz_frame_result* res,
+                                    cz_gcptr64 arena, uint64_t chain_cursor) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
     CZ_PROF_DECL; CZ_PROF_T0();
@@ -1482,13 +1574,13 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
             cz_coop_fill(x.out + x.produced, io.src[body], bsize);
             x.produced += bsize;
         } else {
-            CZ_PROF_ACC(sh, CZ_P_HDR);
-            err = cz_decompress_block(sh, io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor);
+            CZ_PROF_ACC(CZ_P_HDR);
+            err = cz_decompress_block(io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor);
             CZ_PROF_T0();
             if (err) break;
         }
         __syncthreads();
-        if (btype != 2) CZ_PROF_ACC(sh, CZ_P_RAWRLE);
+        if (btype != 2) CZ_PROF_ACC(CZ_P_RAWRLE);
         pos = body + content; blocks++;
         if (blast) {                                                    /* frame_decoder.cairo:189-200 / :300-312 */
             flags |= CZ_RESULT_FINISHED;
@@ -1507,7 +1599,7 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
     uint32_t calc = 0;
     if (io.verify && !err && (flags & CZ_RESULT_HAS_CHECKSUM) && io.produced == 0) {
         /* get_calculated_checksum == get_checksum_from_data (src/tests/decoding.cairo:16-19), on the device */
-        calc = (uint32_t)cz_xxh64_frame(sh, x.out, x.produced);
+        calc = (uint32_t)cz_xxh64_frame(x.out, x.produced);
         flags |= CZ_RESULT_CHECKSUM_COMPUTED | (calc == cksum ? CZ_RESULT_CHECKSUM_MATCH : 0u);
     }
     if (LANE == 0) {
@@ -1519,7 +1611,7 @@ __device__ static void cz_run_frame(CzShared& sh, CzFrameIO io, uint8_t* lit_scr
     __syncthreads();
 }
 
-__device__ static void cz_state_reset(CzShared& sh) {                   /* scratch.cairo:23-40 */
+__device__ static void cz_state_reset() {                   /* scratch.cairo:23-40 */
     if (LANE == 0) {
         sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
         sh.fse_rle[0] = sh.fse_rle[1] = sh.fse_rle[2] = -1;
@@ -1529,11 +1621,8 @@ __device__ static void cz_state_reset(CzShared& sh) {                   /* scrat
 
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_kernel(cz_batch_args a) {
-    __shared__ CzShared sh;
-    CZ_DYNAMIC_LDS(cz_dyn_lds);                                         /* CZ_FSE_LDS_BYTES */
-    if (LANE == 0) { sh.fse_ll = cz_dyn_lds; sh.fse_ml = cz_dyn_lds + 512; sh.fse_of = cz_dyn_lds + 1024; }
-    cz_init_llml(sh);
-    uint8_t* lit_scratch = a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride;
+    cz_init_llml();
+    cz_gptr lit_scratch = (cz_gptr)(a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride);
 #ifdef CZ_PROFILE
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
 #endif
@@ -1546,32 +1635,32 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];
-            io.src = t.src; io.src_len = t.src_len; io.dst = t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
+            io.src = (cz_gcptr)t.src; io.src_len = t.src_len; io.dst = (cz_gptr)t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
             io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
             io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming; io.verify = 0;
             /* restore carried state (the Huffman table stays in t.state->huf until a Treeless block asks for it) */
             cz_device_frame_state* gs = t.state;
-            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { sh.fse_ll[i] = gs->fse[0][i]; sh.fse_ml[i] = gs->fse[2][i]; }
-            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) sh.fse_of[i] = gs->fse[1][i];
+            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { CZ_FSE_LL[i] = gs->fse[0][i]; CZ_FSE_ML[i] = gs->fse[2][i]; }
+            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) CZ_FSE_OF[i] = gs->fse[1][i];
             if (LANE == 0) {
                 for (int k = 0; k < 3; k++) { sh.hist[k] = gs->hist[k]; sh.fse_rle[k] = gs->fse_rle[k]; sh.fse_log[k] = gs->fse_log[k]; }
                 sh.huf_max_bits = gs->huf_max_bits;
             }
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, gs->huf, &a.results[f], nullptr, 0);
-            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = sh.fse_ll[i]; gs->fse[2][i] = sh.fse_ml[i]; }
-            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = sh.fse_of[i];
+            cz_run_frame(io, lit_scratch, (cz_gptr16)gs->huf, (CZ_GLOBAL cz_frame_result*)&a.results[f], nullptr, 0);
+            for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = CZ_FSE_LL[i]; gs->fse[2][i] = CZ_FSE_ML[i]; }
+            for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = CZ_FSE_OF[i];
             if (LANE == 0) {
                 for (int k = 0; k < 3; k++) { gs->hist[k] = sh.hist[k]; gs->fse_rle[k] = sh.fse_rle[k]; gs->fse_log[k] = sh.fse_log[k]; }
                 gs->huf_max_bits = sh.huf_max_bits;
             }
         } else {
-            io.src = a.in_base + a.in_off[f]; io.src_len = a.in_len[f]; io.dst = a.out_base + a.out_off[f]; io.dst_cap = a.out_cap[f];
+            io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
             io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum;
-            cz_state_reset(sh);
+            cz_state_reset();
             __syncthreads();
-            cz_run_frame(sh, io, lit_scratch, (uint16_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES), &a.results[f], a.chain_arena,
+            cz_run_frame(io, lit_scratch, (cz_gptr16)(lit_scratch + CZ_LIT_SCRATCH_BYTES), (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena,
                          a.chain_arena ? cz_uni64(a.frame_first[f]) : 0);
 #ifdef CZ_PROFILE
             if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }

@@ -70,6 +70,8 @@ __attribute__((noinline)) static unsigned long long __ballot(int pred) {
     unsigned long long m = 0; for (int i = 0; i < 64; i++) if (emu_xchg[i]) m |= 1ull << i;
     emu_sync(); return m;
 }
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() do { __label__ emu_wb; emu_wb: emu_site[threadIdx.x] = &&emu_wb; emu_note(&&emu_wb); emu_sync(); } while (0)
 static inline uint32_t __builtin_amdgcn_ubfe(uint32_t x, uint32_t off, uint32_t width) { off &= 31; width &= 31; return width ? (x >> off) & ((1u << width) - 1u) : 0u; }
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   /* callers only pass wave-uniform values */
