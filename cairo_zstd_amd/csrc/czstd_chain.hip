@@ -6,11 +6,14 @@
  * trip plus ~60 in-order instructions whatever the number of active lanes.  In
  * cz_decode_frames_kernel that chain runs on lane 0 of a 64-lane wave (1/64 of the issue
  * bandwidth used) and the frames in flight per CU are capped by that kernel's 10.6 KB of LDS.
- * Here the chain is all a lane does: EIGHT frames per wave, one per lane 0..7, each with its own
- * decoding tables (5 KB) and a 256-byte bit ring in LDS (5.6 KB per chain, 24 chains per CU in three
- * waves; 9 and 12 slots per wave measured slower); the other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
- * (bit position | LL,ML,OF codes) to the chain arena; cz_decode_frames_kernel then extracts the
- * extra bits, resolves offsets and executes the sequences without running any chain itself.
+ * Here the chain is all a lane does: CZC_SLOTS (12) frames per wave, one per lane, each with its own
+ * 16-bit decoding tables (2.5 KB) and a 256-byte bit ring in LDS: 3 KB per chain, 48 chains per CU in
+ * four waves, one per SIMD (the number of chains in flight divided by the step latency is this
+ * kernel's throughput; 8, 16 and 21 slots per wave and two interleaved chains per lane measured
+ * slower).  The other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
+ * (the 32 stream bits that hold the extra bits | LL state, ML state, OF code) to the chain arena, and
+ * per block the state->code maps of the LL and ML tables; cz_decode_frames_kernel then extracts the
+ * extra bits, resolves offsets and executes the sequences without tables, bitstream or chain.
  *
  * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
  * table error, invalid code, overrun, left-over bits, more than 32 extra bits in a sequence,
@@ -20,7 +23,7 @@
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
 #ifndef CZC_SLOTS
-#define CZC_SLOTS 16
+#define CZC_SLOTS 12
 #endif
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 #define CZC_MAXSYM 64
@@ -117,7 +120,8 @@ __device__ static inline void czc_topup(CzChainShared& cs, intptr_t old_lo, intp
     const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
     const uint32_t k = helper ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
     const uintptr_t ok = ((uintptr_t)__shfl((uint32_t)((uint64_t)old_lo >> 32), (int)k) << 32) | __shfl((uint32_t)old_lo, (int)k);
-    const uint32_t cnt = helper ? (uint32_t)__shfl((uint32_t)(old_lo - new_lo), (int)k) >> 4 : 0;
+    const uint32_t cnt_k = (uint32_t)__shfl((uint32_t)(old_lo - new_lo), (int)k) >> 4;       /* every lane takes part in the shuffle */
+    const uint32_t cnt = helper ? cnt_k : 0;
     uint4 v[CZC_PF];
 #pragma unroll
     for (uint32_t r = 0; r < CZC_PF; r++) { const uint32_t c = j + r * CZC_LPS; if (c < cnt) v[r] = czc_load16(ok - 16u * (c + 1), Sk, Ek); }
@@ -148,7 +152,7 @@ __device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
 template <bool TAIL>
 __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, uint32_t steps, uint32_t nseq, uint32_t done, uint32_t sbits,
                                         int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& slow, int32_t& neg) {
-    for (uint32_t i = 0; i < steps; i++) {
+    auto step = [&](uint32_t i) {
         const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
         const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
         const uint32_t eLL = sl.t_ll[sLL], eOF = sl.t_of[sOF], eML = sl.t_ml[sML];
@@ -159,7 +163,7 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
 #else
         if (u == 0x7FFFFFF) rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
 #endif
-        slow |= a_ > 32;
+        slow = slow > a_ ? slow : a_;                                   /* more than 32 extra bits: checked after the chain */
         const uint32_t sel = ph >= a_;
         const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
         const uint32_t vl = eLL >> 6, vm = eML >> 6, vo = eOF >> 6;
@@ -169,7 +173,12 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
         sOF = ((vo << no) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
         if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nl + nm_ + no);
         else u -= (int32_t)(a_ + nl + nm_ + no);
-        neg |= u - (int32_t)sbits;
+        neg = neg < u ? neg : u;                                        /* lowest cursor seen: overrun check after the chain */
+    };
+    if (TAIL) { for (uint32_t i = 0; i < steps; i++) step(i); }
+    else {
+#pragma unroll
+        for (uint32_t i = 0; i < CZC_STEPS; i++) step(i);
     }
 }
 
@@ -340,7 +349,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
             }
             /* ---- chain */
-            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0; int32_t neg = 0;
+            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0; int32_t neg = 0x7FFFFFFF;
             int chain_live = have;
             if (have) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
@@ -348,14 +357,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     const uint32_t b = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> 63) : 0; p -= 1; skipped++;
                     if (b == 1 || skipped > 8) break;
                 }
-                if (skipped > 8) slow = 1;
+                if (skipped > 8) slow = 64;
                 uint32_t stv[3] = {0, 0, 0};
                 for (int t = 0; t < 3; t++) {                           /* init order LL, OF, ML (:207-218) */
                     if (rles[t] >= 0) continue;
                     stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - logs[t])) : 0; p -= (int32_t)logs[t];
                 }
                 sLL = stv[0]; sOF = stv[1]; sML = stv[2];
-                if (p < 0) slow = 1;
+                if (p < 0) slow = 64;
                 u = (int32_t)sbits + p;
             }
             uint64_t* rec = a.chain_arena + hdr + 4 + CZC_MAP_WORDS;
@@ -392,7 +401,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             }
             /* ---- finalize the block */
             if (have) {
-                if (slow || neg < 0 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
+                if (slow > 32 || neg < (int32_t)sbits || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
                 else {
                     uint64_t* h = a.chain_arena + hdr;
                     h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;

@@ -1080,8 +1080,38 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
 
 /* Resolves the repeat offsets of up to 64 sequences (one per lane) with a wave scan over
  * history transforms and advances the uniform history (h0,h1,h2); returns the lane's actual offset. */
+/* A history slot during the cheap scan: an offset value, or CZ_HT(k) = "whatever slot k held before". */
+#define CZ_HT(k) (0xFFFFFFFCu + (k))
+__device__ static inline uint32_t cz_ht_pick(uint32_t q, uint32_t p0, uint32_t p1, uint32_t p2) {
+    return q == CZ_HT(0) ? p0 : (q == CZ_HT(1) ? p1 : (q == CZ_HT(2) ? p2 : q));
+}
 __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
+    /* All but one of the transforms (sequence_execution.cairo:85-129) only permute the three slots or
+     * push a new offset: a slot is then either a value or a reference to an older slot, and composing
+     * two transforms is three 3-way selects.  The exception, offset_value 3 with no literals
+     * (h0 - 1), is rare: a chunk that has one takes the general scan below. */
+    if (!__ballot(active && ((ov == 3 && ll == 0) || ov - 3 >= CZ_HT(0)))) {
+        uint32_t a0 = CZ_HT(0), a1 = CZ_HT(1), a2 = CZ_HT(2);
+        if (active) {
+            const uint32_t kind = ov > 3 ? 3u : (ll > 0 ? ov - 1 : ov);    /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push */
+            if (kind == 3) { a0 = ov - 3; a1 = CZ_HT(0); a2 = CZ_HT(1); }
+            else if (kind == 2) { a0 = CZ_HT(2); a1 = CZ_HT(0); a2 = CZ_HT(1); }
+            else if (kind == 1) { a0 = CZ_HT(1); a1 = CZ_HT(0); }
+        }
+#define CZ_HT_STEP(CTRL, RM) do { const uint32_t p0 = cz_dpp<CTRL, RM>(CZ_HT(0), a0), p1 = cz_dpp<CTRL, RM>(CZ_HT(1), a1), p2 = cz_dpp<CTRL, RM>(CZ_HT(2), a2); \
+        a0 = cz_ht_pick(a0, p0, p1, p2); a1 = cz_ht_pick(a1, p0, p1, p2); a2 = cz_ht_pick(a2, p0, p1, p2); } while (0)
+        CZ_HT_STEP(CZ_DPP_SHR1, 0xF); CZ_HT_STEP(CZ_DPP_SHR2, 0xF); CZ_HT_STEP(CZ_DPP_SHR4, 0xF); CZ_HT_STEP(CZ_DPP_SHR8, 0xF);
+        CZ_HT_STEP(CZ_DPP_BCAST15, 0xA); CZ_HT_STEP(CZ_DPP_BCAST31, 0xC);
+#undef CZ_HT_STEP
+        /* the offset a sequence uses is slot 0 after its own transform */
+        const uint32_t actual = cz_ht_pick(a0, h0, h1, h2);
+        const int lastl = cz_unii((int)cnt - 1);
+        const uint32_t t0 = cz_readlane(a0, lastl), t1 = cz_readlane(a1, lastl), t2 = cz_readlane(a2, lastl);
+        const uint32_t n0 = cz_ht_pick(t0, h0, h1, h2), n1 = cz_ht_pick(t1, h0, h1, h2), n2 = cz_ht_pick(t2, h0, h1, h2);
+        h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
+        return actual;
+    }
     /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
     CzHist T; T.s = CZ_HIST_ID; T.v0 = T.v1 = T.v2 = 0;                            /* identity */
     if (active) {
