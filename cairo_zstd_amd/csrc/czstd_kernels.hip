@@ -106,7 +106,7 @@ struct CzShared {
         struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; } t1;
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
         struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64];
-                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16]; } t4;   /* mirror[8..15] == ring[2040..2047] */
+                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64]; } t4;   /* + one dump byte per lane */   /* mirror[8..15] == ring[2040..2047] */
     } a;
     struct {
         struct { uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
@@ -878,6 +878,31 @@ __device__ static inline CzWarm cz_chunk_warm(const CzExecCtx& x, uint64_t produ
         w.c = lit.p[lit_used + 64u * (uint32_t)LANE];
     return w;
 }
+/* First NL literal bytes and first NMB match bytes (plain far matches) of every lane into the chunk
+ * buffer: all global loads first, then byte writes whose address is the lane's dump byte when the
+ * lane has fewer bytes (an address select is cheaper than masking the lane off). */
+template <int NL, int NMB>
+__device__ static inline void cz_copy_group0(uint8_t* ob, uint32_t orel, uint32_t drel, uint32_t ll, uint32_t ml, const uint8_t* ls, const uint8_t* ms,
+                                             const CzLit& lit, int far_plain, int lit_wide) {
+    uint32_t lw[2] = {0, 0}, mw[NMB / 4];
+    const int lg = ll > 0 && !lit.rle;
+    if (lit_wide) {
+        if (lg) { if (NL <= 2) { uint16_t h; __builtin_memcpy(&h, ls, 2); lw[0] = h; } else __builtin_memcpy(&lw[0], ls, 4); if (NL > 4) __builtin_memcpy(&lw[1], ls + 4, 4); }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < NL; j++) if (lg && j < ll) lw[j >> 2] |= (uint32_t)ls[j] << (8 * (j & 3));
+    }
+    /* no overlap: 4-byte loads; the over-read stays below dst + 3 <= dst + ml <= cap */
+#pragma unroll
+    for (uint32_t j = 0; j < NMB / 4; j++) { mw[j] = 0; if (far_plain && 4 * j < ml) __builtin_memcpy(&mw[j], ms + 4 * j, 4); }
+    if (lit.rle) { lw[0] = 0x01010101u * lit.byte; lw[1] = lw[0]; }
+    const uint32_t dump = CZ_OBUF_BYTES + 16 + (uint32_t)LANE;
+#pragma unroll
+    for (uint32_t j = 0; j < NL; j++) ob[j < ll ? orel + j : dump] = (uint8_t)(lw[j >> 2] >> (8 * (j & 3)));
+    const uint32_t mlim = far_plain ? ml : 0;
+#pragma unroll
+    for (uint32_t j = 0; j < NMB; j++) ob[j < mlim ? drel + j : dump] = (uint8_t)(mw[j >> 2] >> (8 * (j & 3)));
+}
 __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan& p) {
     CZ_PROF_DECL; CZ_PROF_T0();
     const uint32_t ll = p.ll, ml = p.ml, off = p.off, tot = ll + ml, incl_tot = p.orel + tot;
@@ -904,27 +929,23 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         const int far_plain = far && off >= ml, far_period = far && off < ml;
         const uint8_t* ls = lit.p + lit_start;
         const uint8_t* ms = cout + (drel - (uint64_t)off);
-        /* first group of every lane: all loads, then all LDS writes */
-        {
-            uint8_t lt[8], mt[8]; uint32_t mw[4]; uint32_t idx = 0;
-            const int lg = ll > 0 && !lit.rle;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) if (lg && j < ll) lt[j] = ls[j];
-            /* no overlap: 4-byte loads; the over-read stays below dst + 3 <= dst + ml <= cap */
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) if (far_plain && 4 * j < ml) __builtin_memcpy(&mw[j], ms + 4 * j, 4);
-            /* period-off pattern (decode_buffer.cairo:101-120) */
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) { mt[j] = ms[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) if (j < ll) ob[orel + j] = lit.rle ? lit.byte : lt[j];
-#pragma unroll
-            for (uint32_t j = 0; j < 16; j++) if (far_plain && j < ml) ob[drel + j] = (uint8_t)(mw[j >> 2] >> (8 * (j & 3)));
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) ob[drel + j] = mt[j];
+        /* first group of every lane: all loads, then all LDS writes; sized by the longest run of the chunk */
+        const int lit_wide = !__ballot(ll > 0 && !lit.rle && (uint64_t)lit_start + 8 > lit.len);   /* 8-byte literal loads stay inside the buffer */
+        const unsigned long long big = __ballot(ll > 4 || ml > 8), mid = __ballot(ll > 2 || ml > 4);
+        if (!mid) cz_copy_group0<2, 4>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
+        else if (!big) cz_copy_group0<4, 8>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
+        else {
+            cz_copy_group0<8, 16>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
             /* the rest of long runs (rare in a chunk this small) */
             for (uint32_t k = 8; k < ll; k++) ob[orel + k] = lit.rle ? lit.byte : ls[k];
             if (far_plain) for (uint32_t k = 16; k < ml; k++) ob[drel + k] = ms[k];
+        }
+        if (__ballot(far_period)) {                                     /* period-off pattern (decode_buffer.cairo:101-120) */
+            uint8_t mt[8]; uint32_t idx = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) { mt[j] = ms[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) if (far_period && j < ml) ob[drel + j] = mt[j];
             if (far_period) for (uint32_t k = 8; k < ml; k++) { ob[drel + k] = ms[idx]; idx = idx + 1 == off ? 0 : idx + 1; }
         }
         cz_wave_sync();
@@ -1059,23 +1080,24 @@ __device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) {
  * three slots is either a constant (src 3) or old[src] + val.  s packs the three srcs. */
 struct CzHist { uint32_t s, v0, v1, v2; };
 #define CZ_HIST_ID (0u | (1u << 2) | (2u << 4))
-__device__ static inline uint32_t cz_hist_pick(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+__device__ static inline uint32_t cz_hist_pick(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { const uint32_t pa = (k & 1u) ? a1 : a0; return (k & 2u) ? a2 : pa; }
 /* apply P, then Q */
 __device__ static inline CzHist cz_hist_compose(const CzHist& P, const CzHist& Q) {
     CzHist R; uint32_t rs = 0;
     const uint32_t p0 = P.s & 3, p1 = (P.s >> 2) & 3, p2 = (P.s >> 4) & 3;
     for (int k = 0; k < 3; k++) {
         const uint32_t qs = (Q.s >> (2 * k)) & 3, qv = k == 0 ? Q.v0 : (k == 1 ? Q.v1 : Q.v2);
-        uint32_t s_, v_;
-        if (qs == 3) { s_ = 3; v_ = qv; }
-        else { s_ = cz_hist_pick(qs, p0, p1, p2); v_ = cz_hist_pick(qs, P.v0, P.v1, P.v2) + qv; }
+        /* branch-free: the picks are computed even for a constant slot (qs == 3 picks slot 2, unused) */
+        const uint32_t ps = cz_hist_pick(qs, p0, p1, p2), pv = cz_hist_pick(qs, P.v0, P.v1, P.v2) + qv;
+        const uint32_t s_ = qs == 3 ? 3u : ps, v_ = qs == 3 ? qv : pv;
         rs |= s_ << (2 * k);
         if (k == 0) R.v0 = v_; else if (k == 1) R.v1 = v_; else R.v2 = v_;
     }
     R.s = rs; return R;
 }
 __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint32_t h0, uint32_t h1, uint32_t h2) {
-    return src == 3 ? val : cz_hist_pick(src, h0, h1, h2) + val;
+    const uint32_t pv = cz_hist_pick(src, h0, h1, h2) + val;
+    return src == 3 ? val : pv;
 }
 
 /* Resolves the repeat offsets of up to 64 sequences (one per lane) with a wave scan over
@@ -1083,7 +1105,11 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
 /* A history slot during the cheap scan: an offset value, or CZ_HT(k) = "whatever slot k held before". */
 #define CZ_HT(k) (0xFFFFFFFCu + (k))
 __device__ static inline uint32_t cz_ht_pick(uint32_t q, uint32_t p0, uint32_t p1, uint32_t p2) {
-    return q == CZ_HT(0) ? p0 : (q == CZ_HT(1) ? p1 : (q == CZ_HT(2) ? p2 : q));
+    /* selects on single bits of the slot index: a chain of equality tests is turned into a switch
+       (branches) by the compiler */
+    const uint32_t t = q - CZ_HT(0);                                    /* 0..2 for a reference */
+    const uint32_t pa = (t & 1u) ? p1 : p0, pb = (t & 2u) ? p2 : pa;
+    return t < 3u ? pb : q;
 }
 __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
