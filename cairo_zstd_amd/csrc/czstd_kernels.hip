@@ -103,7 +103,7 @@ struct CzShared {
     uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
     union {
         uint16_t huf[2048];
-        struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; } t1;
+        struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; uint32_t rank_cnt[16], rank_idx[16]; } t1;
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
         struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64];
                  __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64]; } t4;   /* + one dump byte per lane */   /* mirror[8..15] == ring[2040..2047] */
@@ -400,7 +400,9 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
     const uint32_t last_w = cz_hbs(left);
     sh.huf_max_bits = (uint8_t)max_bits;                             /* :383 (set before the check, as the reference) */
     if (max_bits > 11) return CZ_E_HUF_MAX_BITS_TOO_HIGH;               /* :385 */
-    uint32_t rank_cnt[13], rank_idx[13];
+    /* in LDS: arrays indexed by a run-time value would otherwise live in scratch memory, one HBM-backed
+       round trip per access of this serial loop */
+    uint32_t* rank_cnt = sh.a.t1.rank_cnt; uint32_t* rank_idx = sh.a.t1.rank_idx;
     for (int b = 0; b < 13; b++) { rank_cnt[b] = 0; rank_idx[b] = 0; }
     for (uint32_t s = 0; s <= nw; s++) {
         uint32_t wt = s < nw ? w[s] : last_w, bits = wt ? max_bits + 1 - wt : 0;
@@ -776,26 +778,25 @@ __device__ static __attribute__((noinline)) int cz_parse_seq_tables(cz_gcptr blk
     CzBroadcast& bc = sh.bc;
     uint32_t off = bc.seq_body_off;
     bc.build_mask = 0;
-    const uint32_t modes[3] = { (bc.seq_modes >> 6) & 3, (bc.seq_modes >> 4) & 3, (bc.seq_modes >> 2) & 3 };   /* LL, OF, ML */
-    const uint32_t max_log[3] = { 9, 8, 9 };
-    const int miss[3] = { CZ_E_SEQ_MISSING_RLE_BYTE_LL, CZ_E_SEQ_MISSING_RLE_BYTE_OF, CZ_E_SEQ_MISSING_RLE_BYTE_ML };
-    for (int t = 0; t < 3; t++) {
-        const uint32_t left = bsize - off;
-        if (modes[t] == 0) {                                            /* Predefined */
+    const uint32_t seq_modes = bc.seq_modes;
+    for (int t = 0; t < 3; t++) {                                       /* LL, OF, ML (no local arrays: they would live in scratch memory) */
+        const uint32_t left = bsize - off, mode = (seq_modes >> (6 - 2 * t)) & 3, max_log = t == 1 ? 8u : 9u;
+        const int miss = t == 0 ? CZ_E_SEQ_MISSING_RLE_BYTE_LL : (t == 1 ? CZ_E_SEQ_MISSING_RLE_BYTE_OF : CZ_E_SEQ_MISSING_RLE_BYTE_ML);
+        if (mode == 0) {                                            /* Predefined */
             const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
             const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u;
             for (uint32_t s = 0; s < n; s++) sh.a.t3.probs[t][s] = d[s];
             bc.nprobs[t] = n; bc.acc_log[t] = t == 1 ? 5u : 6u; bc.build_mask |= 1u << t;
             sh.fse_rle[t] = -1;
-        } else if (modes[t] == 1) {                                     /* RLE */
-            if (left == 0) return miss[t];
+        } else if (mode == 1) {                                         /* RLE */
+            if (left == 0) return miss;
             CzFBits fb; fb.g = blk; fb.stage = sh.a.t3.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
             sh.fse_rle[t] = (int32_t)cz_fb_byte(fb, off); off += 1;
-        } else if (modes[t] == 2) {                                     /* FSE_Compressed */
+        } else if (mode == 2) {                                         /* FSE_Compressed */
             CzFBits br; br.g = blk + off; br.len = left; br.idx = 0; br.stage = sh.a.t3.stage; br.stage_lo = 0; br.stage_hi = 0;
             if (off >= stage_lo && off < stage_hi) { br.stage = sh.a.t3.stage + (off - stage_lo); br.stage_hi = stage_hi - off; }
             uint32_t np, lg, used;
-            int e = cz_fse_read_probs(br, max_log[t], sh.a.t3.probs[t], &np, &lg, &used, 100);
+            int e = cz_fse_read_probs(br, max_log, sh.a.t3.probs[t], &np, &lg, &used, 100);
             if (e) return e;
             bc.nprobs[t] = np; bc.acc_log[t] = lg; bc.build_mask |= 1u << t;
             sh.fse_rle[t] = -1;
@@ -1451,6 +1452,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi);
     __syncthreads();
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
+    CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
     if (bc.huf_fill) {
         cz_huf_fill(bc.huf_nsym); __syncthreads();
         if (!last_block) {                                              /* carried for later Treeless blocks */
