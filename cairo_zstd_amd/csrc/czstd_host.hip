@@ -147,7 +147,7 @@ CZ_EXPORT int cz_context_last_chain_ms(cz_context* c, float* ms) {
 }
 
 /* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context and
- * sizes its record arena: 8 bytes per sequence + 32 per block; frames that do not fit fall back
+ * sizes its record arena: 8 bytes per sequence + 1056 per block with sequences; frames that do not fit fall back
  * to in-kernel chains, so any size is safe. */
 CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (!c) return CZ_E_INVALID_ARG;
@@ -184,7 +184,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
     if (c->chain_arena && !a.tasks) {
-        /* pass A: eight frames per wave, one FSE chain per lane -> records in the arena */
+        /* pass A: CZC_SLOTS frames per wave, one FSE chain per lane -> records in the arena */
         if (c->frame_first_cap < n) {
             if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
             CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8)); c->frame_first_cap = n;

@@ -94,9 +94,9 @@ int cz_decode_batch_host(cz_context* ctx,
                          cz_frame_result* results);
 
 /* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context
- * and sizes its record arena (8 bytes per sequence + 32 per block; ~6x the compressed bytes
- * covers BASELINE config 4a).  With the pre-pass a batch decode is two launches:
- * cz_chain_kernel (eight frames per wave, one FSE state-machine chain per lane) writes
+ * and sizes its record arena (8 bytes per sequence + 1056 per block with sequences; ~6x the
+ * compressed bytes covers BASELINE config 4a).  With the pre-pass a batch decode is two launches:
+ * cz_chain_kernel (twelve frames per wave, one FSE state-machine chain per lane) writes
  * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, that are
  * irregular in any way, or whose chains are short, are decoded entirely by cz_decode_frames_kernel. */
 int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
