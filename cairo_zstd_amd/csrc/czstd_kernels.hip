@@ -1105,6 +1105,7 @@ __device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint3
  * history transforms and advances the uniform history (h0,h1,h2); returns the lane's actual offset. */
 /* A history slot during the cheap scan: an offset value, or CZ_HT(k) = "whatever slot k held before". */
 #define CZ_HT(k) (0xFFFFFFFCu + (k))
+#define CZ_PH(j) (0xFFFFFF80u + (j))     /* "the offset pushed by lane j" (an h0 - 1 sequence), known after the scan */
 __device__ static inline uint32_t cz_ht_pick(uint32_t q, uint32_t p0, uint32_t p1, uint32_t p2) {
     /* selects on single bits of the slot index: a chain of equality tests is turned into a switch
        (branches) by the compiler */
@@ -1116,13 +1117,16 @@ __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t
     const int active = (uint32_t)LANE < cnt;
     /* All but one of the transforms (sequence_execution.cairo:85-129) only permute the three slots or
      * push a new offset: a slot is then either a value or a reference to an older slot, and composing
-     * two transforms is three 3-way selects.  The exception, offset_value 3 with no literals
-     * (h0 - 1), is rare: a chunk that has one takes the general scan below. */
-    if (!__ballot(active && ((ov == 3 && ll == 0) || ov - 3 >= CZ_HT(0)))) {
+     * two transforms is three 3-way selects.  The exception, offset_value 3 with no literals, pushes
+     * h0 - 1: it enters the scan as a push of the placeholder CZ_PH(lane), and the few placeholders of
+     * a chunk are resolved afterwards in lane order (each needs only slot 0 before its lane).
+     * Offsets that collide with the tag values (>= 4 GiB - 128) take the general scan below. */
+    if (!__ballot(active && ov - 3 >= CZ_PH(0))) {
         uint32_t a0 = CZ_HT(0), a1 = CZ_HT(1), a2 = CZ_HT(2);
+        const int dec = active && ov == 3 && ll == 0;
         if (active) {
             const uint32_t kind = ov > 3 ? 3u : (ll > 0 ? ov - 1 : ov);    /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push */
-            if (kind == 3) { a0 = ov - 3; a1 = CZ_HT(0); a2 = CZ_HT(1); }
+            if (kind == 3) { a0 = dec ? CZ_PH((uint32_t)LANE) : ov - 3; a1 = CZ_HT(0); a2 = CZ_HT(1); }
             else if (kind == 2) { a0 = CZ_HT(2); a1 = CZ_HT(0); a2 = CZ_HT(1); }
             else if (kind == 1) { a0 = CZ_HT(1); a1 = CZ_HT(0); }
         }
@@ -1131,11 +1135,30 @@ __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t
         CZ_HT_STEP(CZ_DPP_SHR1, 0xF); CZ_HT_STEP(CZ_DPP_SHR2, 0xF); CZ_HT_STEP(CZ_DPP_SHR4, 0xF); CZ_HT_STEP(CZ_DPP_SHR8, 0xF);
         CZ_HT_STEP(CZ_DPP_BCAST15, 0xA); CZ_HT_STEP(CZ_DPP_BCAST31, 0xC);
 #undef CZ_HT_STEP
+        /* placeholders -> values: xval of lane j = offset pushed by the h0 - 1 sequence in lane j */
+        const unsigned long long dm = __ballot(dec);
+        uint32_t xval = 0;
+        if (dm) {
+            const uint32_t e0 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_HT(0), a0);   /* slot 0 before each lane */
+            for (unsigned long long m = dm; m; m &= m - 1) {
+                const int j = cz_unii(__ffsll((long long)m) - 1);
+                const uint32_t b = cz_readlane(e0, j), tp = b - CZ_PH(0);
+                const uint32_t r = tp < 64u ? cz_readlane(xval, cz_unii((int)tp)) : cz_ht_pick(b, h0, h1, h2);
+                if (LANE == j) xval = r - 1;
+            }
+        }
         /* the offset a sequence uses is slot 0 after its own transform */
-        const uint32_t actual = cz_ht_pick(a0, h0, h1, h2);
+        uint32_t actual = cz_ht_pick(a0, h0, h1, h2);
+        if (dm) { const uint32_t tp = a0 - CZ_PH(0); const uint32_t pv = __shfl(xval, (int)(tp & 63u)); if (tp < 64u) actual = pv; }
         const int lastl = cz_unii((int)cnt - 1);
         const uint32_t t0 = cz_readlane(a0, lastl), t1 = cz_readlane(a1, lastl), t2 = cz_readlane(a2, lastl);
-        const uint32_t n0 = cz_ht_pick(t0, h0, h1, h2), n1 = cz_ht_pick(t1, h0, h1, h2), n2 = cz_ht_pick(t2, h0, h1, h2);
+        uint32_t n0 = cz_ht_pick(t0, h0, h1, h2), n1 = cz_ht_pick(t1, h0, h1, h2), n2 = cz_ht_pick(t2, h0, h1, h2);
+        if (dm) {
+            const uint32_t p0 = t0 - CZ_PH(0), p1 = t1 - CZ_PH(0), p2 = t2 - CZ_PH(0);
+            if (p0 < 64u) n0 = cz_readlane(xval, cz_unii((int)p0));
+            if (p1 < 64u) n1 = cz_readlane(xval, cz_unii((int)p1));
+            if (p2 < 64u) n2 = cz_readlane(xval, cz_unii((int)p2));
+        }
         h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
         return actual;
     }
