@@ -278,13 +278,22 @@ def test_chain_prepass_matches_oracle(cz, arena_mb):
             for m in _mutations(z, idx)[:10]:
                 frames.append(m)
                 caps.append(len(orig) * 2 + 4096)
+        c.set_verify_checksum(True)                                      # the record-driven path feeds the XXH64 pass too
         got = cz.decode_batch_host(frames, caps, c)
+        assert c.last_chain_ms() > 0.0 and c.last_kernel_ms() > c.last_chain_ms()   # both kernels ran and were timed
         bad = []
         for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
             st, ref, info = oracle.decode_frame(fr, cap=cap)
             if st != int(r["status"]) or (st == 0 and out != ref):
                 bad.append((i, cz.status.name(r["status"]), cz.status.name(st)))
+            elif st == 0 and info["has_checksum"]:
+                ok = bool(r["flags"] & cz.RESULT_CHECKSUM_COMPUTED) and int(r["calculated_checksum"]) == oracle.xxh64(ref) & 0xFFFFFFFF
+                if not ok:
+                    bad.append((i, "XXH64"))
         assert not bad, bad[:10]
+        c.set_chain_arena(0)
+        cz.decode_batch_host(frames[:4], caps[:4], c)
+        assert c.last_chain_ms() == 0.0
     finally:
         c.close()
 
