@@ -861,24 +861,6 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
     if (emask) { const int first = __ffsll((long long)emask) - 1; p.err = cz_unii(__shfl(e, first)); }
     return p;
 }
-/* Touches the cache lines cz_chunk_copy will read for a planned chunk that starts at output position
- * `produced` / literal position `lit_used`: the chunk is copied one loop iteration later, so its loads
- * then find the lines in L2 instead of paying the HBM round trip inside the dependent part of the loop.
- * The loaded bytes are returned and must be consumed by the caller AFTER that copy (a plain load whose
- * first use is late: the compiler waits for it there, not here). */
-struct CzWarm { uint8_t a, b, c; };
-__device__ static inline CzWarm cz_chunk_warm(const CzExecCtx& x, uint64_t produced, uint32_t lit_used, const CzLit& lit, const CzPlan& p) {
-    CzWarm w; w.a = w.b = w.c = 0;
-    if (p.err) return w;
-    if (p.ml > 0 && (uint64_t)p.off <= produced + p.orel + p.ll - x.drained) {
-        const uint8_t* s = x.out + (produced + p.orel + p.ll - p.off);
-        const uint32_t span = p.off < p.ml ? p.off : p.ml;
-        w.a = s[0]; w.b = s[span - 1];
-    }
-    if (!lit.rle && 64u * (uint32_t)LANE < p.sum_ll + 64u && (uint64_t)lit_used + 64u * (uint32_t)LANE < lit.len)
-        w.c = lit.p[lit_used + 64u * (uint32_t)LANE];
-    return w;
-}
 /* First NL literal bytes and first NMB match bytes (plain far matches) of every lane into the chunk
  * buffer: all global loads first, then byte writes whose address is the lane's dump byte when the
  * lane has fewer bytes (an address select is cheaper than masking the lane off). */
@@ -1394,9 +1376,6 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
     int exec_err = 0;
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
     CZ_PROF_ACC(CZ_P_RING);
-    /* Software pipeline over chunks of 64 sequences: records are loaded two chunks ahead; a chunk is
-     * PLANNED (codes -> values, repeat offsets, positions, every check) and its source cache lines are
-     * touched one iteration before its bytes are COPIED, so the copy's loads hit L2. */
     auto load_rec = [&](uint32_t first) -> uint64_t { return first + (uint32_t)LANE < nseq ? rec[first + (uint32_t)LANE] : 0; };   /* coalesced 8-byte loads */
     auto plan = [&](uint64_t r, uint32_t first, uint64_t produced, uint32_t lit_used) -> CzPlan {
         const uint32_t cnt = nseq - first < 64 ? nseq - first : 64;
@@ -1413,31 +1392,20 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
         const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
         return cz_chunk_plan(x, produced, lit_used, lit, cnt, ll, ml, actual);
     };
-    uint64_t r1 = load_rec(0), r2 = load_rec(64);
-    CzPlan cur = plan(r1, 0, x.produced, x.lit_used);
-    r1 = r2; r2 = load_rec(128);
-    CZ_PROF_ACC(CZ_P_EXTRACT);
-    CzWarm warm; warm.a = warm.b = warm.c = 0; uint32_t sink = 0;
+    /* Records are loaded three chunks ahead; each chunk is planned (codes -> values, repeat offsets,
+     * positions, every check) and then copied.  (Planning a chunk ahead of the copy and touching its
+     * source lines early was measured: once no access was a flat_* one it no longer paid.) */
+    uint64_t r1 = load_rec(0), r2 = load_rec(64), r3 = load_rec(128);
     for (uint32_t done = 0; done < nseq; done += 64) {
+        const CzPlan cur = plan(r1, done, x.produced, x.lit_used);
+        r1 = r2; r2 = r3; r3 = load_rec(done + 192);
         if (cur.err) return cur.err;
-        CzPlan nxt; nxt.err = 0;
-        const int more = done + 64 < nseq;
-        const CzWarm warmed = warm;                                     /* issued one iteration ago, for `cur` */
-        if (more) {
-            const uint64_t produced = x.produced + cur.sum_tot; const uint32_t lit_used = x.lit_used + cur.sum_ll;
-            nxt = plan(r1, done + 64, produced, lit_used);
-            warm = cz_chunk_warm(x, produced, lit_used, lit, nxt);
-            r1 = r2; r2 = load_rec(done + 192);
-        }
         CZ_PROF_ACC(CZ_P_EXTRACT);
         exec_err = cz_chunk_copy(x, lit, cur);
         CZ_PROF_T0();
         if (exec_err) return exec_err;
-        sink |= (uint32_t)warmed.a | (uint32_t)warmed.b | (uint32_t)warmed.c;
         cz_wave_sync();
-        if (more) cur = nxt;
     }
-    if (sink == 0xFFFFFFFFu && nseq == 0xFFFFFFFFu) sh.bc.detail = sink;   /* keeps the warming loads alive; never true (nseq < 2^17) */
     if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
     if (x.lit_used < lit.len) {                                         /* sequence_execution.cairo:72-78 */
         const uint32_t rest = lit.len - x.lit_used;
