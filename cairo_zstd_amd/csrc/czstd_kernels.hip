@@ -1059,122 +1059,60 @@ __device__ static inline uint64_t cz_ring_window(uint32_t sbits, int32_t t) {
 /* n-bit field (n <= 32) starting o bits below the top of W (o + n <= 64) */
 __device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) { return (uint32_t)(((W << o) >> 1) >> (63 - n)); }
 
-/* offset-history transforms (sequence_execution.cairo:85-129) as composable maps: each of the
- * three slots is either a constant (src 3) or old[src] + val.  s packs the three srcs. */
-struct CzHist { uint32_t s, v0, v1, v2; };
-#define CZ_HIST_ID (0u | (1u << 2) | (2u << 4))
-__device__ static inline uint32_t cz_hist_pick(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { const uint32_t pa = (k & 1u) ? a1 : a0; return (k & 2u) ? a2 : pa; }
-/* apply P, then Q */
-__device__ static inline CzHist cz_hist_compose(const CzHist& P, const CzHist& Q) {
-    CzHist R; uint32_t rs = 0;
-    const uint32_t p0 = P.s & 3, p1 = (P.s >> 2) & 3, p2 = (P.s >> 4) & 3;
-    for (int k = 0; k < 3; k++) {
-        const uint32_t qs = (Q.s >> (2 * k)) & 3, qv = k == 0 ? Q.v0 : (k == 1 ? Q.v1 : Q.v2);
-        /* branch-free: the picks are computed even for a constant slot (qs == 3 picks slot 2, unused) */
-        const uint32_t ps = cz_hist_pick(qs, p0, p1, p2), pv = cz_hist_pick(qs, P.v0, P.v1, P.v2) + qv;
-        const uint32_t s_ = qs == 3 ? 3u : ps, v_ = qs == 3 ? qv : pv;
-        rs |= s_ << (2 * k);
-        if (k == 0) R.v0 = v_; else if (k == 1) R.v1 = v_; else R.v2 = v_;
-    }
-    R.s = rs; return R;
-}
-__device__ static inline uint32_t cz_hist_eval(uint32_t src, uint32_t val, uint32_t h0, uint32_t h1, uint32_t h2) {
-    const uint32_t pv = cz_hist_pick(src, h0, h1, h2) + val;
-    return src == 3 ? val : pv;
-}
-
-/* Resolves the repeat offsets of up to 64 sequences (one per lane) with a wave scan over
- * history transforms and advances the uniform history (h0,h1,h2); returns the lane's actual offset. */
-/* A history slot during the cheap scan: an offset value, or CZ_HT(k) = "whatever slot k held before". */
-#define CZ_HT(k) (0xFFFFFFFCu + (k))
-#define CZ_PH(j) (0xFFFFFF80u + (j))     /* "the offset pushed by lane j" (an h0 - 1 sequence), known after the scan */
-__device__ static inline uint32_t cz_ht_pick(uint32_t q, uint32_t p0, uint32_t p1, uint32_t p2) {
-    /* selects on single bits of the slot index: a chain of equality tests is turned into a switch
-       (branches) by the compiler */
-    const uint32_t t = q - CZ_HT(0);                                    /* 0..2 for a reference */
-    const uint32_t pa = (t & 1u) ? p1 : p0, pb = (t & 2u) ? p2 : pa;
-    return t < 3u ? pb : q;
-}
+/* Repeat-offset history (sequence_execution.cairo:85-129) for up to 64 sequences, one per lane, by a
+ * DPP wave scan.  Every transform either permutes the three history slots or pushes an offset in
+ * front, so after any prefix of sequences a slot holds either what one of the three slots held at
+ * the start of the chunk or the offset pushed by some lane.  A transform is two packed words:
+ *   T byte k = 0,1,2   slot k holds what slot T_k held before
+ *            = 4 + k   slot k holds the offset pushed by lane (V byte k)
+ * Composing "P, then Q" is then two byte permutes with Q's T as the selector (v_perm_b32: selector
+ * 0..3 picks a byte of P, 4..7 a byte of Q), plus moving a "pushed" marker that came from P's slot j
+ * to its new slot k.  The one transform that is not of this kind, offset_value 3 with no literals,
+ * pushes h0 - 1: it scans as a push, and the few such values of a chunk are filled in afterwards in
+ * lane order (each needs only slot 0 before its lane).  Advances the uniform history (h0,h1,h2) and
+ * returns the lane's actual offset = slot 0 after its own transform. */
+#define CZ_T_ID 0x00020100u
+__device__ static inline uint32_t cz_pick3(uint32_t k, uint32_t a0, uint32_t a1, uint32_t a2) { const uint32_t pa = (k & 1u) ? a1 : a0; return (k & 2u) ? a2 : pa; }
 __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
-    /* All but one of the transforms (sequence_execution.cairo:85-129) only permute the three slots or
-     * push a new offset: a slot is then either a value or a reference to an older slot, and composing
-     * two transforms is three 3-way selects.  The exception, offset_value 3 with no literals, pushes
-     * h0 - 1: it enters the scan as a push of the placeholder CZ_PH(lane), and the few placeholders of
-     * a chunk are resolved afterwards in lane order (each needs only slot 0 before its lane).
-     * Offsets that collide with the tag values (>= 4 GiB - 128) take the general scan below. */
-    if (!__ballot(active && ov - 3 >= CZ_PH(0))) {
-        uint32_t a0 = CZ_HT(0), a1 = CZ_HT(1), a2 = CZ_HT(2);
-        const int dec = active && ov == 3 && ll == 0;
-        if (active) {
-            const uint32_t kind = ov > 3 ? 3u : (ll > 0 ? ov - 1 : ov);    /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push */
-            if (kind == 3) { a0 = dec ? CZ_PH((uint32_t)LANE) : ov - 3; a1 = CZ_HT(0); a2 = CZ_HT(1); }
-            else if (kind == 2) { a0 = CZ_HT(2); a1 = CZ_HT(0); a2 = CZ_HT(1); }
-            else if (kind == 1) { a0 = CZ_HT(1); a1 = CZ_HT(0); }
-        }
-#define CZ_HT_STEP(CTRL, RM) do { const uint32_t p0 = cz_dpp<CTRL, RM>(CZ_HT(0), a0), p1 = cz_dpp<CTRL, RM>(CZ_HT(1), a1), p2 = cz_dpp<CTRL, RM>(CZ_HT(2), a2); \
-        a0 = cz_ht_pick(a0, p0, p1, p2); a1 = cz_ht_pick(a1, p0, p1, p2); a2 = cz_ht_pick(a2, p0, p1, p2); } while (0)
-        CZ_HT_STEP(CZ_DPP_SHR1, 0xF); CZ_HT_STEP(CZ_DPP_SHR2, 0xF); CZ_HT_STEP(CZ_DPP_SHR4, 0xF); CZ_HT_STEP(CZ_DPP_SHR8, 0xF);
-        CZ_HT_STEP(CZ_DPP_BCAST15, 0xA); CZ_HT_STEP(CZ_DPP_BCAST31, 0xC);
-#undef CZ_HT_STEP
-        /* placeholders -> values: xval of lane j = offset pushed by the h0 - 1 sequence in lane j */
-        const unsigned long long dm = __ballot(dec);
-        uint32_t xval = 0;
-        if (dm) {
-            const uint32_t e0 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_HT(0), a0);   /* slot 0 before each lane */
-            for (unsigned long long m = dm; m; m &= m - 1) {
-                const int j = cz_unii(__ffsll((long long)m) - 1);
-                const uint32_t b = cz_readlane(e0, j), tp = b - CZ_PH(0);
-                const uint32_t r = tp < 64u ? cz_readlane(xval, cz_unii((int)tp)) : cz_ht_pick(b, h0, h1, h2);
-                if (LANE == j) xval = r - 1;
-            }
-        }
-        /* the offset a sequence uses is slot 0 after its own transform */
-        uint32_t actual = cz_ht_pick(a0, h0, h1, h2);
-        if (dm) { const uint32_t tp = a0 - CZ_PH(0); const uint32_t pv = __shfl(xval, (int)(tp & 63u)); if (tp < 64u) actual = pv; }
-        const int lastl = cz_unii((int)cnt - 1);
-        const uint32_t t0 = cz_readlane(a0, lastl), t1 = cz_readlane(a1, lastl), t2 = cz_readlane(a2, lastl);
-        uint32_t n0 = cz_ht_pick(t0, h0, h1, h2), n1 = cz_ht_pick(t1, h0, h1, h2), n2 = cz_ht_pick(t2, h0, h1, h2);
-        if (dm) {
-            const uint32_t p0 = t0 - CZ_PH(0), p1 = t1 - CZ_PH(0), p2 = t2 - CZ_PH(0);
-            if (p0 < 64u) n0 = cz_readlane(xval, cz_unii((int)p0));
-            if (p1 < 64u) n1 = cz_readlane(xval, cz_unii((int)p1));
-            if (p2 < 64u) n2 = cz_readlane(xval, cz_unii((int)p2));
-        }
-        h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
-        return actual;
-    }
-    /* repeat-offset history (sequence_execution.cairo:85-129) by a wave scan */
-    CzHist T; T.s = CZ_HIST_ID; T.v0 = T.v1 = T.v2 = 0;                            /* identity */
+    const int dec = active && ov == 3 && ll == 0;
+    uint32_t T = CZ_T_ID, V = 0;
     if (active) {
-        if (ov > 3) { T.s = 3 | (0 << 2) | (1 << 4); T.v0 = ov - 3; }             /* push */
-        else if (ll > 0) {
-            if (ov == 2) T.s = 1 | (0 << 2) | (2 << 4);
-            else if (ov == 3) T.s = 2 | (0 << 2) | (1 << 4);
-        } else {
-            if (ov == 1) T.s = 1 | (0 << 2) | (2 << 4);
-            else if (ov == 2) T.s = 2 | (0 << 2) | (1 << 4);
-            else { T.s = 0 | (0 << 2) | (1 << 4); T.v0 = 0xFFFFFFFFu; }           /* (h0 - 1, h0, h1) */
+        const uint32_t kind = ov > 3 ? 3u : (ll > 0 ? ov - 1 : ov);        /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push */
+        if (kind == 3) { T = 0x00010004u; V = (uint32_t)LANE; }
+        else if (kind == 2) T = 0x00010002u;
+        else if (kind == 1) T = 0x00020001u;
+    }
+#define CZ_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pV = cz_dpp<CTRL, RM>(0u, V); \
+        const uint32_t R = __builtin_amdgcn_perm(T, pT, T); V = __builtin_amdgcn_perm(V, pV, T); \
+        const uint32_t m = ((R >> 2) & 0x00010101u) * 0xFFu; T = (0x00060504u & m) | (R & ~m); } while (0)
+    CZ_HT_STEP(CZ_DPP_SHR1, 0xF); CZ_HT_STEP(CZ_DPP_SHR2, 0xF); CZ_HT_STEP(CZ_DPP_SHR4, 0xF); CZ_HT_STEP(CZ_DPP_SHR8, 0xF);
+    CZ_HT_STEP(CZ_DPP_BCAST15, 0xA); CZ_HT_STEP(CZ_DPP_BCAST31, 0xC);
+#undef CZ_HT_STEP
+    /* pushed values: ov - 3, or (h0 before the lane) - 1 for the h0 - 1 sequences, resolved in lane order */
+    uint32_t pv = ov - 3;
+    const unsigned long long dm = __ballot(dec);
+    if (dm) {
+        const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T), eV = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0u, V);   /* transform of everything before the lane */
+        for (unsigned long long m = dm; m; m &= m - 1) {
+            const int j = cz_unii(__ffsll((long long)m) - 1);
+            const uint32_t bT = cz_readlane(eT, j) & 0xFFu, bV = cz_readlane(eV, j) & 63u;
+            const uint32_t r = (bT & 4u) ? cz_readlane(pv, cz_unii((int)bV)) : cz_pick3(bT, h0, h1, h2);
+            if (LANE == j) pv = r - 1;
         }
     }
-    /* inclusive scan; a lane without a predecessor in a step composes with the identity */
-#define CZ_HIST_STEP(CTRL, RM) do { CzHist P; P.s = cz_dpp<CTRL, RM>(CZ_HIST_ID, T.s); P.v0 = cz_dpp<CTRL, RM>(0, T.v0); \
-        P.v1 = cz_dpp<CTRL, RM>(0, T.v1); P.v2 = cz_dpp<CTRL, RM>(0, T.v2); T = cz_hist_compose(P, T); } while (0)
-    CZ_HIST_STEP(CZ_DPP_SHR1, 0xF); CZ_HIST_STEP(CZ_DPP_SHR2, 0xF); CZ_HIST_STEP(CZ_DPP_SHR4, 0xF); CZ_HIST_STEP(CZ_DPP_SHR8, 0xF);
-    CZ_HIST_STEP(CZ_DPP_BCAST15, 0xA); CZ_HIST_STEP(CZ_DPP_BCAST31, 0xC);
-#undef CZ_HIST_STEP
-    CzHist X; X.s = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_HIST_ID, T.s); X.v0 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v0);
-    X.v1 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v1); X.v2 = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0, T.v2);
-    const uint32_t b0 = cz_hist_eval(X.s & 3, X.v0, h0, h1, h2), b1 = cz_hist_eval((X.s >> 2) & 3, X.v1, h0, h1, h2),
-                   b2 = cz_hist_eval((X.s >> 4) & 3, X.v2, h0, h1, h2);          /* history before this sequence */
-    uint32_t actual;
-    if (ov > 3) actual = ov - 3;
-    else if (ll > 0) actual = ov == 1 ? b0 : (ov == 2 ? b1 : b2);
-    else actual = ov == 1 ? b1 : (ov == 2 ? b2 : b0 - 1);
+    const uint32_t pushed = __shfl(pv, (int)(V & 63u));                 /* every lane takes part */
+    const uint32_t actual = (T & 4u) ? pushed : cz_pick3(T & 3u, h0, h1, h2);
     const int lastl = cz_unii((int)cnt - 1);
-    const uint32_t ts = cz_readlane(T.s, lastl), t0 = cz_readlane(T.v0, lastl), t1 = cz_readlane(T.v1, lastl), t2 = cz_readlane(T.v2, lastl);
-    const uint32_t n0 = cz_hist_eval(ts & 3, t0, h0, h1, h2), n1 = cz_hist_eval((ts >> 2) & 3, t1, h0, h1, h2), n2 = cz_hist_eval((ts >> 4) & 3, t2, h0, h1, h2);
-    h0 = cz_uni(n0); h1 = cz_uni(n1); h2 = cz_uni(n2);
+    const uint32_t fT = cz_readlane(T, lastl), fV = cz_readlane(V, lastl);
+    uint32_t n[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t tk = (fT >> (8 * k)) & 0xFFu, vk = (fV >> (8 * k)) & 63u;
+        const uint32_t pk = cz_readlane(pv, cz_unii((int)vk));
+        n[k] = (tk & 4u) ? pk : cz_pick3(tk & 3u, h0, h1, h2);
+    }
+    h0 = cz_uni(n[0]); h1 = cz_uni(n[1]); h2 = cz_uni(n[2]);
     return actual;
 }
 __device__ static int cz_history_and_execute(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t ov,

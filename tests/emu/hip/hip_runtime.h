@@ -73,6 +73,17 @@ __attribute__((noinline)) static unsigned long long __ballot(int pred) {
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() do { __label__ emu_wb; emu_wb: emu_site[threadIdx.x] = &&emu_wb; emu_note(&&emu_wb); emu_sync(); } while (0)
 static inline uint32_t __builtin_amdgcn_ubfe(uint32_t x, uint32_t off, uint32_t width) { off &= 31; width &= 31; return width ? (x >> off) & ((1u << width) - 1u) : 0u; }
+/* v_perm_b32: result byte i = byte (selector byte i) of the 8 bytes {S0 (4..7), S1 (0..3)}; 0x0C -> 0x00 */
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    const uint64_t both = ((uint64_t)s0 << 32) | s1; uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = (sel >> (8 * i)) & 0xFF;
+        uint32_t b;
+        if (c <= 7) b = (uint32_t)(both >> (8 * c)) & 0xFF; else if (c == 0x0C) b = 0; else __builtin_trap();
+        r |= b << (8 * i);
+    }
+    return r;
+}
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31)); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   /* callers only pass wave-uniform values */
 static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned long long)v) + 1 : 0; }
