@@ -1076,12 +1076,13 @@ __device__ static inline uint32_t cz_pick3(uint32_t k, uint32_t a0, uint32_t a1,
 __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
     const int dec = active && ov == 3 && ll == 0;
-    uint32_t T = CZ_T_ID, V = 0;
-    if (active) {
-        const uint32_t kind = ov > 3 ? 3u : (ll > 0 ? ov - 1 : ov);        /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push */
-        if (kind == 3) { T = 0x00010004u; V = (uint32_t)LANE; }
-        else if (kind == 2) T = 0x00010002u;
-        else if (kind == 1) T = 0x00020001u;
+    uint32_t T, V;
+    {
+        /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push — selected on single bits (no branches) */
+        const uint32_t kind = !active ? 0u : (ov > 3 ? 3u : ov - (ll > 0 ? 1u : 0u));
+        const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? 0x00010004u : 0x00010002u;
+        T = (kind & 2u) ? t23 : t01;
+        V = (uint32_t)LANE;                                             /* only read where T says "pushed" */
     }
 #define CZ_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pV = cz_dpp<CTRL, RM>(0u, V); \
         const uint32_t R = __builtin_amdgcn_perm(T, pT, T); V = __builtin_amdgcn_perm(V, pV, T); \
