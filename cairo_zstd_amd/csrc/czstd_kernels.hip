@@ -178,30 +178,39 @@ __device__ static void cz_coop_copy(uint8_t* dst_, const uint8_t* src_, uint64_t
     dst += head; src += head; n -= head;
     const uint64_t nvec = n >> 4;
     uint64_t i = (uint64_t)LANE;
-    /* 4 KiB per wave in flight: four independent 16-byte loads per lane before the first store,
+    /* 8 KiB per wave in flight: eight independent 16-byte loads per lane before the first store,
        so the loop is bound by bandwidth rather than by one HBM round trip per KiB */
-    for (; i + 3 * 64 < nvec; i += 4 * 64) {
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) __builtin_memcpy(&v[k], (const void*)(src + 16 * (i + 64 * k)), 16);   /* source may be unaligned */
-#pragma unroll
-        for (int k = 0; k < 4; k++) __builtin_memcpy((void*)(dst + 16 * (i + 64 * k)), &v[k], 16);
+    for (; i + 7 * 64 < nvec; i += 8 * 64) {
+        uint4 v0, v1, v2, v3, v4, v5, v6, v7;                          /* source may be unaligned */
+        __builtin_memcpy(&v0, src + 16 * i, 16); __builtin_memcpy(&v1, src + 16 * (i + 64), 16);
+        __builtin_memcpy(&v2, src + 16 * (i + 128), 16); __builtin_memcpy(&v3, src + 16 * (i + 192), 16);
+        __builtin_memcpy(&v4, src + 16 * (i + 256), 16); __builtin_memcpy(&v5, src + 16 * (i + 320), 16);
+        __builtin_memcpy(&v6, src + 16 * (i + 384), 16); __builtin_memcpy(&v7, src + 16 * (i + 448), 16);
+        *(cz_gptr4)(dst + 16 * i) = v0; *(cz_gptr4)(dst + 16 * (i + 64)) = v1; *(cz_gptr4)(dst + 16 * (i + 128)) = v2; *(cz_gptr4)(dst + 16 * (i + 192)) = v3;
+        *(cz_gptr4)(dst + 16 * (i + 256)) = v4; *(cz_gptr4)(dst + 16 * (i + 320)) = v5; *(cz_gptr4)(dst + 16 * (i + 384)) = v6; *(cz_gptr4)(dst + 16 * (i + 448)) = v7;
+    }
+    for (; i + 3 * 64 < nvec; i += 4 * 64) {                            /* medium copies: four in flight */
+        uint4 v0, v1, v2, v3;
+        __builtin_memcpy(&v0, src + 16 * i, 16); __builtin_memcpy(&v1, src + 16 * (i + 64), 16);
+        __builtin_memcpy(&v2, src + 16 * (i + 128), 16); __builtin_memcpy(&v3, src + 16 * (i + 192), 16);
+        *(cz_gptr4)(dst + 16 * i) = v0; *(cz_gptr4)(dst + 16 * (i + 64)) = v1; *(cz_gptr4)(dst + 16 * (i + 128)) = v2; *(cz_gptr4)(dst + 16 * (i + 192)) = v3;
     }
     for (; i < nvec; i += 64) {
-        uint4 v; __builtin_memcpy(&v, (const void*)(src + 16 * i), 16);
-        __builtin_memcpy((void*)(dst + 16 * i), &v, 16);
+        uint4 v; __builtin_memcpy(&v, src + 16 * i, 16);
+        *(cz_gptr4)(dst + 16 * i) = v;
     }
     for (uint64_t t = (nvec << 4) + (uint64_t)LANE; t < n; t += 64) dst[t] = src[t];
 }
-__device__ static void cz_coop_fill(uint8_t* dst, uint8_t byte, uint64_t n) {
-    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+__device__ static void cz_coop_fill(uint8_t* dst_, uint8_t byte, uint64_t n) {
+    cz_gptr dst = (cz_gptr)dst_;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst_ & 15u)) & 15u);
     if (head > n) head = (uint32_t)n;
     if ((uint32_t)LANE < head) dst[LANE] = byte;
     dst += head; n -= head;
     const uint32_t w = 0x01010101u * byte;
     uint4 v; v.x = w; v.y = w; v.z = w; v.w = w;
     const uint64_t nvec = n >> 4;
-    for (uint64_t i = (uint64_t)LANE; i < nvec; i += 64) *(uint4*)(dst + 16 * i) = v;
+    for (uint64_t i = (uint64_t)LANE; i < nvec; i += 64) *(cz_gptr4)(dst + 16 * i) = v;
     for (uint64_t i = (nvec << 4) + (uint64_t)LANE; i < n; i += 64) dst[i] = byte;
 }
 
