@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One-off large parity sweep on the GPU (diagnostic): synthetic batches through the C ABI with and
+without the chain pre-pass (forced on every frame), every frame compared with the oracle."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa: F401
+import cairo_zstd_amd as cz
+import oracle
+from cairo_zstd_amd import synth
+
+
+def main():
+    total_bad = 0
+    for kind, n, first in (("mix", 6000, 100000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000)):
+        b = synth.generate(kind, n, first_index=first, nthreads=16)
+        frames = [b.frame(i) for i in range(n)]
+        caps = [int(r) + 8 for r in b.regen]
+        o_off, o_cap, o_total = b.out_layout(64)
+        _, olen, ost = oracle.decode_batch(b.base, b.off, b.length, o_off, o_cap, int(o_total) + 256, nthreads=32)
+        ref_out = _
+        for prepass in (0, 1):
+            c = cz.Context(0)
+            if prepass:
+                c.set_chain_arena(int(b.length.sum()) * 8 + (64 << 20), min_sequences=0)
+            t = time.time()
+            got = cz.decode_batch_host(frames, caps, c)
+            bad = 0
+            for i, (r, out) in enumerate(got):
+                if int(r["status"]) != int(ost[i]) or (int(ost[i]) == 0 and out != ref_out[int(o_off[i]): int(o_off[i]) + int(olen[i])].tobytes()):
+                    bad += 1
+            print(f"{kind:14s} n={n} prepass={prepass} bad={bad} chain_ms={c.last_chain_ms():.2f} ({time.time() - t:.1f} s)", flush=True)
+            total_bad += bad
+            c.close()
+    print("TOTAL BAD", total_bad)
+    sys.exit(1 if total_bad else 0)
+
+
+if __name__ == "__main__":
+    main()
