@@ -635,8 +635,10 @@ __device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_
         for (uint32_t grp = 0; grp < CZ_GB_SYMS / 4; grp++) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
+                /* refill once per PAIR of symbols (a pair takes at most 22 of the >= 33 bits): lanes refill at
+                   different symbols, so a per-symbol test makes the wave run the refill code at every symbol */
+                if ((j & 1u) == 0 && avail <= 32) { buf |= (uint64_t)q5 << (32 - avail); avail += 32; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = q0; q0 = 0; }
                 if (g.p > stop) {
-                    if (avail <= 32) { buf |= (uint64_t)q5 << (32 - avail); avail += 32; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = q0; q0 = 0; }
                     const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
                     const uint32_t nb = e >> 8;
                     word[grp] |= (e & 0xFFu) << (8 * j); n++;
