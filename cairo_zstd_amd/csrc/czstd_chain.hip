@@ -28,8 +28,10 @@
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 #define CZC_MAXSYM 64
 #define CZC_RING 256u
-#define CZC_NEED 96u        /* >= 8 steps x 89 bits */
-#define CZC_STEPS 8u
+#ifndef CZC_STEPS
+#define CZC_STEPS 16u
+#endif
+#define CZC_NEED (CZC_STEPS * 8u + 32u)   /* >= CZC_STEPS steps x 58 bits, + the 8 bytes a step reads below its cursor */
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
    main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
