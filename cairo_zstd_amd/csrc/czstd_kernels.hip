@@ -859,6 +859,15 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
     CzPlan p; p.ll = ll; p.ml = ml; p.off = off; p.orel = incl_tot - tot; p.lrel = incl_ll - ll;
     p.sum_ll = cz_readlane(incl_ll, 63); p.sum_tot = cz_readlane(incl_tot, 63);
     const uint64_t dst = produced + p.orel + ll;                        /* where the match goes */
+    p.err = 0;
+    if (x.cap < 0xC0000000ull) {
+        /* everything fits 32 bits: one cheap any-lane-in-trouble test; the exact first error and its
+           reference code are only worked out below when it fires (inactive lanes and empty literal
+           runs can only trip it when it fires anyway or in streaming mode, where they cost the slow path) */
+        const uint32_t d32 = (uint32_t)produced + p.orel + ll;
+        const int bad = (lit_used + p.lrel + ll > lit.len) | (off == 0) | (off > d32 - (uint32_t)x.drained) | (d32 + ml > (uint32_t)x.cap);
+        if (!__ballot(bad)) return p;
+    }
     int e = 0;
     if (active) {
         if (ll > 0 && (uint64_t)lit_used + p.lrel + ll > lit.len) e = CZ_E_EXEC_NOT_ENOUGH_LITERALS;   /* :28-36 */
@@ -868,7 +877,6 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
         else if (dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
     }
     const unsigned long long emask = __ballot(e != 0);
-    p.err = 0;
     if (emask) { const int first = __ffsll((long long)emask) - 1; p.err = cz_unii(__shfl(e, first)); }
     return p;
 }
