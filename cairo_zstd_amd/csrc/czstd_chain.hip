@@ -26,6 +26,7 @@
 #define CZC_SLOTS 12
 #endif
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
+static_assert(CZC_LPS >= 3, "three lanes of a slot build its three tables");
 #define CZC_MAXSYM 64
 #define CZC_RING 256u
 #ifndef CZC_STEPS
@@ -49,8 +50,10 @@ struct CzChainSlot {
     uint16_t t_ll[512], t_ml[512], t_of[256];
     union {                                              /* table-build time | chain time */
         struct {
-            __attribute__((aligned(16))) uint8_t stage[256]; /* head of the sequences section, linear */
-            int16_t probs[CZC_MAXSYM]; uint16_t counters[CZC_MAXSYM];
+            __attribute__((aligned(16))) uint8_t stage[256]; /* head of the sequences section, linear; once the descriptions are
+                                                                read: the symbol counters of the LL and OF table builds */
+            int16_t probs[3][CZC_MAXSYM];                    /* normalised counts of LL, OF, ML */
+            uint16_t counters_ml[CZC_MAXSYM];
         };
         struct {
             __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == ring[248..255] */
@@ -293,22 +296,22 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 hdr = 8ull + atomicAdd(a.chain_top, units);          /* indices 0..7 are reserved (0 = none) */
                 if (hdr + units > a.chain_capacity) { punt = 1; have = 0; frame_done = 1; }
             }
+            uint32_t binfo = 0;                                         /* per table, 10 bits: (symbols - 1) | log << 6; log 0 = nothing to build */
             if (have) {
                 uint32_t off = sbody;
                 uint8_t* maps = (uint8_t*)(a.chain_arena + hdr + 4);
-                const uint32_t md[3] = { (modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3 };
-                const uint32_t max_log[3] = { 9, 8, 9 };
                 for (int t = 0; t < 3 && !punt; t++) {
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
                     uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : nullptr);   /* the OF code travels in the record */
-                    if (md[t] != 3) mapflags |= 1u << t;
-                    if (md[t] == 0) {
+                    const uint32_t md = (modes >> (6 - 2 * t)) & 3, max_log = t == 1 ? 8u : 9u;
+                    if (md != 3) mapflags |= 1u << t;
+                    if (md == 0) {
                         const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
                         const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u, lg = t == 1 ? 5u : 6u;
-                        for (uint32_t s = 0; s < n; s++) sl.probs[s] = d[s];
-                        (void)czc_fse_build16(table, sl.probs, n, lg, sl.counters, cs.llml, (uint32_t)t, map);
+                        for (uint32_t s = 0; s < n; s++) sl.probs[t][s] = d[s];
+                        binfo |= ((n - 1) | (lg << 6)) << (10 * t);
                         logs[t] = lg; rles[t] = -1;
-                    } else if (md[t] == 1) {
+                    } else if (md == 1) {
                         /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                         if (off >= bsize) { punt = 1; break; }
                         const uint32_t sym = blk[off]; off += 1;
@@ -316,18 +319,40 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         table[0] = CZC_E16(0u, 0u, t == 1 ? sym : (cs.llml[(t == 2 ? 40u : 0u) + sym] >> 24));
                         if (map) map[0] = (uint8_t)sym;
                         rles[t] = (int32_t)sym;
-                    } else if (md[t] == 2) {
+                    } else if (md == 2) {
                         CzFBits br; br.g = (cz_gcptr)(blk + off); br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
                         if (off - sbody < 256) { br.stage = sl.stage + (off - sbody); br.stage_hi = 256 - (off - sbody); }
                         uint32_t np, lg, used;
-                        if (cz_fse_read_probs(br, max_log[t], sl.probs, &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }
-                        if (czc_fse_build16(table, sl.probs, np, lg, sl.counters, cs.llml, (uint32_t)t, map)) { punt = 1; break; }
+                        if (cz_fse_read_probs(br, max_log, sl.probs[t], &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }
+                        if (np == 0) { punt = 1; break; }
+                        binfo |= ((np - 1) | (lg << 6)) << (10 * t);
                         logs[t] = lg; rles[t] = -1; off += used;
                         if (off > bsize) { punt = 1; break; }
                     } else if (rles[t] < 0 && logs[t] == 0) { punt = 1; break; }     /* Repeat of nothing */
                 }
                 bitoff = off;
                 if (punt) { have = 0; frame_done = 1; }
+            }
+            /* ---- build the tables: the LL, OF and ML table of a slot on three different lanes, side by side */
+            {
+                __syncthreads();                                        /* descriptions read: `stage` may become counters */
+                const uint32_t k = (uint32_t)LANE / CZC_LPS < CZC_SLOTS ? (uint32_t)LANE / CZC_LPS : 0, t = (uint32_t)LANE % CZC_LPS;
+                const int role = (uint32_t)LANE / CZC_LPS < CZC_SLOTS && t < 3;
+                const uint32_t info = (__shfl(have ? binfo : 0u, (int)k) >> (10 * (t < 3 ? t : 0))) & 0x3FFu;
+                const uint64_t hk = ((uint64_t)__shfl((uint32_t)(hdr >> 32), (int)k) << 32) | __shfl((uint32_t)hdr, (int)k);
+                int bad = 0;
+                if (role && (info >> 6)) {
+                    CzChainSlot& sk = cs.slot[k];
+                    uint16_t* table = t == 0 ? sk.t_ll : (t == 1 ? sk.t_of : sk.t_ml);
+                    uint16_t* counters = t == 0 ? (uint16_t*)sk.stage : (t == 1 ? (uint16_t*)sk.stage + CZC_MAXSYM : sk.counters_ml);
+                    uint8_t* maps = (uint8_t*)(a.chain_arena + hk + 4);
+                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : nullptr);
+                    bad = czc_fse_build16(table, sk.probs[t], (info & 63u) + 1u, info >> 6, counters, cs.llml, t, map);
+                }
+                __syncthreads();
+                const int base = LANE < CZC_SLOTS ? LANE * (int)CZC_LPS : 0;
+                const int anybad = __shfl(bad, base) | __shfl(bad, base + 1) | __shfl(bad, base + 2);
+                if (have && anybad) { punt = 1; have = 0; frame_done = 1; }
             }
             CZC_PROF_ACC(0);
             /* ---- bit ring: fill every live slot's ring with the top 256 bytes of its stream */
