@@ -32,7 +32,7 @@ static_assert(CZC_LPS >= 3, "three lanes of a slot build its three tables");
 #ifndef CZC_STEPS
 #define CZC_STEPS 16u
 #endif
-#define CZC_NEED (CZC_STEPS * 8u + 32u)   /* >= CZC_STEPS steps x 58 bits, + the 8 bytes a step reads below its cursor */
+#define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor */
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
    main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
