@@ -28,7 +28,7 @@
 #define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
 static_assert(CZC_LPS >= 3, "three lanes of a slot build its three tables");
 #define CZC_MAXSYM 64
-#define CZC_RING 256u
+#define CZC_RING 512u       /* fits in the build scratch it is overlaid with; filled at most 256 bytes per top-up */
 #ifndef CZC_STEPS
 #define CZC_STEPS 16u
 #endif
@@ -56,8 +56,8 @@ struct CzChainSlot {
             uint16_t counters_ml[CZC_MAXSYM];
         };
         struct {
-            __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == ring[248..255] */
-            uint8_t ring[CZC_RING];                      /* reversed bitstream, indexed by absolute address & 255 */
+            __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == the last 8 bytes of ring */
+            uint8_t ring[CZC_RING];                      /* reversed bitstream, indexed by absolute address & (CZC_RING - 1) */
         };
     };
 };
@@ -370,7 +370,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 __syncthreads();
                 if (hm) {
                     const intptr_t hi = (intptr_t)((E + 15) & ~(uintptr_t)15);
-                    loaded_lo = have ? hi - (intptr_t)CZC_RING : 0;
+                    loaded_lo = have ? hi - 256 : 0;
                     czc_topup(cs, have ? hi : 0, loaded_lo, Sk, Ek);
                     __syncthreads();
                 }
@@ -405,6 +405,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         /* lowest start whose 256 bytes still cover the word at the cursor */
                         intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
                         if (new_lo > loaded_lo) new_lo = loaded_lo;
+                        if (new_lo < loaded_lo - 256) new_lo = loaded_lo - 256;      /* czc_topup moves at most 16 pieces */
                         __syncthreads();
                         czc_topup(cs, loaded_lo, new_lo, Sk, Ek);
                         loaded_lo = new_lo;
