@@ -30,8 +30,9 @@ static_assert(CZC_LPS >= 3, "three lanes of a slot build its three tables");
 #define CZC_MAXSYM 64
 #define CZC_RING 512u       /* fits in the build scratch it is overlaid with; filled at most 256 bytes per top-up */
 #ifndef CZC_STEPS
-#define CZC_STEPS 16u
+#define CZC_STEPS 32u
 #endif
+static_assert(((CZC_STEPS * 58u + 7u) / 8u + 12u) + 12u <= 256u + 12u, "a top-up adds at most 256 bytes: one must be enough for the next group");
 #define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor */
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
