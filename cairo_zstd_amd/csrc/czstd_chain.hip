@@ -157,7 +157,7 @@ __device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
  * extra bits, read first, :239-256), high word = LL state | ML state << 9 | OF code << 18. */
 template <bool TAIL>
 __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, uint32_t steps, uint32_t nseq, uint32_t done, uint32_t sbits,
-                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& slow, int32_t& neg) {
+                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& slow) {
     auto step = [&](uint32_t i) {
         const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
         const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
@@ -179,7 +179,6 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
         sOF = ((vo << no) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
         if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nl + nm_ + no);
         else u -= (int32_t)(a_ + nl + nm_ + no);
-        neg = neg < u ? neg : u;                                        /* lowest cursor seen: overrun check after the chain */
     };
     if (TAIL) { for (uint32_t i = 0; i < steps; i++) step(i); }
     else {
@@ -377,7 +376,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
             }
             /* ---- chain */
-            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0; int32_t neg = 0x7FFFFFFF;
+            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0;
             int chain_live = have;
             if (have) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
@@ -420,8 +419,8 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
                     if (chain_live) {
                         const uint32_t steps = left < CZC_STEPS ? left : CZC_STEPS;
-                        if (!tail) czc_group<false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, slow, neg);
-                        else czc_group<true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, slow, neg);
+                        if (!tail) czc_group<false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, slow);
+                        else czc_group<true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, slow);
                         done += steps;
                         if (done >= nseq) chain_live = 0;
                     }
@@ -430,7 +429,8 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             }
             /* ---- finalize the block */
             if (have) {
-                if (slow > 32 || neg < (int32_t)sbits || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
+                /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
+                if (slow > 32 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
                 else {
                     uint64_t* h = a.chain_arena + hdr;
                     h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;
