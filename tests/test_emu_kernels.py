@@ -11,8 +11,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps):
-    res = emu_runner.run(frames, caps)
+def _run_and_compare(frames, caps, chain_bytes=0):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -64,3 +64,28 @@ def test_emu_content_checksum_lengths():
     frames.append(raw_frame_with_checksum(b"abc" * 400, corrupt=True))
     caps.append(1300)
     _run_and_compare(frames, caps)
+
+
+def test_emu_chain_prepass():
+    """cz_chain_kernel + the record-driven path of cz_decode_frames_kernel under ASan/UBSan: corpus frames
+    (multi-block, Repeat/RLE/predefined tables), synthetic frames, malformed frames (the pre-pass must
+    leave them to the decoder, which reports the reference's status), and an arena that is far too small."""
+    frames, caps = [], []
+    for name, z, orig in corpus_pairs(max_orig=9000):
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    b = synth.generate("mix", 24, first_index=4242, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 50000][:10]
+    frames += [b.frame(i) for i in keep]
+    caps += [int(b.regen[i]) + 8 for i in keep]
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=900)):
+        rng = np.random.default_rng(100 + idx)
+        for _ in range(4):
+            a = bytearray(z)
+            a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append(bytes(a))
+            caps.append(len(orig) * 2 + 4096)
+        frames.append(z[: len(z) // 2])
+        caps.append(len(orig) * 2 + 4096)
+    _run_and_compare(frames, caps, chain_bytes=8 << 20)
+    _run_and_compare(frames[:20], caps[:20], chain_bytes=4096)
