@@ -37,6 +37,30 @@ WORKLOADS = {
 }
 
 
+def _spawn_ranks(n: int, backend: str) -> int:
+    """Re-launches this command as n ranks (one per GPU) under torch.distributed.run and returns
+    the launcher's exit code.  Runs in a process that has not initialised the GPU (counting
+    devices does not), as a CHILD process — never an exec."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} GPUs on this node, {have} visible (one rank per GPU over RCCL; "
+                  f"use --dist-backend gloo only to rehearse the N>1 code path)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,12 +78,22 @@ def main():
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
 
+    # ---- --gpus N without a launcher: start the N ranks ourselves (torch.distributed.run, one
+    # process per GPU) BEFORE anything in this process touches the GPU, and exit with their code.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(_spawn_ranks(args.gpus, args.dist_backend))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -2,18 +2,24 @@
  * czstd_chain.hip — cz_chain_kernel: the FSE-chain pre-pass.
  *
  * The interleaved LL/OF/ML FSE state machines of a sequences section are ONE serial dependency
- * chain per block (sequence_section_decoder.cairo:223-286), and a chain step costs one LDS round
- * trip plus ~60 in-order instructions whatever the number of active lanes.  In
- * cz_decode_frames_kernel that chain runs on lane 0 of a 64-lane wave (1/64 of the issue
- * bandwidth used) and the frames in flight per CU are capped by that kernel's 10.6 KB of LDS.
- * Here the chain is all a lane does: CZC_SLOTS (12) frames per wave, one per lane, each with its own
- * 16-bit decoding tables (2.5 KB) and a 256-byte bit ring in LDS: 3 KB per chain, 48 chains per CU in
- * four waves, one per SIMD (the number of chains in flight divided by the step latency is this
- * kernel's throughput; 8, 16 and 21 slots per wave and two interleaved chains per lane measured
- * slower).  The other lanes only help staging bytes.  Per sequence the lane appends one 8-byte record
- * (the 32 stream bits that hold the extra bits | LL state, ML state, OF code) to the chain arena, and
- * per block the state->code maps of the LL and ML tables; cz_decode_frames_kernel then extracts the
- * extra bits, resolves offsets and executes the sequences without tables, bitstream or chain.
+ * chain per block (sequence_section_decoder.cairo:223-286).  With every frame of a batch in flight
+ * at once the pass lasts (sequences per block) x (latency of one chain step), so the step is
+ * written for latency, one wave per SIMD:
+ *   - a chain is spread over a QUAD of lanes: lane 0 runs the LL state, lane 1 the ML state, lane 2
+ *     the OF state (update order LL, ML, OF, :258-277), lane 3 idles on a dummy table.  Each lane does
+ *     ONE table lookup, one v_ffbh and one v_bfe per step; the bit offsets of the three fields and
+ *     the total come from four quad_perm DPP operations; the cursor advances with one v_dot4c.
+ *   - CZC_SLOTS (12) quads per wave, four waves per CU: 48 chains per CU, bounded by LDS (16-bit
+ *     decoding tables 2.5 KB + a 512-byte bit ring per chain).
+ *   - the 32 steps of a group are one hand-scheduled inline-asm block (czc_group_asm): the ring words
+ *     of step i+1 are requested before the state bits of step i are extracted, the next table entry is
+ *     loaded straight into the upper half of its register (ds_read_u16_d16_hi), and the record store,
+ *     the cursor update and the record word of the next step sit in the shadow of that load.
+ *     czc_step is the same step in plain C++ (tail groups, and the CPU emulator of tests/emu).
+ * Per sequence the quad appends one 8-byte record (the 32 stream bits below the cursor, which begin
+ * with the sequence's extra bits | LL state, ML state << 9, OF state << 18) to the chain arena, and per
+ * block the state->code byte maps of the three tables; the decode kernels then extract the extra
+ * bits, resolve offsets and execute the sequences without tables, bitstream or chain.
  *
  * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
  * table error, invalid code, overrun, left-over bits, more than 32 extra bits in a sequence,
@@ -25,27 +31,27 @@
 #ifndef CZC_SLOTS
 #define CZC_SLOTS 12
 #endif
-#define CZC_LPS (64 / CZC_SLOTS)   /* helper lanes per slot for staging */
-static_assert(CZC_LPS >= 3, "three lanes of a slot build its three tables");
+#define CZC_LPS 4           /* lanes per slot: the quad */
+static_assert(CZC_SLOTS * CZC_LPS <= 64, "quads of one wave");
 #define CZC_MAXSYM 64
 #define CZC_RING 512u       /* fits in the build scratch it is overlaid with; filled at most 256 bytes per top-up */
-#ifndef CZC_STEPS
-#define CZC_STEPS 32u
-#endif
+#define CZC_STEPS 32u       /* steps per group (the asm block is unrolled for exactly this many) */
 static_assert(((CZC_STEPS * 58u + 7u) / 8u + 12u) + 12u <= 256u + 12u, "a top-up adds at most 256 bytes: one must be enough for the next group");
 #define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor */
-#define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML */
+#define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML + 256 B OF */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
    main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
 
-/* Chain-time decoding tables are 16 bits per state so that more chains fit in a CU's LDS (the number
- * of chains in flight is what bounds this kernel).  An entry holds only what the serial core needs:
- *   [15:6] v = (1 << (9 - num_bits)) | (base_line >> num_bits)     [5:1] extra bits of the code
+/* Chain-time decoding tables are 16 bits per state so that more chains fit in a CU's LDS.  An entry
+ * holds only what the serial core needs:
+ *   [15:6] v = (1 << (9 - num_bits)) | (base_line >> num_bits)     [4:0] extra bits of the code
  * base_line is always a multiple of 2^num_bits (fse_decoder.cairo:231-255: it is a multiple of the
- * slice width), so num_bits = clz10(v) and next state = ((v << num_bits) | bits) & 511.  The symbol
- * itself is not stored: the record carries the STATE and cz_decode_frames_kernel maps it to the code
- * with the per-block state->code byte maps this kernel leaves in the arena. */
-#define CZC_E16(nb, base, xb) ((uint16_t)(((((1u << (9u - (nb))) | ((base) >> (nb))) << 6) | ((xb) << 1))))
+ * slice width).  Loaded into the UPPER half of a register (E = entry << 16): num_bits = clz(E), and
+ * next state = bits [30:22] of (E << num_bits) | the num_bits stream bits.  The symbol itself is not
+ * stored: the record carries the STATE and the decode kernels map it to the code with the per-block
+ * state->code byte maps this kernel leaves in the arena. */
+#define CZC_E16(nb, base, xb) ((uint16_t)(((((1u << (9u - (nb))) | ((base) >> (nb))) << 6) | (xb))))
+#define CZC_E16_IDLE 0x8000u   /* num_bits 0, base 0, no extra bits: what a lane without a chain spins on */
 
 struct CzChainSlot {
     uint16_t t_ll[512], t_ml[512], t_of[256];
@@ -62,7 +68,7 @@ struct CzChainSlot {
         };
     };
 };
-struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; };
+struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; uint16_t idle[2]; };
 
 /* build_decoding_table (fse_decoder.cairo:156-256) into 16-bit chain entries + the state->code map
  * (global, bytes).  kind 0 LL, 1 OF, 2 ML.  Returns 1 if the table holds a code the sequence decoder
@@ -100,7 +106,7 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
             else bl = (k - dbl) * width;
         }
         table[i] = CZC_E16(nb, bl, xb);
-        if (map) map[i] = (uint8_t)s;
+        map[i] = (uint8_t)s;
     }
     return 0;
 }
@@ -115,29 +121,32 @@ __device__ static inline uint4 czc_load16(uintptr_t a, uintptr_t S, uintptr_t E)
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
-/* Ring top-up.  The 256-byte ring of slot k holds stream bytes [lo_k, lo_k + 256), indexed by absolute
- * address & 255.  Lanes k*LPS .. k*LPS+LPS-1 extend it downwards from old_lo to new_lo (both 16-aligned,
- * old_lo - new_lo <= 256) with 16-byte loads, all issued before the first LDS write.  Sk/Ek are the
- * helper lane's copy of its slot's stream bounds; old_lo/new_lo are the OWNER lane's values.
- * A wave stalls on global-memory latency here, so the caller tops up EVERY slot to the brim whenever
- * any slot runs low: one stall per ~50 chain steps instead of one per slot per block. */
-#define CZC_PF ((16 + CZC_LPS - 1) / CZC_LPS)
-__device__ static inline void czc_topup(CzChainShared& cs, intptr_t old_lo, intptr_t new_lo, uintptr_t Sk, uintptr_t Ek) {
-    const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
-    const uint32_t k = helper ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
-    const uintptr_t ok = ((uintptr_t)__shfl((uint32_t)((uint64_t)old_lo >> 32), (int)k) << 32) | __shfl((uint32_t)old_lo, (int)k);
-    const uint32_t cnt_k = (uint32_t)__shfl((uint32_t)(old_lo - new_lo), (int)k) >> 4;       /* every lane takes part in the shuffle */
-    const uint32_t cnt = helper ? cnt_k : 0;
-    uint4 v[CZC_PF];
+/* Ring top-up.  The ring of a slot holds stream bytes [lo, lo + 512), indexed by absolute address & 511.
+ * The four lanes of the slot's quad extend it downwards from old_lo to new_lo (both 16-aligned,
+ * old_lo - new_lo <= 256).  Every lane of a quad passes the same arguments.  The 256 bytes below the
+ * ring are always on their way or already in registers (czc_prefetch, issued right after the previous
+ * top-up), so a top-up is sixteen LDS writes per slot and no wait for global memory; the caller tops up
+ * EVERY slot whenever any slot runs low. */
+#define CZC_PF (16 / CZC_LPS)
+struct CzcPre { uint4 v[CZC_PF]; };
+__device__ static inline void czc_prefetch(CzcPre& pre, int has_slot, intptr_t lo, uintptr_t Sk, uintptr_t Ek) {
+    const uint32_t j = (uint32_t)LANE & 3u;
 #pragma unroll
-    for (uint32_t r = 0; r < CZC_PF; r++) { const uint32_t c = j + r * CZC_LPS; if (c < cnt) v[r] = czc_load16(ok - 16u * (c + 1), Sk, Ek); }
+    for (uint32_t r = 0; r < CZC_PF; r++) {
+        const uint32_t c = j + r * CZC_LPS;
+        if (has_slot) pre.v[r] = czc_load16((uintptr_t)lo - 16u * (c + 1), Sk, Ek);
+    }
+}
+__device__ static inline void czc_commit(CzChainSlot& sk, int has_slot, intptr_t old_lo, intptr_t new_lo, const CzcPre& pre) {
+    const uint32_t j = (uint32_t)LANE & 3u;
+    const uint32_t cnt = has_slot ? (uint32_t)(old_lo - new_lo) >> 4 : 0u;
 #pragma unroll
     for (uint32_t r = 0; r < CZC_PF; r++) {
         const uint32_t c = j + r * CZC_LPS;
         if (c < cnt) {
-            const uint32_t slot = (uint32_t)((ok - 16u * (c + 1)) & (CZC_RING - 1));
-            *(uint4*)&cs.slot[k].ring[slot] = v[r];
-            if (slot == CZC_RING - 16) { *(uint32_t*)&cs.slot[k].mirror[8] = v[r].z; *(uint32_t*)&cs.slot[k].mirror[12] = v[r].w; }
+            const uint32_t slot = (uint32_t)(((uintptr_t)old_lo - 16u * (c + 1)) & (CZC_RING - 1));
+            *(uint4*)&sk.ring[slot] = pre.v[r];
+            if (slot == CZC_RING - 16) { *(uint32_t*)&sk.mirror[8] = pre.v[r].z; *(uint32_t*)&sk.mirror[12] = pre.v[r].w; }
         }
     }
 }
@@ -151,41 +160,169 @@ __device__ static inline uint64_t czc_window(const CzChainSlot& sl, int32_t u) {
     return ((uint64_t)h << 32) | l;
 }
 
-/* `steps` chain steps of one lane (sequence_section_decoder.cairo:223-286, serial core).
- * TAIL: the group may contain the block's last sequence (which updates no state, :258).
- * Record per sequence: low word = the 32 stream bits below the cursor (they hold the sequence's
- * extra bits, read first, :239-256), high word = LL state | ML state << 9 | OF code << 18. */
-template <bool TAIL>
-__device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, uint32_t steps, uint32_t nseq, uint32_t done, uint32_t sbits,
-                                        int32_t& u, uint32_t& sLL, uint32_t& sOF, uint32_t& sML, uint32_t& slow) {
-    auto step = [&](uint32_t i) {
-        const uint32_t ba = ((uint32_t)u >> 3) & (CZC_RING - 4);
-        const uint32_t w2 = *(const uint32_t*)(sl.ring + ba), w1 = *(const uint32_t*)(sl.ring + ba - 4), w0 = *(const uint32_t*)(sl.ring + ba - 8);
-        const uint32_t eLL = sl.t_ll[sLL], eOF = sl.t_of[sOF], eML = sl.t_ml[sML];
-        const uint32_t xl = (eLL >> 1) & 31, xm = (eML >> 1) & 31, xo = (eOF >> 1) & 31, a_ = xl + xm + xo;
-        const uint32_t ph = (uint32_t)u & 31;
-#ifndef CZC_EXP_NOSTORE
-        rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
-#else
-        if (u == 0x7FFFFFF) rec[done + i] = (uint64_t)__builtin_amdgcn_alignbit(w2, w1, ph) | ((uint64_t)(sLL | (sML << 9) | (xo << 18)) << 32);
-#endif
-        slow = slow > a_ ? slow : a_;                                   /* more than 32 extra bits: checked after the chain */
-        const uint32_t sel = ph >= a_;
-        const uint32_t xh = __builtin_amdgcn_alignbit(sel ? w2 : w1, sel ? w1 : w0, (ph - a_) & 31);
-        const uint32_t vl = eLL >> 6, vm = eML >> 6, vo = eOF >> 6;
-        const uint32_t nl = (uint32_t)__builtin_clz(vl) - 22, nm_ = (uint32_t)__builtin_clz(vm) - 22, no = (uint32_t)__builtin_clz(vo) - 22;   /* v != 0 in a built table */
-        sLL = ((vl << nl) | __builtin_amdgcn_ubfe(xh, 32 - nl, nl)) & 511;       /* update order LL, ML, OF (:258-277) */
-        sML = ((vm << nm_) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_, nm_)) & 511;
-        sOF = ((vo << no) | __builtin_amdgcn_ubfe(xh, 32 - nl - nm_ - no, no)) & 255;
-        if (TAIL) u -= (int32_t)((done + i + 1 == nseq) ? a_ : a_ + nl + nm_ + no);
-        else u -= (int32_t)(a_ + nl + nm_ + no);
-    };
-    if (TAIL) { for (uint32_t i = 0; i < steps; i++) step(i); }
-    else {
-#pragma unroll
-        for (uint32_t i = 0; i < CZC_STEPS; i++) step(i);
+/* ---- the chain step ----------------------------------------------------------------------------
+ * Per-lane state of a chain.  The three working lanes of a quad hold the same cursor (u, ph, ring
+ * words) and each its own table state. */
+struct CzcLane {
+    uint32_t E;              /* current table entry << 16 */
+    uint32_t S;              /* current state of this lane's table */
+    int32_t  u;              /* ring-space bit address just above the next unread bit */
+    uint32_t ph;             /* u & 31 */
+    uint32_t w0, w1, w2;     /* ring words at ((u >> 5) & 127) - 2, - 1, - 0 */
+    uint32_t slow;           /* largest number of extra bits seen in one sequence (> 32: the frame is left alone) */
+};
+struct CzcRole {
+    const uint16_t* tb;      /* this lane's table (LDS) */
+    const uint8_t* ringm8;   /* this slot's ring - 8 (LDS) */
+    uint32_t m1, m2;         /* 0xFF00 where the LL / ML state bits precede this lane's in the stream */
+    uint32_t sh;             /* position of this lane's state in the record's high word */
+    uint32_t lane0;          /* lane 0 of its quad */
+};
+#define CZC_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+template <int CTRL> __device__ static inline uint32_t czc_qp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+
+__device__ static inline void czc_ring_words(CzcLane& c, const CzcRole& ro) {
+    const uint8_t* ba = ro.ringm8 + (__builtin_amdgcn_ubfe((uint32_t)c.u, 5, 7) << 2);
+    c.w0 = *(const uint32_t*)ba; c.w1 = *(const uint32_t*)(ba + 4); c.w2 = *(const uint32_t*)(ba + 8);
+    c.ph = (uint32_t)c.u & 31u;
+}
+/* One step (sequence_section_decoder.cairo:223-286, serial core) in plain C++: all 64 lanes call it
+ * together.  `act`: this lane's chain takes the step; `last`: it is the block's last sequence (no
+ * state update, :258); `store`: this lane writes the record.  The asm block below is this, scheduled. */
+__device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL uint64_t* rec, int act, int last, int store) {
+    const uint32_t n = (uint32_t)__builtin_clz(c.E);                    /* E != 0 in a built table */
+    const uint32_t x = __builtin_amdgcn_ubfe(c.E, 16, 5);
+    const uint32_t p = (n << 8) + x;
+    const uint32_t T = p + czc_qp<CZC_QP(1, 2, 0, 3)>(p) + czc_qp<CZC_QP(2, 0, 1, 3)>(p);   /* byte 0: extra bits of the sequence, byte 1: state bits */
+    const uint32_t t1 = czc_qp<CZC_QP(0, 0, 0, 0)>(p) & ro.m1, t2 = czc_qp<CZC_QP(1, 1, 1, 1)>(p) & ro.m2;
+    const uint32_t incl = (t1 + t2 + p) >> 8;                           /* state bits up to and including this lane's */
+    const uint32_t a_ = T & 0xFFu;
+    /* 32 stream bits that follow the a_ extra bits (read order: extras first, :239) */
+    const uint32_t sel = c.ph >= a_;
+    const uint32_t xh = __builtin_amdgcn_alignbit(sel ? c.w2 : c.w1, sel ? c.w1 : c.w0, (c.ph - a_) & 31u);
+    const uint32_t bits = __builtin_amdgcn_ubfe(xh, (0u - incl) & 31u, n);
+    const uint32_t window = __builtin_amdgcn_alignbit(c.w2, c.w1, c.ph);
+    const uint32_t cS = c.S << ro.sh;
+    const uint32_t H = cS + czc_qp<CZC_QP(1, 2, 0, 3)>(cS) + czc_qp<CZC_QP(2, 0, 1, 3)>(cS);
+    if (act) {
+        if (store) *rec = (uint64_t)window | ((uint64_t)H << 32);
+        c.slow = c.slow > a_ ? c.slow : a_;
+        if (last) c.u -= (int32_t)a_;
+        else {
+            c.S = (((c.E >> 22) << n) | bits) & 511u;                  /* (v << num_bits) carries the marker to bit 9 */
+            c.E = (uint32_t)ro.tb[c.S] << 16;
+            c.u -= (int32_t)(a_ + (T >> 8));
+        }
+        czc_ring_words(c, ro);
     }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+/* CZC_STEPS steps of every chain of the wave, none of them a block's last sequence.  Lanes without a live chain spin on the
+ * idle entry and store into the sink.  Registers v100..v123 are scratch.  Wait states: a VGPR written by a VALU instruction is
+ * read through DPP no sooner than two instructions later; the result of v_dot4c is read no sooner than four
+ * instructions later (gfx940-family dot hazard); vcc is read no sooner than two instructions after v_cmp; a data
+ * register of a store of more than 8 bytes is not written by the instruction right behind the store.
+ *   v100 n   v101 x << 16 | 64   v102 p   v103 v = E >> 22   v105 T   v106 t1   v107 t2   v108 a   v109 o
+ *   v110 d   v111 hi  v112 lo  v113 xh  v114 wi   v115 ba  v116 bits  v117 A   v118 c   v[124:125] ring words 0, 1
+ *   v[120:121] / v[122:123]  record (window, states) of the even / odd step, stored together after the odd one */
+#define CZC_ASM_HEAD(WIN) \
+    CZC_ASM_LGKM_E                                 /* the table entry; the ring words may still be on their way */ \
+    "v_ffbh_u32 v100, %[E]\n" \
+    "v_and_or_b32 v101, %[E], %[XM], %[K64]\n" \
+    "v_sub_u32 v102, v101, v100\n" \
+    "v_lshrrev_b32 v103, 22, %[E]\n" \
+    "v_max_u32 %[SLOW], %[SLOW], v108\n"          /* extra bits of the PREVIOUS step (0 before the first) */ \
+    "v_add_u32_dpp v105, v102, v102 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_and_b32_dpp v106, v102, %[M1] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n" \
+    "v_and_b32_dpp v107, v102, %[M2] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp v105, v102, v105 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add3_u32 v109, v106, v107, v102\n" \
+    "v_bfe_u32 v108, v105, 16, 8\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_cmp_ge_u32 vcc, %[PH], v108\n" \
+    "v_sub_u32 v110, %[PH], v108\n" \
+    "v_alignbit_b32 " WIN ", %[W2], v125, %[PH]\n" \
+    "v_cndmask_b32 v111, v125, %[W2], vcc\n" \
+    "v_cndmask_b32 v112, v124, v125, vcc\n" \
+    "v_alignbit_b32 v113, v111, v112, v110\n" \
+    "v_bfe_u32 v116, v113, v109, v100\n" \
+    "v_lshl_or_b32 %[S], v103, v100, v116\n" \
+    "v_lshl_add_u32 v117, %[S], 1, %[TB]\n" \
+    "ds_read_u16_d16_hi %[E], v117\n"
+/* In the shadow of the table load (about 25 ns, a dozen instructions): the state word of the next record is
+   formed, the cursor moves, the records of two steps go out in one 16-byte store, the ring words of the
+   next step are requested.  Every lane stores: lanes 0..2 of a live quad the same records to the same
+   address, all others into the sink. */
+#ifdef CZC_EXP_NOSTORE   /* diagnostic builds (make exp): what the record store costs */
+#define CZC_ASM_STORE(OFF) "s_nop 0\n"
+#else
+#define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF "\n"
+#endif
+#ifdef CZC_BISECT_C
+#undef CZC_ASM_STORE
+#define CZC_ASM_STORE(OFF) "global_store_dwordx2 %[RP], v[120:121], off offset:" #OFF "\n" "global_store_dwordx2 %[RP], v[122:123], off offset:" #OFF "+8\n"
+#endif
+#ifdef CZC_BISECT_B
+#define CZC_ASM_RING01 "ds_read_b32 v124, v115\n" "ds_read_b32 v125, v115 offset:4\n"
+#define CZC_ASM_LGKM_E "s_waitcnt lgkmcnt(3)\n"
+#else
+#define CZC_ASM_RING01 "ds_read2_b32 v[124:125], v115 offset1:1\n"
+#define CZC_ASM_LGKM_E "s_waitcnt lgkmcnt(2)\n"
+#endif
+#define CZC_ASM_TAIL(STORE, NEXTH) \
+    STORE \
+    "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n" \
+    "v_dot4c_i32_i8_e32 %[U], 0x01ff0001, v105\n" \
+    "v_and_b32 v119, 31, v108\n"                  /* spacer: v118 -> DPP two instructions, v_dot4c -> reader three, 16-byte store -> write of its data one */ \
+    "v_add_u32_dpp " NEXTH ", v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp " NEXTH ", v118, " NEXTH " quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_bfe_u32 v114, %[U], 5, 7\n" \
+    "v_and_b32 %[PH], 31, %[U]\n" \
+    "v_lshl_add_u32 v115, v114, 2, %[RB]\n" \
+    CZC_ASM_RING01 \
+    "ds_read_b32 %[W2], v115 offset:8\n"
+#define CZC_ASM_EVEN(OFF) CZC_ASM_HEAD("v120") CZC_ASM_TAIL("", "v123")
+#define CZC_ASM_ODD(OFF) CZC_ASM_HEAD("v122") CZC_ASM_TAIL(CZC_ASM_STORE(OFF), "v121")
+#define CZC_ASM_PAIR(A) CZC_ASM_EVEN(A) CZC_ASM_ODD(A)
+/* `rec`: where this lane's 32 records go (lanes 0..2 of a live quad: the chain's records; every other lane: the sink) */
+__device__ static inline void czc_group_asm(CzcLane& c, const CzcRole& ro, CZ_GLOBAL uint64_t* rec) {
+    static_assert(CZC_STEPS == 32, "the asm block is unrolled for 32 steps");
+    /* ds_* instructions take the 32-bit LDS address */
+    const uint32_t tb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)ro.tb;
+    const uint32_t rb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)ro.ringm8;
+    /* Inside the block the state register holds state + 512: (v << num_bits) | bits keeps the marker of v at
+       bit 9, which the table base (tb32 - 1024) and the record word (nk = -(512 << sh)) absorb.
+       Per lane p = extra bits << 16 | (64 - num_bits) [| 64 << 24 on lane 0]: summed over the quad, byte 0 is
+       192 - state bits (its low 5 bits, summed over the lanes up to this one, are the v_bfe offset of this
+       lane's field counted from the top of the window), byte 2 the extra bits, byte 3 the 64 that v_dot4c
+       with weights (+1, 0, -1, +1) needs to turn byte 0 (-64 - state bits as a signed byte) into -state bits. */
+    const uint32_t tbm = tb32 - 1024u, nk = 0u - (512u << ro.sh), k64 = ro.lane0 ? 0x40000040u : 0x40u;
+    c.S += 512u;
+    asm volatile(
+        "v_mov_b32 v124, %[W0]\n"
+        "v_mov_b32 v125, %[W1]\n"
+        "v_mov_b32 v108, 0\n"
+        /* state word of the first record */
+        "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp v121, v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n"
+        "v_add_u32_dpp v121, v118, v121 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n"
+        CZC_ASM_PAIR(0) CZC_ASM_PAIR(16) CZC_ASM_PAIR(32) CZC_ASM_PAIR(48) CZC_ASM_PAIR(64) CZC_ASM_PAIR(80) CZC_ASM_PAIR(96) CZC_ASM_PAIR(112)
+        CZC_ASM_PAIR(128) CZC_ASM_PAIR(144) CZC_ASM_PAIR(160) CZC_ASM_PAIR(176) CZC_ASM_PAIR(192) CZC_ASM_PAIR(208) CZC_ASM_PAIR(224) CZC_ASM_PAIR(240)
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_max_u32 %[SLOW], %[SLOW], v108\n"
+        "v_mov_b32 %[W0], v124\n"
+        "v_mov_b32 %[W1], v125\n"
+        : [E] "+v"(c.E), [S] "+v"(c.S), [U] "+v"(c.u), [PH] "+v"(c.ph), [W0] "+v"(c.w0), [W1] "+v"(c.w1), [W2] "+v"(c.w2), [SLOW] "+v"(c.slow)
+        : [TB] "v"(tbm), [RB] "v"(rb32), [M1] "v"(ro.m1 ? 0xFFu : 0u), [M2] "v"(ro.m2 ? 0xFFu : 0u), [SH] "v"(ro.sh), [NK] "v"(nk), [K64] "v"(k64),
+          [XM] "s"(0x1F0000u), [RP] "v"(rec)
+        : "memory", "vcc",
+          "v100", "v101", "v102", "v103", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125");
+    c.S -= 512u;
+}
+#endif
 
 /* Diagnostic build only: wave-level s_memtime sums per phase of this kernel, in args.prof[32..39]:
  * 32 block parse + table build, 33 ring fill + state init, 34 top-up events, 35 chain groups, 36 finalize,
@@ -197,18 +334,30 @@ __device__ static inline void czc_group(const CzChainSlot& sl, uint64_t* rec, ui
 #define CZC_PROF_ACC(i) do { } while (0)
 #define CZC_PROF_CNT(i) do { } while (0)
 #endif
+/* value held by lane 0 of this lane's quad (every lane takes part) */
+__device__ static inline uint32_t czc_q0(uint32_t v) { return (uint32_t)__shfl((int)v, LANE & ~3); }
+__device__ static inline uint64_t czc_q0_64(uint64_t v) { return ((uint64_t)czc_q0((uint32_t)(v >> 32)) << 32) | czc_q0((uint32_t)v); }
+
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
     __shared__ CzChainShared cs;
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) cs.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) cs.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+    if (LANE < 2) cs.idle[LANE] = (uint16_t)CZC_E16_IDLE;
     __syncthreads();
-    const int owner = LANE < CZC_SLOTS;
-    CzChainSlot& sl = cs.slot[owner ? LANE : 0];
+    const uint32_t qk = (uint32_t)LANE >> 2, ql = (uint32_t)LANE & 3u;  /* slot, lane of the quad: 0 LL (owner), 1 ML, 2 OF, 3 idle */
+    const int has_slot = qk < CZC_SLOTS;
+    const int owner = has_slot && ql == 0;                              /* does the serial parsing of its slot's frame */
+    CzChainSlot& sl = cs.slot[has_slot ? qk : 0];
+    const uint32_t kind = ql == 0 ? 0u : (ql == 1 ? 2u : 1u);           /* table of this lane in LL, OF, ML numbering */
+    CzcRole ro;
+    ro.ringm8 = sl.ring - 8;
+    ro.m1 = (ql == 1 || ql == 2) ? 0xFF00u : 0u; ro.m2 = ql == 2 ? 0xFF00u : 0u; ro.sh = ql == 3 ? 0u : 9u * ql; ro.lane0 = ql == 0;
+    const uint16_t* my_table = ql == 0 ? sl.t_ll : (ql == 1 ? sl.t_ml : sl.t_of);
 #ifdef CZ_PROFILE
     unsigned long long cprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
-        /* ---- one frame per slot */
+        /* ---- one frame per slot (owner lane; the other lanes of the quad follow through broadcasts) */
         uint32_t f = 0xFFFFFFFFu;
         if (owner) f = atomicAdd(a.chain_counter, 1u);
         int frame_live = owner && f < a.n;
@@ -233,7 +382,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             }
             if (punt) frame_live = 0;
         }
-        int frame_done = !frame_live;
+        int frame_done = !frame_live;                                   /* owner lanes only */
         /* ---- blocks: every slot advances to its next block that has sequences */
         while (__ballot(!frame_done)) {
             const uint8_t* blk = nullptr; uint32_t bsize = 0, nseq = 0, modes = 0, sbody = 0, blast = 0;
@@ -279,30 +428,26 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             {
                 const unsigned long long hm = __ballot(have);
                 if (hm) {
-                    const uintptr_t base = (uintptr_t)blk + sbody, Sx = (uintptr_t)blk, Ex = (uintptr_t)blk + bsize;
-                    const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
-                    const uint32_t k = helper ? (uint32_t)LANE / CZC_LPS : 0, j = (uint32_t)LANE % CZC_LPS;
-                    const uintptr_t bk = ((uintptr_t)__shfl((uint32_t)((uint64_t)base >> 32), (int)k) << 32) | __shfl((uint32_t)base, (int)k);
-                    const uintptr_t Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)Sx >> 32), (int)k) << 32) | __shfl((uint32_t)Sx, (int)k);
-                    const uintptr_t Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)Ex >> 32), (int)k) << 32) | __shfl((uint32_t)Ex, (int)k);
-                    if (helper && ((hm >> k) & 1ull)) for (uint32_t c = j; c < 16; c += CZC_LPS) *(uint4*)&cs.slot[k].stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
+                    const uintptr_t base = (uintptr_t)blk + sbody;
+                    const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk), Ek = Sk + czc_q0(bsize);
+                    if (czc_q0((uint32_t)have) && has_slot) for (uint32_t c = ql; c < 16; c += CZC_LPS) *(uint4*)&sl.stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
                     __syncthreads();
                 }
             }
-            /* ---- tables (sequence_section_decoder.cairo:405-647), serial per lane */
+            /* ---- tables (sequence_section_decoder.cairo:405-647), serial per owner lane */
             uint32_t bitoff = 0, mapflags = 0; uint64_t hdr = 0;
             if (have) {                                                 /* arena: 4-word header + code maps + nseq records */
                 const unsigned long long units = 4ull + CZC_MAP_WORDS + nseq;
-                hdr = 8ull + atomicAdd(a.chain_top, units);          /* indices 0..7 are reserved (0 = none) */
+                hdr = 64ull + atomicAdd(a.chain_top, units);         /* indices 0..63 are reserved: 0 = none, 8..39 = the sink of czc_group_asm */
                 if (hdr + units > a.chain_capacity) { punt = 1; have = 0; frame_done = 1; }
             }
             uint32_t binfo = 0;                                         /* per table, 10 bits: (symbols - 1) | log << 6; log 0 = nothing to build */
             if (have) {
                 uint32_t off = sbody;
                 uint8_t* maps = (uint8_t*)(a.chain_arena + hdr + 4);
-                for (int t = 0; t < 3 && !punt; t++) {
+                for (int t = 0; t < 3 && !punt; t++) {                  /* LL, OF, ML */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
-                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : nullptr);   /* the OF code travels in the record */
+                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : maps + 1024);
                     const uint32_t md = (modes >> (6 - 2 * t)) & 3, max_log = t == 1 ? 8u : 9u;
                     if (md != 3) mapflags |= 1u << t;
                     if (md == 0) {
@@ -317,7 +462,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                         const uint32_t sym = blk[off]; off += 1;
                         if (sym >= (t == 0 ? 36u : (t == 1 ? 32u : 53u))) { punt = 1; break; }
                         table[0] = CZC_E16(0u, 0u, t == 1 ? sym : (cs.llml[(t == 2 ? 40u : 0u) + sym] >> 24));
-                        if (map) map[0] = (uint8_t)sym;
+                        map[0] = (uint8_t)sym;
                         rles[t] = (int32_t)sym;
                     } else if (md == 2) {
                         CzFBits br; br.g = (cz_gcptr)(blk + off); br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
@@ -333,104 +478,123 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 bitoff = off;
                 if (punt) { have = 0; frame_done = 1; }
             }
-            /* ---- build the tables: the LL, OF and ML table of a slot on three different lanes, side by side */
+            /* ---- build the tables: the LL, ML and OF table of a slot on lanes 0, 1, 2 of its quad, side by side */
             {
                 __syncthreads();                                        /* descriptions read: `stage` may become counters */
-                const uint32_t k = (uint32_t)LANE / CZC_LPS < CZC_SLOTS ? (uint32_t)LANE / CZC_LPS : 0, t = (uint32_t)LANE % CZC_LPS;
-                const int role = (uint32_t)LANE / CZC_LPS < CZC_SLOTS && t < 3;
-                const uint32_t info = (__shfl(have ? binfo : 0u, (int)k) >> (10 * (t < 3 ? t : 0))) & 0x3FFu;
-                const uint64_t hk = ((uint64_t)__shfl((uint32_t)(hdr >> 32), (int)k) << 32) | __shfl((uint32_t)hdr, (int)k);
+                const uint32_t info = (czc_q0(have ? binfo : 0u) >> (10 * kind)) & 0x3FFu;
+                const uint64_t hk = czc_q0_64(hdr);
                 int bad = 0;
-                if (role && (info >> 6)) {
-                    CzChainSlot& sk = cs.slot[k];
-                    uint16_t* table = t == 0 ? sk.t_ll : (t == 1 ? sk.t_of : sk.t_ml);
-                    uint16_t* counters = t == 0 ? (uint16_t*)sk.stage : (t == 1 ? (uint16_t*)sk.stage + CZC_MAXSYM : sk.counters_ml);
+                if (has_slot && ql < 3 && (info >> 6)) {
+                    uint16_t* table = kind == 0 ? sl.t_ll : (kind == 1 ? sl.t_of : sl.t_ml);
+                    uint16_t* counters = kind == 0 ? (uint16_t*)sl.stage : (kind == 1 ? (uint16_t*)sl.stage + CZC_MAXSYM : sl.counters_ml);
                     uint8_t* maps = (uint8_t*)(a.chain_arena + hk + 4);
-                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : nullptr);
-                    bad = czc_fse_build16(table, sk.probs[t], (info & 63u) + 1u, info >> 6, counters, cs.llml, t, map);
+                    uint8_t* map = kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024);
+                    bad = czc_fse_build16(table, sl.probs[kind], (info & 63u) + 1u, info >> 6, counters, cs.llml, kind, map);
                 }
                 __syncthreads();
-                const int base = LANE < CZC_SLOTS ? LANE * (int)CZC_LPS : 0;
-                const int anybad = __shfl(bad, base) | __shfl(bad, base + 1) | __shfl(bad, base + 2);
+                const int q0 = LANE & ~3;
+                const int anybad = __shfl(bad, q0) | __shfl(bad, q0 + 1) | __shfl(bad, q0 + 2);
                 if (have && anybad) { punt = 1; have = 0; frame_done = 1; }
             }
             CZC_PROF_ACC(0);
-            /* ---- bit ring: fill every live slot's ring with the top 256 bytes of its stream */
-            const uintptr_t S = have ? (uintptr_t)blk + bitoff : 0, E = have ? (uintptr_t)blk + bsize : 0;
+            /* ---- bit ring: fill every live slot's ring with the top 256 bytes of its stream.  From here on
+                    every lane of a quad holds its slot's values. */
+            const int qhave = (int)czc_q0((uint32_t)have) && has_slot;
+            const uint32_t qnseq = czc_q0(nseq);
+            const uintptr_t qblk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk);
+            const uint32_t qbitoff = czc_q0(bitoff), qbsize = czc_q0(bsize);
+            const uintptr_t S = qhave ? qblk + qbitoff : 0, E = qhave ? qblk + qbsize : 0;
             const uint32_t sbits = (uint32_t)(S & (CZC_RING - 1)) * 8u;
             const intptr_t ring_base = (intptr_t)(S & ~(uintptr_t)(CZC_RING - 1));          /* ring-space bit u <-> byte ring_base + (u >> 3) */
             intptr_t loaded_lo = 0;
-            uintptr_t Sk, Ek;                                           /* helper lanes: bounds of their slot's stream */
+            CzcPre pre;
+            for (uint32_t r = 0; r < CZC_PF; r++) pre.v[r] = uint4{0, 0, 0, 0};
             {
-                const int helper = (uint32_t)LANE / CZC_LPS < CZC_SLOTS;
-                const int k = helper ? (int)((uint32_t)LANE / CZC_LPS) : 0;
-                Sk = ((uintptr_t)__shfl((uint32_t)((uint64_t)S >> 32), k) << 32) | __shfl((uint32_t)S, k);
-                Ek = ((uintptr_t)__shfl((uint32_t)((uint64_t)E >> 32), k) << 32) | __shfl((uint32_t)E, k);
-                const unsigned long long hm = __ballot(have);
+                const unsigned long long hm = __ballot(qhave);
                 __syncthreads();
                 if (hm) {
                     const intptr_t hi = (intptr_t)((E + 15) & ~(uintptr_t)15);
-                    loaded_lo = have ? hi - 256 : 0;
-                    czc_topup(cs, have ? hi : 0, loaded_lo, Sk, Ek);
+                    loaded_lo = qhave ? hi - 256 : 0;
+                    czc_prefetch(pre, qhave, qhave ? hi : 0, S, E);
+                    czc_commit(sl, qhave, qhave ? hi : 0, loaded_lo, pre);
                     __syncthreads();
+                    czc_prefetch(pre, qhave, loaded_lo, S, E);        /* the next 256 bytes: in registers long before they are needed */
                 }
             }
-            /* ---- chain */
-            int32_t u = 0; uint32_t sLL = 0, sOF = 0, sML = 0, done = 0, slow = 0;
-            int chain_live = have;
+            /* ---- initial states (owner), handed to the lanes of the quad */
+            int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0, slow0 = 0;
             if (have) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
                 for (;;) {                                              /* padding :46-64 */
                     const uint32_t b = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> 63) : 0; p -= 1; skipped++;
                     if (b == 1 || skipped > 8) break;
                 }
-                if (skipped > 8) slow = 64;
+                if (skipped > 8) slow0 = 64;
                 uint32_t stv[3] = {0, 0, 0};
                 for (int t = 0; t < 3; t++) {                           /* init order LL, OF, ML (:207-218) */
                     if (rles[t] >= 0) continue;
                     stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - logs[t])) : 0; p -= (int32_t)logs[t];
                 }
-                sLL = stv[0]; sOF = stv[1]; sML = stv[2];
-                if (p < 0) slow = 64;
-                u = (int32_t)sbits + p;
+                st_ll = stv[0]; st_of = stv[1]; st_ml = stv[2];
+                if (p < 0) slow0 = 64;
+                u0 = (int32_t)sbits + p;
             }
-            uint64_t* rec = a.chain_arena + hdr + 4 + CZC_MAP_WORDS;
+            CzcLane c;
+            {
+                const uint32_t qll = czc_q0(st_ll), qml = czc_q0(st_ml), qof = czc_q0(st_of);
+                c.u = (int32_t)czc_q0((uint32_t)u0); c.slow = czc_q0(slow0);
+                c.S = ql == 0 ? qll : (ql == 1 ? qml : (ql == 2 ? qof : 0u));
+                if (!qhave || ql == 3) { ro.tb = cs.idle; c.S = 0; } else ro.tb = my_table;
+                c.E = (uint32_t)ro.tb[c.S] << 16;
+                czc_ring_words(c, ro);
+            }
+            CZ_GLOBAL uint64_t* rec = (CZ_GLOBAL uint64_t*)(a.chain_arena + czc_q0_64(hdr) + 4 + CZC_MAP_WORDS);
+            uint32_t done = 0;
+            int chain_live = qhave;
             CZC_PROF_ACC(1);
             while (__ballot(chain_live)) {
                 /* keep CZC_NEED bytes below every live cursor staged; when one slot runs low, all top up */
                 {
-                    const intptr_t curb = ring_base + ((u > 0 ? u - 1 : 0) >> 3);       /* byte that holds the next unread bit */
+                    const int32_t uq = (int32_t)czc_qp<CZC_QP(0, 0, 0, 0)>((uint32_t)c.u);   /* lane 3 of a quad does not follow the cursor */
+                    const intptr_t curb = ring_base + ((uq > 0 ? uq - 1 : 0) >> 3);    /* byte that holds the next unread bit */
                     const int need = chain_live && (curb - (intptr_t)CZC_NEED < loaded_lo);
                     if (__ballot(need)) {
-                        /* lowest start whose 256 bytes still cover the word at the cursor */
+                        /* lowest start whose 512 bytes still cover the word at the cursor */
                         intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
                         if (new_lo > loaded_lo) new_lo = loaded_lo;
                         if (new_lo < loaded_lo - 256) new_lo = loaded_lo - 256;      /* czc_topup moves at most 16 pieces */
                         __syncthreads();
-                        czc_topup(cs, loaded_lo, new_lo, Sk, Ek);
+                        czc_commit(sl, chain_live, loaded_lo, new_lo, pre);
                         loaded_lo = new_lo;
                         __syncthreads();
+                        czc_prefetch(pre, chain_live, loaded_lo, S, E);
+                        if (chain_live) czc_ring_words(c, ro);            /* the words under the cursor may just have arrived */
                         CZC_PROF_ACC(2); CZC_PROF_CNT(5);
                     }
                 }
                 {
                     /* uniform choice of the loop flavour for this group of CZC_STEPS steps */
-                    const uint32_t left = nseq - done;
+                    const uint32_t left = qnseq - done;
                     const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
-                    if (chain_live) {
-                        const uint32_t steps = left < CZC_STEPS ? left : CZC_STEPS;
-                        if (!tail) czc_group<false>(sl, rec, CZC_STEPS, nseq, done, sbits, u, sLL, sOF, sML, slow);
-                        else czc_group<true>(sl, rec, steps, nseq, done, sbits, u, sLL, sOF, sML, slow);
-                        done += steps;
-                        if (done >= nseq) chain_live = 0;
-                    }
+                    const uint32_t steps = !chain_live ? 0u : (left < CZC_STEPS ? left : CZC_STEPS);
+                    (void)tail;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (!tail) czc_group_asm(c, ro, chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8));
+                    else
+#endif
+                    for (uint32_t i = 0; i < CZC_STEPS; i++) czc_step(c, ro, rec + done + i, i < steps, done + i + 1 == qnseq, ql == 0);
+                    done += steps;
+                    if (chain_live && done >= qnseq) { chain_live = 0; ro.tb = cs.idle; c.S = 0; c.E = (uint32_t)CZC_E16_IDLE << 16; }
                     CZC_PROF_ACC(3); CZC_PROF_CNT(6);
                 }
             }
-            /* ---- finalize the block */
+            /* ---- finalize the block (owner) */
             if (have) {
                 /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
-                if (slow > 32 || u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
+#ifdef CZ_EMU_DEBUG
+                fprintf(stderr, "chain f=%u nseq=%u slow=%u rem=%d\n", f, nseq, c.slow, c.u - (int32_t)sbits);
+#endif
+                if (c.slow > 32 || c.u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
                 else {
                     uint64_t* h = a.chain_arena + hdr;
                     h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;

@@ -155,6 +155,7 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     if (c->chain_arena) { (void)hipFree(c->chain_arena); c->chain_arena = nullptr; c->chain_capacity = 0; }
     if (!bytes) return CZ_OK;
+    if (bytes < 4096) bytes = 4096;                                     /* header indices 0..63 are reserved (sink of the chain step) */
     if (!c->chain_top) { CZ_HIP(c, hipMalloc((void**)&c->chain_top, 64)); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
     CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
     c->chain_capacity = bytes / 8;

@@ -1317,18 +1317,19 @@ __device__ static int cz_sequences(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, c
 /* Same as cz_sequences, for a block whose FSE chain was already run by cz_chain_kernel: every
  * sequence has an 8-byte record in the chain arena — low word = the 32 stream bits that start with
  * the sequence's extra bits (OF, ML, LL; sequence_section_decoder.cairo:239-256), high word = LL state |
- * ML state << 9 | OF code << 18 — and the block header carries the state->code byte maps of its LL
- * and ML tables.  This pass needs neither decoding tables nor the bitstream, only the maps (kept in
+ * ML state << 9 | OF state << 18 — and the block header carries the state->code byte maps of its LL,
+ * ML and OF tables.  This pass needs neither decoding tables nor the bitstream, only the maps (kept in
  * the LDS that holds the FSE tables otherwise; they persist over Repeat-mode blocks). */
-#define CZ_CHAIN_MAP_WORDS 128u
+#define CZ_CHAIN_MAP_WORDS 160u   /* LL 512 B, ML 512 B, OF 256 B */
 __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& lit, cz_gcptr64 maps, cz_gcptr64 rec,
                                                    uint32_t nseq, uint32_t mapflags) {
-    uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapml = mapll + 512;
+    uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapml = mapll + 512; uint8_t* mapof = mapll + 1024;
     CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
     {
-        const uint32_t half = (uint32_t)LANE >> 5, j = (uint32_t)LANE & 31;           /* 32 lanes x 16 B per map */
+        const uint32_t half = (uint32_t)LANE >> 5, j = (uint32_t)LANE & 31;           /* 32 lanes x 16 B per 512-byte map */
         if ((mapflags >> (half ? 2 : 0)) & 1u) { uint4 v; __builtin_memcpy(&v, (cz_gcptr)maps + 512u * half + 16u * j, 16); *(uint4*)(mapll + 512u * half + 16u * j) = v; }
+        if (((mapflags >> 1) & 1u) && LANE < 16) { uint4 v; __builtin_memcpy(&v, (cz_gcptr)maps + 1024u + 16u * (uint32_t)LANE, 16); *(uint4*)(mapof + 16u * (uint32_t)LANE) = v; }
     }
     __syncthreads();
     int exec_err = 0;
@@ -1340,7 +1341,7 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
         uint32_t ll = 0, ml = 0, ov = 4;
         if ((uint32_t)LANE < cnt) {
             const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
-            const uint32_t oc = (st >> 18) & 31;
+            const uint32_t oc = mapof[(st >> 18) & 255];
             const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
             const uint32_t mx = tm >> 24, lx = tl >> 24;                /* <= 32 in total (the pre-pass leaves other frames alone) */
             ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */

@@ -42,7 +42,7 @@ template <class T> __attribute__((noinline)) static T __shfl_up(T v, unsigned d)
     uint64_t raw = 0; memcpy(&raw, &v, sizeof(T)); emu_xchg[threadIdx.x] = raw; emu_sync();
     uint64_t r = threadIdx.x >= d ? emu_xchg[threadIdx.x - d] : raw; emu_sync(); T out; memcpy(&out, &r, sizeof(T)); return out;
 }
-/* DPP (data-parallel primitives) as the kernels use them: row_shr:n (0x110+n), wave_shr:1 (0x138),
+/* DPP (data-parallel primitives) as the kernels use them: quad_perm (0x00-0xFF), row_shr:n (0x110+n), wave_shr:1 (0x138),
  * row_bcast:15 (0x142), row_bcast:31 (0x143); rows are 16 lanes, banks 4 lanes.  A lane whose row or
  * bank is masked off, or whose source lane does not exist, keeps `old` (bound_ctrl:0 semantics). */
 __attribute__((noinline)) static int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
@@ -50,7 +50,8 @@ __attribute__((noinline)) static int __builtin_amdgcn_update_dpp(int old, int sr
     emu_xchg[threadIdx.x] = (uint32_t)src; emu_sync();
     const int l = (int)threadIdx.x, row = l >> 4, pos = l & 15;
     int from = -1;
-    if (ctrl > 0x110 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = pos - n >= 0 ? l - n : -1; }
+    if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);   /* quad_perm:[a,b,c,d] */
+    else if (ctrl > 0x110 && ctrl <= 0x11F) { const int n = ctrl - 0x110; from = pos - n >= 0 ? l - n : -1; }
     else if (ctrl == 0x138) from = l - 1;
     else if (ctrl == 0x142) from = row >= 1 ? row * 16 - 1 : -1;
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
