@@ -82,6 +82,20 @@ class Context:
             raise CzError(st, "cz_context_last_chain_ms")
         return float(ms.value)
 
+    def set_exec_kernel(self, on: bool = True):
+        """Frames with chain records run on cz_exec_frames_kernel (default) or on the record path of cz_decode_frames_kernel."""
+        lib().cz_context_set_exec_kernel(self._h, 1 if on else 0)
+
+    def last_exec_ms(self) -> float:
+        """Milliseconds of the last launch spent in cz_exec_frames_kernel (0 when it did not run)."""
+        if not hasattr(lib(), "cz_context_last_exec_ms"):
+            return 0.0
+        ms = C.c_float(0)
+        st = lib().cz_context_last_exec_ms(self._h, C.byref(ms))
+        if st:
+            raise CzError(st, "cz_context_last_exec_ms")
+        return float(ms.value)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         st = lib().cz_context_last_kernel_ms(self._h, C.byref(ms))

@@ -79,6 +79,11 @@ def lib() -> C.CDLL:
     L.cz_context_set_chain_arena.argtypes = [vp, sz]
     L.cz_context_set_verify_checksum.restype = C.c_int
     L.cz_context_set_verify_checksum.argtypes = [vp, C.c_int]
+    if hasattr(L, "cz_context_last_exec_ms"):                          # absent from round-1 experiment builds
+        L.cz_context_last_exec_ms.restype = C.c_int
+        L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.cz_context_set_exec_kernel.restype = C.c_int
+        L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
     L.cz_context_set_chain_min_sequences.restype = C.c_int
     L.cz_context_set_chain_min_sequences.argtypes = [vp, C.c_uint32]
     L.cz_context_read_profile.restype = C.c_int

@@ -23,6 +23,7 @@
 
 #include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
 #include "czstd_chain.hip"
+#include "czstd_exec.hip"
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -32,7 +33,10 @@ struct cz_context {
     hipStream_t stream = nullptr; bool own_stream = false;
     int num_cu = 0, occupancy = 0, grid_max = 0;
     uint8_t* lit_scratch = nullptr; uint32_t* work_counter = nullptr;
-    hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false;
+    hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
+    bool exec_kernel = false;              /* frames with chain records run on cz_exec_frames_kernel (one workgroup per CU); off by default:
+                                              measured slower than the one-wave record path, DESIGN.md §5 */
+    int exec_grid = 0; bool exec_attr_set = false;
     int last_grid = 0;
     int last_hip_error = 0;
     /* staging for cz_decode_batch_host */
@@ -71,7 +75,8 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     const int scratch_slots = c->grid_max;   /* one scratch region per resident workgroup */
     if (hipMalloc((void**)&c->lit_scratch, (size_t)scratch_slots * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
         hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
-        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || hipEventCreate(&c->ev_mid2) != hipSuccess ||
+        hipEventCreate(&c->ev_stop) != hipSuccess) {
         if (c->lit_scratch) (void)hipFree(c->lit_scratch);
         if (c->work_counter) (void)hipFree(c->work_counter);
         delete c; return CZ_E_HIP;
@@ -93,7 +98,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
     (void)hipMemset(c->d_prof, 0, sizeof tmp);
     int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
     for (int i = 0; i < n; i++) out[i] = tmp[i];
-    for (int i = 32; i < 40 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_* */
+    for (int i = 32; i < 50 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
     return n;
 }
 
@@ -110,6 +115,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
+    if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -141,6 +147,7 @@ CZ_EXPORT int cz_context_last_chain_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
     *ms = 0.0f;
     if (!c->timed || !c->timed_chain) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipEventSynchronize(c->ev_stop));
     CZ_HIP(c, hipEventElapsedTime(ms, c->ev_start, c->ev_mid));
     return CZ_OK;
@@ -157,6 +164,13 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (!bytes) return CZ_OK;
     if (bytes < 4096) bytes = 4096;                                     /* header indices 0..63 are reserved (sink of the chain step) */
     if (!c->chain_top) { CZ_HIP(c, hipMalloc((void**)&c->chain_top, 64)); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
+    if (!c->exec_attr_set) {
+        /* cz_exec_frames_kernel: 128 KiB output ring + chunk summaries in dynamic LDS, one workgroup per CU */
+        CZ_HIP(c, hipFuncSetAttribute((const void*)cz_exec_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CZX_LDS_BYTES));
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_exec_frames_kernel, CZX_THREADS, CZX_LDS_BYTES) != hipSuccess || occ <= 0) occ = 1;
+        c->exec_grid = c->num_cu * occ; c->exec_attr_set = true;
+    }
     CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
     c->chain_capacity = bytes / 8;
     int occ = 0;
@@ -165,10 +179,24 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
+/* Frames that have chain records run on cz_exec_frames_kernel (default) or on cz_decode_frames_kernel's record path (0). */
+CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; return CZ_OK; }
+
 CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
 
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
+
+/* Part of the last launch spent in cz_exec_frames_kernel (0 when it did not run). */
+CZ_EXPORT int cz_context_last_exec_ms(cz_context* c, float* ms) {
+    if (!c || !ms) return CZ_E_INVALID_ARG;
+    *ms = 0.0f;
+    if (!c->timed || !c->timed_exec) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_mid, c->ev_mid2));
+    return CZ_OK;
+}
 
 /* ------------------------------------------------------------------ launch */
 static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
@@ -199,7 +227,18 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
         c->timed_chain = true;
-    } else c->timed_chain = false;
+        c->timed_exec = false;
+        if (c->exec_kernel && !a.verify_checksum && (size_t)c->grid_max >= (size_t)c->exec_grid) {
+            /* pass B: one workgroup per CU executes the frames that got chain records; what it cannot
+               finish (any irregularity) stays for pass C */
+            a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24);
+            const int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
+            hipLaunchKernelGGL(cz_exec_frames_kernel, dim3(egrid), dim3(CZX_THREADS), CZX_LDS_BYTES, c->stream, a);
+            CZ_HIP(c, hipGetLastError());
+            CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
+            c->timed_exec = true;
+        }
+    } else { c->timed_chain = false; c->timed_exec = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, a);

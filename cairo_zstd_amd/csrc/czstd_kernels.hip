@@ -26,7 +26,7 @@
 
 #include "czstd_types.h"
 
-#define LANE ((int)threadIdx.x)
+#define LANE ((int)(threadIdx.x & 63u))   /* lane of the wavefront (cz_exec_frames_kernel has workgroups of several waves) */
 #define CZ_NOINLINE __attribute__((noinline))
 /* Pointers to global memory say so in their type.  A generic pointer that crosses a function that is
  * not inlined (or sits in a struct) makes the compiler emit flat_* instructions, which count against
@@ -1640,6 +1640,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         __syncthreads();
         const uint32_t f = cz_uni(sh.frame_idx);
         if (f >= a.n) break;
+        if (!a.tasks && a.chain_arena && cz_uni64(a.frame_first[f]) == 0xFFFFFFFFFFFFFFFFull) continue;   /* finished by cz_exec_frames_kernel */
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];

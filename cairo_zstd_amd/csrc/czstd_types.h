@@ -54,6 +54,7 @@ typedef struct cz_batch_args {
        frame has no chain info and cz_decode_frames_kernel runs the chains itself */
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
     uint32_t* chain_counter; uint32_t chain_min_nseq;
+    uint32_t* exec_counter;                   /* work counter of cz_exec_frames_kernel */
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
 } cz_batch_args;
 

@@ -116,6 +116,12 @@ int cz_context_set_verify_checksum(cz_context* ctx, int on);
 int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
 /* The part of it spent in the FSE-chain pre-pass kernel (0 when the pre-pass is off). */
 int cz_context_last_chain_ms(cz_context* ctx, float* ms);
+/* The part of it spent in cz_exec_frames_kernel (0 when it did not run). */
+int cz_context_last_exec_ms(cz_context* ctx, float* ms);
+/* With the pre-pass on, frames that got chain records run on cz_decode_frames_kernel's record path (one wave per
+ * frame; default, the faster of the two as measured) or, with on = 1, on cz_exec_frames_kernel: one workgroup of
+ * 16 waves per frame, the block's output assembled in a 128 KiB LDS ring and written to HBM once. */
+int cz_context_set_exec_kernel(cz_context* ctx, int on);
 
 /* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the
  * per-phase shader-cycle sums accumulated by the kernels; returns the number of phases written

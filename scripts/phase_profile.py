@@ -52,5 +52,13 @@ def main():
         print(f"  top-up events {cv[5]}  ({cv[2] / max(cv[5], 1):.0f} ticks each), groups {cv[6]} ({cv[3] / max(cv[6], 1):.1f} ticks each; 1 tick = 10 ns)")
 
 
+    xv = [buf[40 + i] for i in range(9)]
+    if sum(xv):
+        xt = sum(xv)
+        print(f"cz_exec_frames_kernel thread-0 time shares (s_memtime ticks; {ctx.last_exec_ms():.3f} ms of the launch):")
+        for name, v in zip(["headers+parse", "huffman table", "huffman streams", "maps", "pass 1", "pass 2", "pass 3", "flush", "raw/rle/tail"], xv):
+            print(f"  {name:15s} {100.0 * v / xt:5.1f} %   {v / n:10.0f} ticks/frame")
+
+
 if __name__ == "__main__":
     main()

@@ -13,11 +13,13 @@
 thread_local emu_dim3 threadIdx;
 thread_local emu_dim3 blockIdx;
 pthread_barrier_t emu_barrier;
-volatile uint64_t emu_xchg[64];
-void* volatile emu_site[64];
-void* volatile emu_ring[64][64];
-volatile uint64_t emu_sync_count[64];
-static volatile int emu_lane_done[64];
+pthread_barrier_t emu_wbar[EMU_MAX_WAVES];
+volatile uint64_t emu_xchg_all[EMU_MAX_WAVES][64];
+void* volatile emu_site[EMU_MAX_THREADS];
+void* volatile emu_ring[EMU_MAX_THREADS][64];
+volatile uint64_t emu_sync_count[EMU_MAX_THREADS];
+static volatile int emu_lane_done[EMU_MAX_THREADS];
+static volatile int emu_nthreads = 64;
 #include <execinfo.h>
 #include <unistd.h>
 /* watchdog: if no lane passes a barrier for 20 s, print where every lane waits and abort */
@@ -25,11 +27,11 @@ static void* emu_watchdog(void*) {
     uint64_t last = 0; int idle = 0;
     for (;;) {
         sleep(1);
-        uint64_t sum = 0; for (int i = 0; i < 64; i++) sum += emu_sync_count[i];
+        uint64_t sum = 0; for (int i = 0; i < EMU_MAX_THREADS; i++) sum += emu_sync_count[i];
         if (sum != last) { last = sum; idle = 0; continue; }
         if (++idle < 20) continue;
         fprintf(stderr, "EMU HANG: barrier sites per lane (addr2line -e emu_decode <addr>):\n");
-        for (int i = 0; i < 64; i++) fprintf(stderr, "lane %d done=%d syncs=%llu site=%p\n", i, emu_lane_done[i], (unsigned long long)emu_sync_count[i], emu_site[i]);
+        for (int i = 0; i < emu_nthreads; i++) fprintf(stderr, "lane %d done=%d syncs=%llu site=%p\n", i, emu_lane_done[i], (unsigned long long)emu_sync_count[i], emu_site[i]);
         for (int l = 0; l < 2; l++) { fprintf(stderr, "ring lane %d:", l); for (int k = 0; k < 64; k++) fprintf(stderr, " %p", emu_ring[l][(emu_sync_count[l] + 1 + k) & 63]); fprintf(stderr, "\n"); }
         _exit(3);
     }
@@ -38,13 +40,14 @@ static void* emu_watchdog(void*) {
 
 #include "czstd_kernels.hip"
 #include "czstd_chain.hip"
+#include "czstd_exec.hip"
 
 struct lane_arg { cz_batch_args a; unsigned lane, block; int which; };
 static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else cz_decode_frames_kernel(la->a);
+    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a); else cz_decode_frames_kernel(la->a);
     emu_lane_done[la->lane] = 1;
     return nullptr;
 }
@@ -85,15 +88,25 @@ int main(int argc, char** argv) {
         a.frame_first = frame_first.data(); a.chain_counter = &chain_counter;
         a.chain_min_nseq = getenv("EMU_CHAIN_MIN") ? (uint32_t)atoi(getenv("EMU_CHAIN_MIN")) : 0;
     }
-    pthread_barrier_init(&emu_barrier, nullptr, 64);
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
-    /* passes: [chain pre-pass,] main kernel */
-    for (int pass = arena ? 0 : 1; pass < 2; pass++)
-    for (int b = 0; b < grid; b++) {
-        pthread_t th[64]; lane_arg la[64];
-        for (unsigned l = 0; l < 64; l++) { la[l].a = a; la[l].lane = l; la[l].block = (unsigned)b; la[l].which = pass == 0 ? 0 : 1; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
-        for (unsigned l = 0; l < 64; l++) pthread_join(th[l], nullptr);
+    for (int w = 0; w < EMU_MAX_WAVES; w++) pthread_barrier_init(&emu_wbar[w], nullptr, 64);
+    uint32_t exec_counter = 0; a.exec_counter = &exec_counter;
+    /* passes: [chain pre-pass, [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
+    const int with_exec = arena && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
+    for (int pass = arena ? 0 : 1; pass < 3; pass++) {
+        const int which = pass == 0 ? 0 : (pass == 1 ? 2 : 1);
+        if (which == 2 && !with_exec) continue;
+        const int nthreads = which == 2 ? CZX_THREADS : 64;
+        emu_nthreads = nthreads;
+        pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
+        for (int b = 0; b < grid; b++) {
+            std::vector<pthread_t> th((size_t)nthreads); std::vector<lane_arg> la((size_t)nthreads);
+            for (int l = 0; l < nthreads; l++) { la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
+            for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);
+        }
+        pthread_barrier_destroy(&emu_barrier);
     }
+    if (with_exec) { unsigned long long donef = 0; for (uint64_t i = 0; i < n; i++) donef += frame_first[i] == ~0ull; fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_exec_frames_kernel\n", donef); }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {
         fwrite(&res[i], sizeof(cz_frame_result), 1, g);

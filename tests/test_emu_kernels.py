@@ -11,8 +11,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps, chain_bytes=0):
-    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes)
+def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -89,3 +89,26 @@ def test_emu_chain_prepass():
         caps.append(len(orig) * 2 + 4096)
     _run_and_compare(frames, caps, chain_bytes=8 << 20)
     _run_and_compare(frames[:20], caps[:20], chain_bytes=4096)
+
+
+def test_emu_exec_kernel():
+    """cz_exec_frames_kernel (workgroups of several waves, output assembled in the LDS ring, chunks finishing out of
+    order behind done flags) under ASan/UBSan, 4 waves per workgroup: corpus frames, synthetic frames, malformed
+    frames (it must leave them to cz_decode_frames_kernel)."""
+    frames, caps = [], []
+    for name, z, orig in corpus_pairs(max_orig=9000):
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    b = synth.generate("mix", 24, first_index=4242, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 50000][:10]
+    frames += [b.frame(i) for i in keep]
+    caps += [int(b.regen[i]) + 8 for i in keep]
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=900)):
+        rng = np.random.default_rng(300 + idx)
+        for _ in range(3):
+            a = bytearray(z)
+            a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append(bytes(a))
+            caps.append(len(orig) * 2 + 4096)
+    _run_and_compare(frames, caps, chain_bytes=8 << 20, exec_kernel=True)
+    assert "frames finished by cz_exec_frames_kernel" in emu_runner.run.last_stderr

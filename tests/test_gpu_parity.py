@@ -298,6 +298,38 @@ def test_chain_prepass_matches_oracle(cz, arena_mb):
         c.close()
 
 
+def test_exec_kernel_matches_oracle(cz):
+    """The optional cz_exec_frames_kernel path (one workgroup per frame, output assembled in a 128 KiB LDS ring):
+    same results as the oracle on frames it finishes and on frames it hands back."""
+    from cairo_zstd_amd import synth
+    c = cz.Context(0)
+    c.set_chain_arena(256 << 20, min_sequences=0)
+    c.set_exec_kernel(True)
+    try:
+        frames, caps = [], []
+        for kind, n in (("full_4a", 8), ("full_4b", 3), ("mix", 400)):
+            b = synth.generate(kind, n, first_index=311)
+            frames += [b.frame(i) for i in range(n)]
+            caps += [int(r) + 16 for r in b.regen]
+        for name, z, orig in corpus_pairs():
+            frames.append(z)
+            caps.append(len(orig) + 32)
+        for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=6000)):
+            for m in _mutations(z, idx)[:6]:
+                frames.append(m)
+                caps.append(len(orig) * 2 + 4096)
+        got = cz.decode_batch_host(frames, caps, c)
+        assert c.last_exec_ms() > 0.0
+        bad = []
+        for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+            st, ref, info = oracle.decode_frame(fr, cap=cap)
+            if st != int(r["status"]) or (st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"] or int(r["blocks_decoded"]) != info["blocks"])):
+                bad.append((i, cz.status.name(r["status"]), cz.status.name(st)))
+        assert not bad, bad[:10]
+    finally:
+        c.close()
+
+
 def test_more_frames_than_resident_workgroups_with_prepass(cz):
     """Grid-size regression: both launches of the two-pass pipeline index per-workgroup scratch."""
     from cairo_zstd_amd import synth
