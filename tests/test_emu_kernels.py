@@ -112,3 +112,13 @@ def test_emu_exec_kernel():
             caps.append(len(orig) * 2 + 4096)
     _run_and_compare(frames, caps, chain_bytes=8 << 20, exec_kernel=True)
     assert "frames finished by cz_exec_frames_kernel" in emu_runner.run.last_stderr
+
+
+def test_emu_d2_weight_log_10_unsupported():
+    """DESIGN.md D2, device side: CZ_E_UNSUPPORTED for a Huffman-weight FSE accuracy log above 9."""
+    import os
+    from conftest import GOLDEN
+    z = open(os.path.join(GOLDEN, "vectors", "d2_weight_log10.zst"), "rb").read()
+    for chain in (0, 1 << 20):
+        res = emu_runner.run([z], [64], chain_bytes=chain)
+        assert int(res[0][0]["status"]) == status.CZ_E_UNSUPPORTED

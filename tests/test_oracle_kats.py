@@ -207,3 +207,34 @@ def test_decode_from_to_streaming(golden_corpus):
         st, r, got = fd.decode_from_to(b"", cap=len(orig) + 64)
         out += got
         assert out == orig, name
+
+
+def test_oracle_large_corpus_frames_vs_manifest():
+    """The 31 large corpus frames (compressed side committed under tests/golden/decode_corpus_large): the oracle's
+    output matches the sha256 / XXH64 the manifest recorded from the reference's originals."""
+    import hashlib
+    import json
+    from conftest import GOLDEN
+    m = json.load(open(os.path.join(GOLDEN, "decode_corpus_manifest.json")))
+    n = 0
+    for name in sorted(m):
+        e = m[name]
+        if e["committed"]:
+            continue
+        z = open(os.path.join(GOLDEN, "decode_corpus_large", name + ".zst"), "rb").read()
+        assert hashlib.sha256(z).hexdigest() == e["zst_sha256"]
+        st, out, info = oracle.decode_frame(z, cap=e["orig_len"] + 16)
+        assert st == 0 and len(out) == e["orig_len"], name
+        assert hashlib.sha256(out).hexdigest() == e["orig_sha256"] and f"{oracle.xxh64(out):016x}" == e["xxh64"], name
+        assert info["has_checksum"] and info["checksum"] == int(e["xxh64"], 16) & 0xFFFFFFFF, name
+        n += 1
+    assert n == 31
+
+
+def test_oracle_accepts_huffman_weight_fse_log_10():
+    """DESIGN.md D2, reference side: max_log 100 for the FSE table of the Huffman weights (src/huff0/huff0_decoder.cairo:176)."""
+    from conftest import GOLDEN
+    d = os.path.join(GOLDEN, "vectors")
+    z, want = open(os.path.join(d, "d2_weight_log10.zst"), "rb").read(), open(os.path.join(d, "d2_weight_log10"), "rb").read()
+    st, out, _ = oracle.decode_frame(z, cap=64)
+    assert st == 0 and out == want
