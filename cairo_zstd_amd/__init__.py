@@ -169,6 +169,127 @@ def read_block_header(src):
     return st, bh
 
 
+STREAM_ENTRY_DTYPE = np.dtype([("offset", "<u8"), ("length", "<u8"), ("kind", "<u4"), ("magic", "<u4"), ("content_size", "<u8"),
+                               ("out_bound", "<u8"), ("window_size", "<u8")])
+STREAM_FRAME, STREAM_SKIPPABLE = 0, 1
+
+
+def stream_split(src):
+    """cz_stream_split: cuts a stream of concatenated zstd / skippable frames (the caller's side of SkipFrame,
+    src/frame.cairo:160-166) into entries.  Returns (status, entries, consumed)."""
+    a = _as_u8(src)
+    cap = 64
+    while True:
+        ents = np.zeros(cap, dtype=STREAM_ENTRY_DTYPE)
+        count, consumed = C.c_size_t(), C.c_size_t()
+        st = lib().cz_stream_split(a.ctypes.data if a.size else None, a.size, ents.ctypes.data, cap, C.byref(count), C.byref(consumed))
+        if st == status.CZ_E_TARGET_TOO_SMALL:
+            cap = count.value
+            continue
+        return st, ents[: min(count.value, cap)], consumed.value
+
+
+def decode_stream(src, ctx: "Context | None" = None) -> bytes:
+    """Decodes every zstd frame of a multi-frame stream in ONE batch launch (skippable frames are skipped) and
+    returns the concatenated output.  Raises CzError on a malformed stream or frame."""
+    a = _as_u8(src)
+    st, ents, consumed = stream_split(a)
+    if st:
+        raise CzError(st, f"cz_stream_split stopped at byte {consumed}")
+    fr = ents[ents["kind"] == STREAM_FRAME]
+    frames = [a[int(e["offset"]): int(e["offset"] + e["length"])] for e in fr]
+    caps = [int(e["out_bound"]) + 64 for e in fr]
+    out = []
+    for (r, o), e in zip(decode_batch_host(frames, caps, ctx), fr):
+        if int(r["status"]):
+            raise CzError(int(r["status"]), f"frame at byte {int(e['offset'])}")
+        out.append(o)
+    return b"".join(out)
+
+
+class DecoderScratch:
+    """DecoderScratch (src/decoding/scratch.cairo:11-67) resident on the device."""
+
+    def __init__(self, ctx: "Context", window_size: int = 0, _borrowed=None):
+        self._ctx, self._own = ctx, _borrowed is None
+        if _borrowed is not None:
+            self._h = _borrowed
+            return
+        self._h = C.c_void_p()
+        st = lib().cz_decoder_scratch_create(ctx._h, window_size, C.byref(self._h))
+        if st:
+            self._h = None
+            raise CzError(st, "cz_decoder_scratch_create")
+        ctx._decoders.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._own:
+            lib().cz_decoder_scratch_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def reset(self, window_size: int):
+        return lib().cz_decoder_scratch_reset(self._h, window_size)
+
+    def buffer_len(self) -> int:
+        return int(lib().cz_decoder_scratch_buffer_len(self._h))
+
+    def total_output(self) -> int:
+        return int(lib().cz_decoder_scratch_total_output(self._h))
+
+    def drain(self, cap: int = 1 << 24) -> bytes:
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        w = C.c_size_t()
+        st = lib().cz_decoder_scratch_drain(self._h, out.ctypes.data, cap, C.byref(w))
+        if st:
+            raise CzError(st, "cz_decoder_scratch_drain")
+        return out[: w.value].tobytes()
+
+    def drain_to_window_size(self, cap: int = 1 << 24):
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        w = C.c_size_t()
+        rc = lib().cz_decoder_scratch_drain_to_window_size(self._h, out.ctypes.data, cap, C.byref(w))
+        if rc < 0:
+            raise CzError(-rc, "cz_decoder_scratch_drain_to_window_size")
+        return out[: w.value].tobytes() if rc == 1 else None
+
+    def hash_digest(self) -> int:
+        return int(lib().cz_decoder_scratch_hash_digest(self._h))
+
+
+class BlockDecoder:
+    """BlockDecoder (src/decoding/block_decoder.cairo:20-30, :69-137, :237-278)."""
+
+    class _State(C.Structure):
+        _fields_ = [("internal_state", C.c_uint8), ("header_buffer", C.c_uint8 * 3)]
+
+    READY_FOR_HEADER, READY_FOR_BODY, FAILED = 0, 1, 2
+
+    def __init__(self):
+        self._s = BlockDecoder._State()
+        lib().cz_block_decoder_new(C.byref(self._s))
+
+    @property
+    def internal_state(self) -> int:
+        return int(self._s.internal_state)
+
+    def read_block_header(self, src):
+        """Returns (status, BlockHeader, consumed)."""
+        a = _as_u8(src)
+        bh = BlockHeader()
+        used = C.c_uint8()
+        st = lib().cz_block_decoder_read_block_header(C.byref(self._s), a.ctypes.data if a.size else None, a.size, C.byref(bh), C.byref(used))
+        return st, bh, int(used.value)
+
+    def decode_block_content(self, header, workspace: DecoderScratch, src):
+        """Returns (status, bytes of src the block took)."""
+        a = _as_u8(src)
+        used = C.c_uint64()
+        st = lib().cz_block_decoder_decode_block_content(C.byref(self._s), C.byref(header), workspace._h, a.ctypes.data if a.size else None, a.size, C.byref(used))
+        return st, int(used.value)
+
+
 class BlockDecodingStrategy:
     """src/frame_decoder.cairo:33-37"""
     ALL, UPTO_BLOCKS, UPTO_BYTES = 0, 1, 2
@@ -193,6 +314,10 @@ class FrameDecoder:
             self._h = None
 
     __del__ = close
+
+    def scratch(self) -> "DecoderScratch":
+        """FrameDecoderState.decoder_scratch (src/frame_decoder.cairo:25), owned by this frame decoder."""
+        return DecoderScratch(self._ctx, _borrowed=C.c_void_p(lib().cz_frame_decoder_scratch(self._h)))
 
     def _init(self, fn, src):
         a = _as_u8(src)

@@ -125,5 +125,30 @@ def lib() -> C.CDLL:
     L.cz_frame_decoder_read.argtypes = [vp, vp, sz]
     L.cz_frame_decoder_decode_from_to.restype = C.c_int
     L.cz_frame_decoder_decode_from_to.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    if hasattr(L, "cz_stream_split"):                                  # absent from round-1 experiment builds
+        L.cz_stream_split.restype = C.c_int
+        L.cz_stream_split.argtypes = [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+        L.cz_decoder_scratch_create.restype = C.c_int
+        L.cz_decoder_scratch_create.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.cz_decoder_scratch_reset.restype = C.c_int
+        L.cz_decoder_scratch_reset.argtypes = [vp, C.c_uint64]
+        L.cz_decoder_scratch_destroy.argtypes = [vp]
+        L.cz_decoder_scratch_buffer_len.restype = sz
+        L.cz_decoder_scratch_buffer_len.argtypes = [vp]
+        L.cz_decoder_scratch_total_output.restype = C.c_uint64
+        L.cz_decoder_scratch_total_output.argtypes = [vp]
+        L.cz_decoder_scratch_drain.restype = C.c_int
+        L.cz_decoder_scratch_drain.argtypes = [vp, vp, sz, C.POINTER(sz)]
+        L.cz_decoder_scratch_drain_to_window_size.restype = C.c_int
+        L.cz_decoder_scratch_drain_to_window_size.argtypes = [vp, vp, sz, C.POINTER(sz)]
+        L.cz_decoder_scratch_hash_digest.restype = C.c_uint64
+        L.cz_decoder_scratch_hash_digest.argtypes = [vp]
+        L.cz_block_decoder_new.argtypes = [vp]
+        L.cz_block_decoder_read_block_header.restype = C.c_int
+        L.cz_block_decoder_read_block_header.argtypes = [vp, vp, sz, C.POINTER(BlockHeader), C.POINTER(C.c_uint8)]
+        L.cz_block_decoder_decode_block_content.restype = C.c_int
+        L.cz_block_decoder_decode_block_content.argtypes = [vp, C.POINTER(BlockHeader), vp, vp, sz, u64p]
+        L.cz_frame_decoder_scratch.restype = vp
+        L.cz_frame_decoder_scratch.argtypes = [vp]
     _lib = L
     return L

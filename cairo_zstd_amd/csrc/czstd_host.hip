@@ -32,7 +32,7 @@ struct cz_context {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     int num_cu = 0, occupancy = 0, grid_max = 0;
-    uint8_t* lit_scratch = nullptr; uint32_t* work_counter = nullptr;
+    uint8_t* lit_scratch = nullptr; int lit_slots = 0; uint32_t* work_counter = nullptr;
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
     bool exec_kernel = false;              /* frames with chain records run on cz_exec_frames_kernel (one workgroup per CU); off by default:
                                               measured slower than the one-wave record path, DESIGN.md §5 */
@@ -53,6 +53,7 @@ struct cz_context {
 #define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
 
 CZ_EXPORT int cz_abi_version(void) { return CZ_ABI_VERSION; }
+CZ_EXPORT void cz_context_destroy(cz_context* c);
 
 CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     if (!out) return CZ_E_INVALID_ARG;
@@ -71,15 +72,12 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, CZ_FSE_LDS_BYTES) != hipSuccess || occ <= 0) occ = 4;
     c->occupancy = occ; c->grid_max = c->num_cu * occ;
     if (stream) c->stream = (hipStream_t)stream;
-    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CZ_E_HIP; } c->own_stream = true; }
-    const int scratch_slots = c->grid_max;   /* one scratch region per resident workgroup */
-    if (hipMalloc((void**)&c->lit_scratch, (size_t)scratch_slots * CZ_WG_SCRATCH_BYTES) != hipSuccess ||
-        hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = nullptr; delete c; return CZ_E_HIP; } c->own_stream = true; }
+    /* the per-workgroup literal scratch (266 KB each) is allocated by the first launch, for the workgroups it uses */
+    if (hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
         hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || hipEventCreate(&c->ev_mid2) != hipSuccess ||
         hipEventCreate(&c->ev_stop) != hipSuccess) {
-        if (c->lit_scratch) (void)hipFree(c->lit_scratch);
-        if (c->work_counter) (void)hipFree(c->work_counter);
-        delete c; return CZ_E_HIP;
+        cz_context_destroy(c); return CZ_E_HIP;
     }
 #ifdef CZ_PROFILE
     if (hipMalloc((void**)&c->d_prof, 64 * 8) == hipSuccess) (void)hipMemset(c->d_prof, 0, 64 * 8);
@@ -105,7 +103,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
 CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->lit_scratch) (void)hipFree(c->lit_scratch);
     if (c->work_counter) (void)hipFree(c->work_counter);
     if (c->d_stage) (void)hipFree(c->d_stage);
@@ -117,7 +115,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -209,6 +207,12 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
 #ifdef CZ_EXPERIMENT
     if (const char* e = getenv("CZ_GRID_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < grid) grid = g; }
 #endif
+    if (c->lit_slots < grid) {                                          /* one literal scratch region per resident workgroup */
+        if (c->lit_scratch) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->lit_scratch); c->lit_scratch = nullptr; c->lit_slots = 0; }
+        const int slots = grid <= 16 ? 16 : c->grid_max;
+        CZ_HIP(c, hipMalloc((void**)&c->lit_scratch, (size_t)slots * CZ_WG_SCRATCH_BYTES)); c->lit_slots = slots;
+        a.lit_scratch = c->lit_scratch;
+    }
     CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
@@ -352,6 +356,49 @@ CZ_EXPORT int cz_read_block_header(const uint8_t* p, size_t len, cz_block_header
     return CZ_OK;
 }
 
+/* ------------------------------------------------------------------ stream walker */
+/* A .zst stream is a concatenation of zstd frames and skippable frames.  read_frame_header hands a skippable frame
+ * back as the error SkipFrame(magic, length) for the CALLER to skip (src/frame.cairo:160-166); this is that caller:
+ * it cuts the stream into batch entries — one per zstd frame, found by walking the frame's block headers
+ * (block_decoder.cairo:237-321) to its last block and optional checksum — and steps over skippable frames
+ * (8 bytes + length).  Host side, no decoding: the entries go to cz_decode_batch_* in ONE launch. */
+CZ_EXPORT int cz_stream_split(const uint8_t* src, size_t len, cz_stream_entry* entries, size_t cap, size_t* count, size_t* consumed) {
+    if ((!src && len) || !count || (!entries && cap)) return CZ_E_INVALID_ARG;
+    size_t pos = 0, n = 0; int st = CZ_OK;
+    while (pos < len) {
+        cz_frame_header fh; uint64_t detail[2] = {0, 0};
+        const int e = cz_read_frame_header(src + pos, len - pos, &fh, detail);
+        cz_stream_entry ent; memset(&ent, 0, sizeof ent);
+        ent.offset = pos;
+        if (e == CZ_E_FH_SKIP_FRAME) {                                  /* frame.cairo:160-166 */
+            if (len - pos - 8 < detail[1]) { st = CZ_E_BLOCK_TRUNCATED; break; }
+            ent.kind = CZ_STREAM_SKIPPABLE; ent.magic = (uint32_t)detail[0]; ent.length = 8 + detail[1];
+        } else if (e) { st = e; break; }
+        else {
+            size_t p = pos + fh.header_len; uint64_t bound = 0; int bad = 0;
+            for (;;) {
+                cz_block_header bh;
+                const int be = cz_read_block_header(src + p, len - p, &bh);
+                if (be) { bad = be; break; }
+                if (len - p - 3 < bh.content_size) { bad = CZ_E_BLOCK_TRUNCATED; break; }
+                bound += bh.block_type == 2 ? 128u * 1024u : bh.decompressed_size;
+                p += 3 + bh.content_size;
+                if (bh.last_block) break;
+            }
+            if (bad) { st = bad; break; }
+            if ((fh.descriptor >> 2) & 1) { if (len - p < 4) { st = CZ_E_CHECKSUM_TRUNCATED; break; } p += 4; }
+            ent.kind = CZ_STREAM_FRAME; ent.length = p - pos; ent.content_size = fh.frame_content_size; ent.out_bound = bound;
+            ent.window_size = fh.window_size;
+        }
+        if (n < cap) entries[n] = ent;
+        n++; pos += ent.length;
+    }
+    *count = n;
+    if (consumed) *consumed = pos;
+    if (!st && n > cap) return CZ_E_TARGET_TOO_SMALL;                   /* call again with room for *count entries */
+    return st;
+}
+
 /* ------------------------------------------------------------------ XXH64 (frame content checksum) */
 /* src/utils/xxhash64.cairo:20-163.  The reference hashes what DecodeBuffer drains
  * (decode_buffer.cairo:162,181), seed 0; the low 32 bits are compared (frame_decoder.cairo:133-138). */
@@ -391,24 +438,206 @@ struct Xxh64 {
 };
 }  // namespace
 
+/* ------------------------------------------------------------------ DecoderScratch on the device */
+/* DecoderScratch (src/decoding/scratch.cairo:11-67): the per-frame carried state (Huffman table, three FSE tables,
+ * RLE symbols, offset history: cz_device_frame_state in HBM) and the DecodeBuffer (decode_buffer.cairo:9-15).  The
+ * decoded frame stays in HBM; `drained` marks how much the host already collected (buffer.len() == produced - drained)
+ * and `base_off` how many leading frame bytes were dropped from the resident buffer (only drained bytes are ever
+ * dropped, and a match can only reach bytes that are still in the buffer, decode_buffer.cairo:65). */
+struct cz_decoder_scratch {
+    cz_context* ctx = nullptr;
+    uint64_t window_size = 0;
+    uint8_t* d_out = nullptr; size_t d_out_cap = 0; uint64_t base_off = 0; uint64_t produced = 0, drained = 0;
+    Xxh64 hash;
+    uint8_t* d_src = nullptr; size_t d_src_cap = 0;
+    uint8_t* d_ctl = nullptr;   /* [state | state backup | task | result] */
+};
+static const size_t CTL_STATE = 0, CTL_BACKUP = (sizeof(cz_device_frame_state) + 255) & ~(size_t)255,
+                    CTL_TASK = 2 * CTL_BACKUP, CTL_RES = CTL_TASK + 256, CTL_BYTES = CTL_RES + 256;
+
+static int scratch_reset_state(cz_decoder_scratch* s, uint64_t window_size) {      /* scratch.cairo:23-58 */
+    cz_context* c = s->ctx;
+    CZ_HIP(c, hipSetDevice(c->device));
+    cz_device_frame_state init; memset(&init, 0, sizeof init);
+    init.hist[0] = 1; init.hist[1] = 4; init.hist[2] = 8; init.fse_rle[0] = init.fse_rle[1] = init.fse_rle[2] = -1;
+    CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_STATE, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    s->window_size = window_size; s->produced = 0; s->drained = 0; s->base_off = 0; s->hash.reset();
+    return CZ_OK;
+}
+CZ_EXPORT int cz_decoder_scratch_create(cz_context* ctx, uint64_t window_size, cz_decoder_scratch** out) {
+    if (!ctx || !out) return CZ_E_INVALID_ARG;
+    *out = nullptr;
+    cz_decoder_scratch* s = new (std::nothrow) cz_decoder_scratch();
+    if (!s) return CZ_E_INVALID_ARG;
+    s->ctx = ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&s->d_ctl, CTL_BYTES) != hipSuccess) { delete s; return CZ_E_HIP; }
+    const int st = scratch_reset_state(s, window_size);
+    if (st) { (void)hipFree(s->d_ctl); delete s; return st; }
+    *out = s; return CZ_OK;
+}
+CZ_EXPORT int cz_decoder_scratch_reset(cz_decoder_scratch* s, uint64_t window_size) { return s ? scratch_reset_state(s, window_size) : CZ_E_INVALID_ARG; }
+CZ_EXPORT void cz_decoder_scratch_destroy(cz_decoder_scratch* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->d_src) (void)hipFree(s->d_src);
+    if (s->d_ctl) (void)hipFree(s->d_ctl);
+    delete s;
+}
+CZ_EXPORT size_t cz_decoder_scratch_buffer_len(const cz_decoder_scratch* s) { return s ? (size_t)(s->produced - s->drained) : 0; }   /* buffer.len() */
+CZ_EXPORT uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s) { return s ? s->produced : 0; }              /* total_output_counter */
+
+/* Makes room for `need` resident bytes behind base_off, keeping what a match or a drain can still reach:
+ * first drops the drained prefix (compaction), then grows. */
+static int scratch_reserve_out(cz_decoder_scratch* s, size_t need_abs /* frame position the buffer must reach */) {
+    cz_context* c = s->ctx;
+    if (need_abs - s->base_off <= s->d_out_cap) return CZ_OK;
+    /* a fresh buffer for [drained, need_abs): the drained prefix is gone for the reference too */
+    const size_t live = (size_t)(s->produced - s->drained), need = (size_t)(need_abs - s->drained);
+    size_t nc = s->d_out_cap ? s->d_out_cap : (size_t)1 << 20;
+    while (nc < need) nc *= 2;
+    uint8_t* p = nullptr;
+    CZ_HIP(c, hipMalloc((void**)&p, nc));
+    if (s->d_out && live) CZ_HIP(c, hipMemcpyAsync(p, s->d_out + (s->drained - s->base_off), live, hipMemcpyDeviceToDevice, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (s->d_out) (void)hipFree(s->d_out);
+    s->d_out = p; s->d_out_cap = nc; s->base_off = s->drained;
+    return CZ_OK;
+}
+
+/* Uploads `src` (positioned at a block header), runs the kernel on ONE frame task, returns the device's result record. */
+static int scratch_run(cz_decoder_scratch* s, const uint8_t* src, size_t len, uint32_t strategy, uint64_t n, uint32_t streaming,
+                       uint32_t has_checksum, cz_frame_result* res) {
+    cz_context* c = s->ctx;
+    CZ_HIP(c, hipSetDevice(c->device));
+    if (s->d_src_cap < len + 16) {
+        if (s->d_src) (void)hipFree(s->d_src);
+        s->d_src = nullptr; s->d_src_cap = 0;
+        size_t nc = (len + 16 + 65535) & ~(size_t)65535;
+        CZ_HIP(c, hipMalloc((void**)&s->d_src, nc)); s->d_src_cap = nc;
+    }
+    if (len) CZ_HIP(c, hipMemcpyAsync(s->d_src, src, len, hipMemcpyHostToDevice, c->stream));
+    /* output bound: a Raw / RLE block regenerates exactly its size; a compressed block at most 128 KiB in valid
+       data — the reference does not enforce that, so grow and retry on CZ_E_OUTPUT_TOO_SMALL */
+    size_t bound = 0, blocks = 0, pos = 0;
+    while (len - pos >= 3) {
+        cz_block_header bh; if (cz_read_block_header(src + pos, len - pos, &bh)) break;
+        if (pos + 3 + bh.content_size > len) { if (!streaming) bound += bh.block_type == 2 ? 128u * 1024u : bh.decompressed_size; break; }
+        bound += bh.block_type == 2 ? 128u * 1024u : bh.decompressed_size;
+        blocks++; pos += 3 + bh.content_size;
+        if (bh.last_block) break;
+        if (strategy == CZ_STRATEGY_UPTO_BLOCKS && blocks >= n) break;
+        if (strategy == CZ_STRATEGY_UPTO_BYTES && bound >= n + 128u * 1024u) break;
+    }
+    uint64_t want = s->produced + bound + 4096;
+    CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_BACKUP, s->d_ctl + CTL_STATE, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        int st = scratch_reserve_out(s, (size_t)want); if (st) return st;
+        cz_device_task t; memset(&t, 0, sizeof t);
+        t.src = s->d_src; t.src_len = len;
+        t.dst = s->d_out - s->base_off;                                 /* frame position p lives at dst + p (p >= base_off) */
+        t.dst_cap = s->base_off + s->d_out_cap; t.produced = s->produced; t.drained = s->drained;
+        t.window_size = s->window_size; t.strategy = strategy; t.strategy_n = n; t.has_checksum = has_checksum; t.streaming = streaming;
+        t.state = (cz_device_frame_state*)(s->d_ctl + CTL_STATE);
+        CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_TASK, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+        cz_batch_args a; memset(&a, 0, sizeof a);
+        a.tasks = (const cz_device_task*)(s->d_ctl + CTL_TASK); a.results = (cz_frame_result*)(s->d_ctl + CTL_RES);
+        st = cz_launch(c, a, 1); if (st) return st;
+        CZ_HIP(c, hipMemcpyAsync(res, s->d_ctl + CTL_RES, sizeof *res, hipMemcpyDeviceToHost, c->stream));
+        CZ_HIP(c, hipStreamSynchronize(c->stream));
+        if (res->status != CZ_E_OUTPUT_TOO_SMALL) return CZ_OK;
+        /* roll the carried state back and retry with a larger resident buffer */
+        CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_STATE, s->d_ctl + CTL_BACKUP, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
+        want = s->drained + (uint64_t)(s->d_out_cap ? s->d_out_cap : (size_t)1 << 20) * 4;
+    }
+    return CZ_OK;
+}
+/* drain_to (decode_buffer.cairo:168-186): device -> host, hash update, advance */
+static size_t scratch_drain(cz_decoder_scratch* s, size_t amount, uint8_t* dst, size_t cap) {
+    const size_t bl = (size_t)(s->produced - s->drained);
+    size_t n = bl < amount ? bl : amount;
+    if (n > cap) n = cap;
+    if (!n) return 0;
+    cz_context* c = s->ctx;
+    if (hipSetDevice(c->device) != hipSuccess) return 0;
+    if (hipMemcpyAsync(dst, s->d_out + (s->drained - s->base_off), n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    s->hash.update(dst, n);
+    s->drained += n;
+    return n;
+}
+/* DecodeBuffer::drain (decode_buffer.cairo:157-166): everything in the buffer; *written = 0 and CZ_E_TARGET_TOO_SMALL when dst cannot hold it. */
+CZ_EXPORT int cz_decoder_scratch_drain(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written) {
+    if (!s || !written) return CZ_E_INVALID_ARG;
+    *written = 0;
+    const size_t bl = (size_t)(s->produced - s->drained);
+    if (bl > cap) return CZ_E_TARGET_TOO_SMALL;
+    *written = scratch_drain(s, bl, dst, cap);
+    return CZ_OK;
+}
+/* DecodeBuffer::drain_to_window_size (:145-155): what exceeds window_size; returns 1 = Some, 0 = None, < 0 = -status. */
+CZ_EXPORT int cz_decoder_scratch_drain_to_window_size(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written) {
+    if (!s || !written) return -CZ_E_INVALID_ARG;
+    *written = 0;
+    const size_t bl = (size_t)(s->produced - s->drained);
+    if (bl <= s->window_size) return 0;
+    const size_t can = (size_t)(bl - s->window_size);
+    if (can > cap) return -CZ_E_TARGET_TOO_SMALL;
+    *written = scratch_drain(s, can, dst, cap);
+    return 1;
+}
+CZ_EXPORT uint64_t cz_decoder_scratch_hash_digest(const cz_decoder_scratch* s) { return s ? s->hash.digest() : 0; }   /* XXH64 of what was drained */
+
+/* ------------------------------------------------------------------ block decoder */
+/* BlockDecoder (src/decoding/block_decoder.cairo:20-30, :69-137, :237-278): the two-state machine around one block.
+ * The body of a block is always decoded by the device kernel, against the DecoderScratch the caller passes. */
+CZ_EXPORT void cz_block_decoder_new(cz_block_decoder* bd) { if (bd) { bd->internal_state = CZ_BLOCK_READY_FOR_HEADER; bd->header_buffer[0] = bd->header_buffer[1] = bd->header_buffer[2] = 0; } }
+CZ_EXPORT int cz_block_decoder_read_block_header(cz_block_decoder* bd, const uint8_t* src, size_t len, cz_block_header* out, uint8_t* consumed) {
+    if (!bd || !out) return CZ_E_INVALID_ARG;
+    if (consumed) *consumed = 0;
+    if (len < 3 || !src) return CZ_E_BH_TRUNCATED;                      /* (panic) r.slice(0, 3) :240 */
+    bd->header_buffer[0] = src[0]; bd->header_buffer[1] = src[1]; bd->header_buffer[2] = src[2];      /* :241 */
+    if (consumed) *consumed = 3;                                        /* the slice is advanced before the checks (:242) */
+    const int e = cz_read_block_header(src, len, out);
+    if (e) return e;                                                    /* header_buffer keeps the bytes, the state does not move */
+    bd->header_buffer[0] = bd->header_buffer[1] = bd->header_buffer[2] = 0;                            /* reset_buffer :270 */
+    bd->internal_state = CZ_BLOCK_READY_FOR_BODY;                       /* :271 */
+    return CZ_OK;
+}
+CZ_EXPORT int cz_block_decoder_decode_block_content(cz_block_decoder* bd, const cz_block_header* h, cz_decoder_scratch* ws,
+                                                    const uint8_t* src, size_t len, uint64_t* consumed) {
+    if (!bd || !h || !ws || (!src && len)) return CZ_E_INVALID_ARG;
+    if (consumed) *consumed = 0;
+    if (bd->internal_state == CZ_BLOCK_READY_FOR_HEADER) return CZ_E_BLOCK_EXPECTED_HEADER;     /* :86-88 */
+    if (bd->internal_state == CZ_BLOCK_FAILED) return CZ_E_BLOCK_STATE_FAILED;                  /* :90-92 */
+    if (h->block_type > 2) return CZ_E_BH_RESERVED;                                             /* ReservedBlock :134 */
+    const uint32_t size = h->block_type == 1 ? h->decompressed_size : h->content_size;
+    if (len < h->content_size) return CZ_E_BLOCK_TRUNCATED;                                     /* (panic) :98,105,145 */
+    /* the device task walks blocks from their header: put this block's header back in front of its content */
+    std::vector<uint8_t> buf(3 + (size_t)h->content_size);
+    const uint32_t v = (uint32_t)(h->last_block ? 1 : 0) | ((uint32_t)h->block_type << 1) | (size << 3);
+    buf[0] = (uint8_t)v; buf[1] = (uint8_t)(v >> 8); buf[2] = (uint8_t)(v >> 16);
+    if (h->content_size) memcpy(buf.data() + 3, src, h->content_size);
+    cz_frame_result r; memset(&r, 0, sizeof r);
+    const int st = scratch_run(ws, buf.data(), buf.size(), CZ_STRATEGY_UPTO_BLOCKS, 1, 0, 0, &r);
+    if (st) return st;
+    if (r.status) return r.status;                                      /* DecompressBlockError leaves; the state stays ReadyToDecodeNextBody like the reference */
+    ws->produced = r.bytes_produced;
+    bd->internal_state = CZ_BLOCK_READY_FOR_HEADER;                     /* :101,108,131 */
+    if (consumed) *consumed = h->content_size;                          /* :102,122,132 */
+    return CZ_OK;
+}
+
 /* ------------------------------------------------------------------ frame decoder */
 struct cz_frame_decoder {
     cz_context* ctx = nullptr;
     cz_frame_header fh{}; bool initialised = false;
     bool frame_finished = false; size_t block_counter = 0; uint64_t bytes_read_counter = 0;    /* frame_decoder.cairo:22-30 */
     uint32_t check_sum = 0; bool has_check_sum = false;
-    uint64_t window_size = 0;
-    /* DecodeBuffer (decode_buffer.cairo:9-15): the decoded frame stays in HBM; `drained`
-       marks how much the host already collected, so buffer.len() == produced - drained */
-    uint8_t* d_out = nullptr; size_t d_out_cap = 0; uint64_t produced = 0, drained = 0;
-    Xxh64 hash;
-    /* device-side bookkeeping */
-    uint8_t* d_src = nullptr; size_t d_src_cap = 0;
-    uint8_t* d_ctl = nullptr;   /* [state | state backup | task | result] */
-    std::vector<uint8_t> bounce;
+    cz_decoder_scratch* scratch = nullptr;                              /* decoder_scratch (frame_decoder.cairo:25) */
 };
-static const size_t CTL_STATE = 0, CTL_BACKUP = (sizeof(cz_device_frame_state) + 255) & ~(size_t)255,
-                    CTL_TASK = 2 * CTL_BACKUP, CTL_RES = CTL_TASK + 256, CTL_BYTES = CTL_RES + 256;
 
 CZ_EXPORT int cz_frame_decoder_create(cz_context* ctx, cz_frame_decoder** out) {
     if (!ctx || !out) return CZ_E_INVALID_ARG;
@@ -416,16 +645,13 @@ CZ_EXPORT int cz_frame_decoder_create(cz_context* ctx, cz_frame_decoder** out) {
     cz_frame_decoder* fd = new (std::nothrow) cz_frame_decoder();
     if (!fd) return CZ_E_INVALID_ARG;
     fd->ctx = ctx;
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void**)&fd->d_ctl, CTL_BYTES) != hipSuccess) { delete fd; return CZ_E_HIP; }
+    const int st = cz_decoder_scratch_create(ctx, 0, &fd->scratch);
+    if (st) { delete fd; return st; }
     *out = fd; return CZ_OK;
 }
 CZ_EXPORT void cz_frame_decoder_destroy(cz_frame_decoder* fd) {
     if (!fd) return;
-    (void)hipSetDevice(fd->ctx->device);
-    (void)hipStreamSynchronize(fd->ctx->stream);
-    if (fd->d_out) (void)hipFree(fd->d_out);
-    if (fd->d_src) (void)hipFree(fd->d_src);
-    if (fd->d_ctl) (void)hipFree(fd->d_ctl);
+    cz_decoder_scratch_destroy(fd->scratch);
     delete fd;
 }
 
@@ -435,16 +661,11 @@ static int fd_init(cz_frame_decoder* fd, const uint8_t* src, size_t len, size_t*
     int e = cz_read_frame_header(src, len, &fh, detail);                /* frame_decoder.cairo:55-64 / :81-90 */
     if (e) return e;
     if (is_reset && fh.window_size > 1024ull * 1024 * 100) return CZ_E_WINDOW_SIZE_TOO_BIG;     /* :92 (D4: new() has no cap) */
-    cz_context* c = fd->ctx;
-    CZ_HIP(c, hipSetDevice(c->device));
-    /* DecoderScratch::new / reset (scratch.cairo:23-58) */
-    cz_device_frame_state init; memset(&init, 0, sizeof init);
-    init.hist[0] = 1; init.hist[1] = 4; init.hist[2] = 8; init.fse_rle[0] = init.fse_rle[1] = init.fse_rle[2] = -1;
-    CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_STATE, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    CZ_HIP(c, hipStreamSynchronize(c->stream));
-    fd->fh = fh; fd->window_size = fh.window_size; fd->initialised = true;
+    e = scratch_reset_state(fd->scratch, fh.window_size);              /* DecoderScratch::new / reset (scratch.cairo:23-58) */
+    if (e) return e;
+    fd->fh = fh; fd->initialised = true;
     fd->frame_finished = false; fd->block_counter = 0; fd->bytes_read_counter = fh.header_len;
-    fd->check_sum = 0; fd->has_check_sum = false; fd->produced = 0; fd->drained = 0; fd->hash.reset();
+    fd->check_sum = 0; fd->has_check_sum = false;
     if (consumed) *consumed = fh.header_len;
     return CZ_OK;
 }
@@ -453,7 +674,7 @@ CZ_EXPORT int cz_frame_decoder_reset(cz_frame_decoder* fd, const uint8_t* src, s
 
 CZ_EXPORT uint64_t cz_frame_decoder_content_size(const cz_frame_decoder* fd) { return fd ? fd->fh.frame_content_size : 0; }
 CZ_EXPORT int cz_frame_decoder_checksum_from_data(const cz_frame_decoder* fd, uint32_t* v) { if (fd && fd->has_check_sum && v) *v = fd->check_sum; return fd && fd->has_check_sum; }
-CZ_EXPORT uint32_t cz_frame_decoder_calculated_checksum(const cz_frame_decoder* fd) { return fd ? (uint32_t)fd->hash.digest() : 0; }
+CZ_EXPORT uint32_t cz_frame_decoder_calculated_checksum(const cz_frame_decoder* fd) { return fd ? (uint32_t)fd->scratch->hash.digest() : 0; }
 CZ_EXPORT uint64_t cz_frame_decoder_bytes_read_from_source(const cz_frame_decoder* fd) { return fd ? fd->bytes_read_counter : 0; }
 CZ_EXPORT int cz_frame_decoder_is_finished(const cz_frame_decoder* fd) {
     if (!fd) return 0;
@@ -461,75 +682,24 @@ CZ_EXPORT int cz_frame_decoder_is_finished(const cz_frame_decoder* fd) {
     return fd->frame_finished;
 }
 CZ_EXPORT size_t cz_frame_decoder_blocks_decoded(const cz_frame_decoder* fd) { return fd ? fd->block_counter : 0; }
+/* the DecoderScratch of this frame decoder (owned by it), e.g. to decode single blocks against it */
+CZ_EXPORT cz_decoder_scratch* cz_frame_decoder_scratch(cz_frame_decoder* fd) { return fd ? fd->scratch : nullptr; }
 
-static inline size_t fd_buffer_len(const cz_frame_decoder* fd) { return (size_t)(fd->produced - fd->drained); }
+static inline size_t fd_buffer_len(const cz_frame_decoder* fd) { return (size_t)(fd->scratch->produced - fd->scratch->drained); }
 
-/* grows the resident frame buffer, keeping what is already decoded (window reach-back) */
-static int fd_reserve_out(cz_frame_decoder* fd, size_t need) {
-    if (fd->d_out_cap >= need) return CZ_OK;
-    cz_context* c = fd->ctx;
-    size_t nc = fd->d_out_cap ? fd->d_out_cap : (size_t)1 << 20;
-    while (nc < need) nc *= 2;
-    uint8_t* p = nullptr;
-    CZ_HIP(c, hipMalloc((void**)&p, nc));
-    if (fd->d_out && fd->produced) CZ_HIP(c, hipMemcpyAsync(p, fd->d_out, fd->produced, hipMemcpyDeviceToDevice, c->stream));
-    CZ_HIP(c, hipStreamSynchronize(c->stream));
-    if (fd->d_out) (void)hipFree(fd->d_out);
-    fd->d_out = p; fd->d_out_cap = nc;
-    return CZ_OK;
-}
-
-/* Uploads `src`, runs the kernel on ONE frame task, folds the result into the counters. */
-static int fd_run(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint32_t strategy, uint64_t n, uint32_t streaming, cz_frame_result* res) {
-    cz_context* c = fd->ctx;
-    CZ_HIP(c, hipSetDevice(c->device));
-    if (fd->d_src_cap < len + 16) {
-        if (fd->d_src) (void)hipFree(fd->d_src);
-        fd->d_src = nullptr; fd->d_src_cap = 0;
-        size_t nc = (len + 16 + 65535) & ~(size_t)65535;
-        CZ_HIP(c, hipMalloc((void**)&fd->d_src, nc)); fd->d_src_cap = nc;
-    }
-    if (len) CZ_HIP(c, hipMemcpyAsync(fd->d_src, src, len, hipMemcpyHostToDevice, c->stream));
-    /* output bound: every block regenerates at most 128 KiB in valid data; the reference does
-       not enforce that, so grow and retry on CZ_E_OUTPUT_TOO_SMALL */
-    size_t blocks = 0, pos = 0;
-    while (len - pos >= 3) {
-        cz_block_header bh; if (cz_read_block_header(src + pos, len - pos, &bh)) break;
-        blocks++; pos += 3 + bh.content_size;
-        if (bh.last_block || pos > len) break;
-        if (strategy == CZ_STRATEGY_UPTO_BLOCKS && blocks >= n) break;
-    }
-    size_t want = (size_t)fd->produced + (blocks ? blocks : 1) * (128u * 1024u) + 4096;
-    CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_BACKUP, fd->d_ctl + CTL_STATE, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
-    for (int attempt = 0; attempt < 8; attempt++) {
-        int st = fd_reserve_out(fd, want); if (st) return st;
-        cz_device_task t; memset(&t, 0, sizeof t);
-        t.src = fd->d_src; t.src_len = len; t.dst = fd->d_out; t.dst_cap = fd->d_out_cap; t.produced = fd->produced; t.drained = fd->drained;
-        t.window_size = fd->window_size; t.strategy = strategy; t.strategy_n = n; t.has_checksum = (fd->fh.descriptor >> 2) & 1; t.streaming = streaming;
-        t.state = (cz_device_frame_state*)(fd->d_ctl + CTL_STATE);
-        CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_TASK, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
-        cz_batch_args a; memset(&a, 0, sizeof a);
-        a.tasks = (const cz_device_task*)(fd->d_ctl + CTL_TASK); a.results = (cz_frame_result*)(fd->d_ctl + CTL_RES);
-        st = cz_launch(c, a, 1); if (st) return st;
-        CZ_HIP(c, hipMemcpyAsync(res, fd->d_ctl + CTL_RES, sizeof *res, hipMemcpyDeviceToHost, c->stream));
-        CZ_HIP(c, hipStreamSynchronize(c->stream));
-        if (res->status != CZ_E_OUTPUT_TOO_SMALL) return CZ_OK;
-        /* roll the carried state back and retry with a larger resident buffer */
-        CZ_HIP(c, hipMemcpyAsync(fd->d_ctl + CTL_STATE, fd->d_ctl + CTL_BACKUP, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
-        want = fd->d_out_cap * 4;
-    }
-    return CZ_OK;
+static void fd_fold(cz_frame_decoder* fd, const cz_frame_result& r) {
+    fd->bytes_read_counter += r.bytes_consumed; fd->block_counter += r.blocks_decoded; fd->scratch->produced = r.bytes_produced;
+    if (r.flags & CZ_RESULT_FINISHED) fd->frame_finished = true;
+    if (r.flags & CZ_RESULT_HAS_CHECKSUM) { fd->check_sum = r.checksum_from_data; fd->has_check_sum = true; }
 }
 
 CZ_EXPORT int cz_frame_decoder_decode_blocks(cz_frame_decoder* fd, const uint8_t* src, size_t len, cz_strategy strategy, size_t n,
                                              size_t* consumed, int* finished) {
     if (!fd || !fd->initialised || (!src && len)) return CZ_E_INVALID_ARG;
     cz_frame_result r; memset(&r, 0, sizeof r);
-    int st = fd_run(fd, src, len, (uint32_t)strategy, n, 0, &r);       /* frame_decoder.cairo:156-222 */
+    int st = scratch_run(fd->scratch, src, len, (uint32_t)strategy, n, 0, (fd->fh.descriptor >> 2) & 1, &r);       /* frame_decoder.cairo:156-222 */
     if (st) return st;
-    fd->bytes_read_counter += r.bytes_consumed; fd->block_counter += r.blocks_decoded; fd->produced = r.bytes_produced;
-    if (r.flags & CZ_RESULT_FINISHED) fd->frame_finished = true;
-    if (r.flags & CZ_RESULT_HAS_CHECKSUM) { fd->check_sum = r.checksum_from_data; fd->has_check_sum = true; }
+    fd_fold(fd, r);
     if (consumed) *consumed = (size_t)r.bytes_consumed;
     if (finished) *finished = fd->frame_finished;
     return r.status;
@@ -539,20 +709,7 @@ CZ_EXPORT size_t cz_frame_decoder_can_collect(const cz_frame_decoder* fd) {     
     if (!fd) return 0;
     const size_t bl = fd_buffer_len(fd);
     if (cz_frame_decoder_is_finished(fd)) return bl;
-    return bl > fd->window_size ? (size_t)(bl - fd->window_size) : 0;
-}
-/* drain_to (decode_buffer.cairo:168-186): device -> host, hash update, advance */
-static size_t fd_drain(cz_frame_decoder* fd, size_t amount, uint8_t* dst, size_t cap) {
-    size_t n = fd_buffer_len(fd) < amount ? fd_buffer_len(fd) : amount;
-    if (n > cap) n = cap;
-    if (!n) return 0;
-    cz_context* c = fd->ctx;
-    if (hipSetDevice(c->device) != hipSuccess) return 0;
-    if (hipMemcpyAsync(dst, fd->d_out + fd->drained, n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
-    fd->hash.update(dst, n);
-    fd->drained += n;
-    return n;
+    return bl > fd->scratch->window_size ? (size_t)(bl - fd->scratch->window_size) : 0;
 }
 CZ_EXPORT int cz_frame_decoder_collect(cz_frame_decoder* fd, uint8_t* dst, size_t cap, size_t* written) {     /* :224-231 */
     if (!fd || !written) return -CZ_E_INVALID_ARG;
@@ -560,20 +717,15 @@ CZ_EXPORT int cz_frame_decoder_collect(cz_frame_decoder* fd, uint8_t* dst, size_
     const size_t bl = fd_buffer_len(fd);
     if (cz_frame_decoder_is_finished(fd)) {
         if (bl > cap) return -CZ_E_TARGET_TOO_SMALL;
-        *written = fd_drain(fd, bl, dst, cap); return 1;
+        *written = scratch_drain(fd->scratch, bl, dst, cap); return 1;
     }
-    if (bl > fd->window_size) {
-        const size_t can = (size_t)(bl - fd->window_size);
-        if (can > cap) return -CZ_E_TARGET_TOO_SMALL;
-        *written = fd_drain(fd, can, dst, cap); return 1;
-    }
-    return 0;
+    return cz_decoder_scratch_drain_to_window_size(fd->scratch, dst, cap, written);
 }
 CZ_EXPORT size_t cz_frame_decoder_read(cz_frame_decoder* fd, uint8_t* dst, size_t cap) {                     /* :328-334 */
     if (!fd) return 0;
     const size_t bl = fd_buffer_len(fd);
-    const size_t amount = fd->frame_finished ? bl : (bl > fd->window_size ? (size_t)(bl - fd->window_size) : 0);
-    return fd_drain(fd, amount, dst, cap);
+    const size_t amount = fd->frame_finished ? bl : (bl > fd->scratch->window_size ? (size_t)(bl - fd->scratch->window_size) : 0);
+    return scratch_drain(fd->scratch, amount, dst, cap);
 }
 CZ_EXPORT int cz_frame_decoder_decode_from_to(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint8_t* dst, size_t cap,
                                               size_t* read_len, size_t* written) {                           /* :245-326 */
@@ -587,11 +739,9 @@ CZ_EXPORT int cz_frame_decoder_decode_from_to(cz_frame_decoder* fd, const uint8_
             *read_len = 4; return CZ_OK;                                /* (4, 0) even when fewer than 4 bytes were there */
         }
         cz_frame_result r; memset(&r, 0, sizeof r);
-        int st = fd_run(fd, src, len, CZ_STRATEGY_ALL, 0, 1, &r);
+        int st = scratch_run(fd->scratch, src, len, CZ_STRATEGY_ALL, 0, 1, cks, &r);
         if (st) return st;
-        fd->bytes_read_counter += r.bytes_consumed; fd->block_counter += r.blocks_decoded; fd->produced = r.bytes_produced;
-        if (r.flags & CZ_RESULT_FINISHED) fd->frame_finished = true;
-        if (r.flags & CZ_RESULT_HAS_CHECKSUM) { fd->check_sum = r.checksum_from_data; fd->has_check_sum = true; }
+        fd_fold(fd, r);
         if (r.status) return r.status;
     }
     *written = cz_frame_decoder_read(fd, dst, cap);

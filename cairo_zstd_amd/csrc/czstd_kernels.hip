@@ -407,8 +407,9 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
     const uint32_t max_bits = cz_hbs(sum), left = (1u << max_bits) - sum;
     if (left == 0 || (left & (left - 1))) return CZ_E_HUF_LEFTOVER_NOT_POW2;            /* :359 */
     const uint32_t last_w = cz_hbs(left);
-    sh.huf_max_bits = (uint8_t)max_bits;                             /* :383 (set before the check, as the reference) */
-    if (max_bits > 11) return CZ_E_HUF_MAX_BITS_TOO_HIGH;               /* :385 */
+    sh.huf_max_bits = (uint8_t)max_bits;                             /* :383 */
+    if (max_bits > 11) { sh.huf_max_bits = 0; return CZ_E_HUF_MAX_BITS_TOO_HIGH; }   /* :385; the reference leaves the too-large value in its (now unusable)
+                                                                           table; here a resumed decoder must not index a 2^11-entry table with it */
     /* in LDS: arrays indexed by a run-time value would otherwise live in scratch memory, one HBM-backed
        round trip per access of this serial loop */
     uint32_t* rank_cnt = sh.a.t1.rank_cnt; uint32_t* rank_idx = sh.a.t1.rank_idx;
@@ -1538,7 +1539,7 @@ struct CzFrameIO {
 __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 huf_global, CZ_GLOBAL cz_frame_result* res,
                                     cz_gcptr64 arena, uint64_t chain_cursor) {
     CzBroadcast& bc = sh.bc;
-    uint64_t pos = 0; int err = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
+    uint64_t pos = 0; int err = 0, hdr_ok = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
     CZ_PROF_DECL; CZ_PROF_T0();
     if (io.parse_header) {
         if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(io.src, io.src_len, bc); }
@@ -1569,6 +1570,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         const uint32_t btype = cz_uni(bc.btype), bsize = cz_uni(bc.bsize), blast = cz_uni(bc.blast);
         __syncthreads();
         if (err) break;
+        hdr_ok = 1;
         const uint64_t body = pos + 3, avail = io.src_len - body;
         const uint32_t content = btype == 1 ? 1u : bsize;
         if (io.streaming && avail < content) break;                     /* frame_decoder.cairo:282 */
@@ -1589,7 +1591,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         }
         __syncthreads();
         if (btype != 2) CZ_PROF_ACC(CZ_P_RAWRLE);
-        pos = body + content; blocks++;
+        pos = body + content; blocks++; hdr_ok = 0;
         if (blast) {                                                    /* frame_decoder.cairo:189-200 / :300-312 */
             flags |= CZ_RESULT_FINISHED;
             if (io.has_checksum) {
@@ -1604,6 +1606,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         if (io.strategy == 1 && blocks >= io.strategy_n) break;         /* :204-208 */
         if (io.strategy == 2 && x.produced - produced0 >= io.strategy_n) break;         /* :209-213 */
     }
+    if (err && hdr_ok) pos += 3;                                         /* the reference counts the 3 header bytes before it decodes the body (frame_decoder.cairo:172) */
     uint32_t calc = 0;
     if (io.verify && !err && (flags & CZ_RESULT_HAS_CHECKSUM) && io.produced == 0) {
         /* get_calculated_checksum == get_checksum_from_data (src/tests/decoding.cairo:16-19), on the device */

@@ -152,6 +152,62 @@ typedef struct cz_block_header {
 } cz_block_header;
 int cz_read_block_header(const uint8_t* src, size_t len, cz_block_header* out);
 
+/* ------------------------------------------------- stream walker */
+/* read_frame_header returns a skippable frame to its caller as the error SkipFrame(magic, length)
+ * (src/frame.cairo:160-166); cz_stream_split is that caller for a stream of concatenated frames: it cuts the stream
+ * into one entry per zstd frame (its end found by walking the block headers, no decoding) and steps over skippable
+ * frames, so that a multi-frame .zst goes through cz_decode_batch_* in one launch. */
+typedef struct cz_stream_entry {
+    uint64_t offset, length;      /* bytes of the stream this entry covers */
+    uint32_t kind;                /* CZ_STREAM_FRAME or CZ_STREAM_SKIPPABLE */
+    uint32_t magic;               /* skippable frame: its magic number (0x184D2A50..5F) */
+    uint64_t content_size;        /* zstd frame: frame_content_size of its header (0 when absent) */
+    uint64_t out_bound;           /* zstd frame: Raw / RLE sizes + 128 KiB per compressed block: an output capacity that
+                                     holds every frame the zstd format allows (the reference accepts larger blocks: D3) */
+    uint64_t window_size;
+} cz_stream_entry;
+#define CZ_STREAM_FRAME 0u
+#define CZ_STREAM_SKIPPABLE 1u
+/* Fills entries[0 .. min(*count, cap)); *count = entries in the stream, *consumed = bytes they cover.  Returns CZ_OK
+ * when the whole stream was cut up, CZ_E_TARGET_TOO_SMALL when cap < *count, or the status of the header that could
+ * not be read (the entries before it are valid). */
+int cz_stream_split(const uint8_t* src, size_t len, cz_stream_entry* entries, size_t cap, size_t* count, size_t* consumed);
+
+/* ------------------------------------------------- block level (BlockDecoder + DecoderScratch) */
+/* DecoderScratch (src/decoding/scratch.cairo:11-67): the state a frame carries from block to block — Huffman
+ * table, three FSE tables + RLE symbols, offset history (1, 4, 8) — and its DecodeBuffer
+ * (src/decoding/decode_buffer.cairo:9-15).  Both live in HBM; the handle is the `ref workspace: DecoderScratch` of
+ * decode_block_content.  Only the last window_size bytes plus what was not drained yet stay resident. */
+typedef struct cz_decoder_scratch cz_decoder_scratch;
+int  cz_decoder_scratch_create(cz_context* ctx, uint64_t window_size, cz_decoder_scratch** out);   /* DecoderScratchTrait::new, scratch.cairo:23-40 */
+int  cz_decoder_scratch_reset(cz_decoder_scratch* s, uint64_t window_size);                        /* reset, scratch.cairo:42-58 */
+void cz_decoder_scratch_destroy(cz_decoder_scratch* s);
+size_t cz_decoder_scratch_buffer_len(const cz_decoder_scratch* s);                                 /* buffer.len() */
+uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s);                             /* buffer.total_output_counter */
+/* DecodeBuffer::drain (decode_buffer.cairo:157-166): moves the whole buffer to dst and feeds the XXH64 state. */
+int  cz_decoder_scratch_drain(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written);
+/* DecodeBuffer::drain_to_window_size (:145-155): 1 = Some (bytes beyond window_size moved), 0 = None, < 0 = -cz_status. */
+int  cz_decoder_scratch_drain_to_window_size(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written);
+uint64_t cz_decoder_scratch_hash_digest(const cz_decoder_scratch* s);                              /* buffer.hash.digest(): XXH64 of what was drained */
+
+/* BlockDecoder (src/decoding/block_decoder.cairo:20-30): a plain value like the reference's struct. */
+typedef struct cz_block_decoder {
+    uint8_t internal_state;       /* DecoderState, block_decoder.cairo:26-30 */
+    uint8_t header_buffer[3];
+} cz_block_decoder;
+#define CZ_BLOCK_READY_FOR_HEADER 0   /* ReadyToDecodeNextHeader */
+#define CZ_BLOCK_READY_FOR_BODY   1   /* ReadyToDecodeNextBody */
+#define CZ_BLOCK_FAILED           2   /* Failed (never set by the reference either, block_decoder.cairo:26-30) */
+void cz_block_decoder_new(cz_block_decoder* bd);                                                   /* BlockDecoderTrait::new, :71-75 */
+/* read_block_header (:237-278): *consumed = 3 once three bytes were there; moves the state to ReadyToDecodeNextBody. */
+int  cz_block_decoder_read_block_header(cz_block_decoder* bd, const uint8_t* src, size_t len, cz_block_header* out, uint8_t* consumed);
+/* decode_block_content (:77-137): decodes the body of the block `header` describes from src (positioned just behind the
+ * header) into the workspace's DecodeBuffer, on the device.  *consumed = bytes of src the block took (Raw: its size,
+ * RLE: 1, Compressed: content_size).  Errors: CZ_E_BLOCK_EXPECTED_HEADER / CZ_E_BLOCK_STATE_FAILED (state machine),
+ * CZ_E_BH_RESERVED, or the DecompressBlockError leaf. */
+int  cz_block_decoder_decode_block_content(cz_block_decoder* bd, const cz_block_header* header, cz_decoder_scratch* workspace,
+                                           const uint8_t* src, size_t len, uint64_t* consumed);
+
 /* ------------------------------------------- 3. resumable single-frame decoder */
 /* FrameDecoder / FrameDecoderState (src/frame_decoder.cairo:17-30).  Source and target are
  * HOST buffers (as the reference's ByteArraySlice / ByteArray are); decoding runs on the
@@ -188,6 +244,8 @@ size_t cz_frame_decoder_can_collect(const cz_frame_decoder* fd);                
 int  cz_frame_decoder_collect(cz_frame_decoder* fd, uint8_t* dst, size_t cap, size_t* written);
 /* read (:328-334); returns bytes moved. */
 size_t cz_frame_decoder_read(cz_frame_decoder* fd, uint8_t* dst, size_t cap);
+/* FrameDecoderState.decoder_scratch (:25): the frame decoder's own DecoderScratch (owned by the frame decoder). */
+cz_decoder_scratch* cz_frame_decoder_scratch(cz_frame_decoder* fd);
 /* decode_from_to (:245-326): (*read_len, *written) = (source bytes consumed, target bytes produced). */
 int  cz_frame_decoder_decode_from_to(cz_frame_decoder* fd, const uint8_t* src, size_t len, uint8_t* dst, size_t cap,
                                      size_t* read_len, size_t* written);

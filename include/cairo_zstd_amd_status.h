@@ -46,6 +46,7 @@ typedef enum cz_status {
     CZ_E_BH_TRUNCATED = 22,        /* (panic) r.slice(0,3) on <3 bytes block_decoder.cairo:240 */
 
     /* DecodeBlockContentError — block_decoder.cairo:60-65 */
+    CZ_E_BLOCK_STATE_FAILED = 24,    /* DecoderStateIsFailed          block_decoder.cairo:91 */
     CZ_E_BLOCK_EXPECTED_HEADER = 25, /* ExpectedHeaderOfPreviousBlock block_decoder.cairo:87 */
     CZ_E_BLOCK_TRUNCATED = 26,     /* (panic) body slice out of range block_decoder.cairo:98,105,145 */
     CZ_E_CHECKSUM_TRUNCATED = 27,  /* (panic) source.slice(0,4)       frame_decoder.cairo:192 */

@@ -69,3 +69,42 @@ def test_block_header_parser():
     assert cz.read_block_header(bytes([0x08, 0x00, 0x10]))[0] == cz.status.CZ_E_BH_SIZE_TOO_LARGE   # 131073
     assert cz.read_block_header(bytes([0x00, 0x00, 0x10]))[0] == 0                                   # 131072 is allowed
     assert cz.read_block_header(b"\x00\x00")[0] == cz.status.CZ_E_BH_TRUNCATED
+
+
+def test_stream_split_walks_frames_and_skippable_frames():
+    """cz_stream_split (host side): the caller's half of SkipFrame (src/frame.cairo:160-166)."""
+    pairs = corpus_pairs(max_orig=3000)[:4]
+    skip = bytes.fromhex("5a2a4d18") + (5).to_bytes(4, "little") + b"hello"
+    parts = [pairs[0][1], skip, pairs[1][1], pairs[2][1], skip, skip, pairs[3][1]]
+    data = b"".join(parts)
+    st, ents, consumed = cz.stream_split(data)
+    assert st == 0 and consumed == len(data) and len(ents) == len(parts)
+    pos = 0
+    for e, p in zip(ents, parts):
+        assert int(e["offset"]) == pos and int(e["length"]) == len(p)
+        assert int(e["kind"]) == (cz.STREAM_SKIPPABLE if p is skip else cz.STREAM_FRAME)
+        pos += len(p)
+    assert all(int(e["magic"]) == 0x184D2A5A for e in ents if int(e["kind"]) == cz.STREAM_SKIPPABLE)
+    for e, (name, z, orig) in zip(ents[ents["kind"] == cz.STREAM_FRAME], pairs):
+        assert int(e["out_bound"]) >= len(orig)
+    # a cut inside the last frame: the entries before it stay valid, the status says what could not be read
+    st, ents2, consumed2 = cz.stream_split(data[:-3])
+    assert st == cz.status.CZ_E_CHECKSUM_TRUNCATED and len(ents2) == len(parts) - 1 and consumed2 == len(data) - len(parts[-1])
+    st, ents3, _ = cz.stream_split(data + b"\x00\x01\x02\x03\x04")
+    assert st == cz.status.CZ_E_FH_BAD_MAGIC and len(ents3) == len(parts)
+    assert cz.stream_split(b"")[0] == 0
+    # a skippable frame that claims more bytes than there are
+    assert cz.stream_split(bytes.fromhex("502a4d18") + (9).to_bytes(4, "little") + b"abc")[0] == cz.status.CZ_E_BLOCK_TRUNCATED
+
+
+def test_block_decoder_state_machine_without_a_device():
+    """BlockDecoder's two-state machine (src/decoding/block_decoder.cairo:26-30, :86-93, :271) is host logic."""
+    bd = cz.BlockDecoder()
+    assert bd.internal_state == cz.BlockDecoder.READY_FOR_HEADER
+    st, bh, used = bd.read_block_header(bytes([0b110, 0, 0]))            # Reserved
+    assert st == cz.status.CZ_E_BH_RESERVED and used == 3 and bd.internal_state == cz.BlockDecoder.READY_FOR_HEADER
+    st, bh, used = bd.read_block_header(b"\x00\x00")
+    assert st == cz.status.CZ_E_BH_TRUNCATED and used == 0
+    st, bh, used = bd.read_block_header(bytes([0b010 | (5 << 3), 0, 0]))  # RLE, size 5
+    assert st == 0 and used == 3 and bd.internal_state == cz.BlockDecoder.READY_FOR_BODY
+    assert (bh.block_type, bh.content_size, bh.decompressed_size) == (1, 1, 5)

@@ -298,6 +298,120 @@ def test_chain_prepass_matches_oracle(cz, arena_mb):
         c.close()
 
 
+def test_decode_stream_multi_frame_with_skippable_frames(cz, ctx):
+    """A multi-frame .zst with skippable frames in between goes through ONE batch launch (cz_stream_split +
+    cz_decode_batch_host); src/frame.cairo:160-166 leaves the skipping to the caller."""
+    pairs = corpus_pairs(max_orig=70000)[::5]
+    skip = bytes.fromhex("532a4d18") + (11).to_bytes(4, "little") + b"not a frame"
+    data, want = b"", b""
+    for i, (name, z, orig) in enumerate(pairs):
+        data += z + (skip if i % 3 == 0 else b"")
+        want += orig
+    assert cz.decode_stream(data, ctx) == want
+    with pytest.raises(cz.CzError):
+        cz.decode_stream(data[:-2], ctx)
+
+
+def test_block_decoder_walks_frames_block_by_block(cz, ctx):
+    """BlockDecoder::read_block_header + decode_block_content (src/decoding/block_decoder.cairo:237-278, :77-137)
+    against a DecoderScratch on the device, one block per call, next to the oracle's frame decoder stepping one block;
+    the first block also against the oracle's fresh-scratch single-block entry."""
+    for name, z, orig in corpus_pairs()[3::7]:
+        st, fh, _ = cz.read_frame_header(z)
+        assert st == 0
+        ws = cz.DecoderScratch(ctx, fh.window_size)
+        bd = cz.BlockDecoder()
+        od = oracle.FrameDecoder()
+        od.new(z)
+        pos, out, first = fh.header_len, b"", True
+        assert bd.decode_block_content(cz.BlockHeader(), ws, b"")[0] == cz.status.CZ_E_BLOCK_EXPECTED_HEADER   # :86-88
+        while True:
+            st, bh, used = bd.read_block_header(z[pos:])
+            assert st == 0 and used == 3, name
+            st, took = bd.decode_block_content(bh, ws, z[pos + 3:])
+            ost, oused, ofin = od.decode_blocks(z[pos:], oracle.FrameDecoder.UPTO_BLOCKS, 1)
+            assert st == 0 == ost and 3 + took == oused - (4 if ofin and (fh.descriptor >> 2) & 1 else 0), (name, pos)
+            assert bd.internal_state == cz.BlockDecoder.READY_FOR_HEADER
+            if first:
+                fst, fout, fused = oracle.decode_single_block(z[pos:], cap=len(orig) + 64, window=int(fh.window_size))
+                assert fst == 0 and fused == 3 + took and ws.buffer_len() == len(fout), name
+                first = False
+            assert ws.total_output() == len(out) + ws.buffer_len()
+            pos += 3 + took
+            part = ws.drain_to_window_size(cap=len(orig) + 64)
+            out += part or b""
+            od.collect(cap=len(orig) + 64)
+            if bh.last_block:
+                break
+        out += ws.drain(cap=len(orig) + 64)
+        assert out == orig, name
+        assert ws.hash_digest() == oracle.xxh64(orig), name
+        ws.close()
+
+
+def test_many_tiny_blocks_stream_through_decode_from_to(cz, ctx):
+    """A frame of thousands of small Raw / RLE blocks fed in slices: the resident output stays bounded (exact sizes
+    for Raw / RLE, drained bytes are dropped) and the result equals the oracle's."""
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, 400_000, dtype=np.uint8).tobytes()
+    frame = bytearray(b"\x28\xb5\x2f\xfd" + bytes([0x04, 0x00]))          # checksum flag, window 1 KiB
+    pos, nblk = 0, 0
+    while pos < len(data):
+        n = int(rng.integers(1, 200))
+        chunk = data[pos:pos + n]
+        last = pos + n >= len(data)
+        if nblk % 5 == 4:                                                     # an RLE block now and then
+            chunk = bytes([chunk[0]]) * len(chunk)
+            data = data[:pos] + chunk + data[pos + len(chunk):]
+            v = (1 if last else 0) | (1 << 1) | (len(chunk) << 3)
+            frame += bytes([v & 255, (v >> 8) & 255, (v >> 16) & 255]) + chunk[:1]
+        else:
+            v = (1 if last else 0) | (len(chunk) << 3)
+            frame += bytes([v & 255, (v >> 8) & 255, (v >> 16) & 255]) + chunk
+        pos += len(chunk)
+        nblk += 1
+    frame += (oracle.xxh64(data) & 0xFFFFFFFF).to_bytes(4, "little")
+    z = bytes(frame)
+    assert nblk > 3000
+    fd, od = cz.FrameDecoder(ctx), oracle.FrameDecoder()
+    st, hl, _ = fd.new(z)
+    od.new(z)
+    assert st == 0
+    p, out, guard = hl, b"", 0
+    while not fd.is_finished() and guard < 500:
+        guard += 1
+        chunk = z[p:p + 50_000]
+        a = fd.decode_from_to(chunk, cap=len(data) + 64)
+        b = od.decode_from_to(chunk, cap=len(data) + 64)
+        assert a == b and a[0] == 0, guard
+        p += a[1]
+        out += a[2]
+    out += fd.decode_from_to(b"", cap=len(data) + 64)[2]
+    assert out == data and fd.get_calculated_checksum() == fd.get_checksum_from_data() == oracle.xxh64(data) & 0xFFFFFFFF
+    fd.close()
+
+
+def test_bytes_read_counter_after_a_failed_block(cz, ctx):
+    """frame_decoder.cairo:172: the 3 header bytes of the block whose body fails are already counted."""
+    name, z, orig = [p for p in corpus_pairs(max_orig=20000) if len(p[1]) > 300][0]
+    for cut in (len(z) - 9, len(z) // 2):
+        a = bytearray(z)
+        a[cut] ^= 0x55
+        bad = bytes(a)
+        fd, od = cz.FrameDecoder(ctx), oracle.FrameDecoder()
+        st, hl, _ = fd.new(bad)
+        ost, ohl, _ = od.new(bad)
+        assert (st, hl) == (ost, ohl)
+        if st:
+            continue
+        ra = fd.decode_blocks(bad[hl:])
+        rb = od.decode_blocks(bad[hl:])
+        assert ra[0] == rb[0]
+        assert fd.bytes_read_from_source() == od.bytes_read_from_source(), (cut, ra, rb)
+        assert fd.blocks_decoded() == od.blocks_decoded()
+        fd.close()
+
+
 def _large_corpus():
     m = json.load(open(os.path.join(GOLDEN, "decode_corpus_manifest.json")))
     d = os.path.join(GOLDEN, "decode_corpus_large")
