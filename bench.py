@@ -61,22 +61,53 @@ def _spawn_ranks(n: int, backend: str) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _kernel_source_hash() -> str:
+    """sha256 over the kernel sources: profiles/ files carry it, so a PMC measurement is only quoted for the code it was made on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cairo_zstd_amd", "csrc")
+    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_exec.hip", "czstd_host.hip", "czstd_types.h"):
+        h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _libzstd():
+    """ZSTD_decompress from the host's libzstd.so.1 when there is one (a second, stronger CPU baseline on spec-valid configs)."""
+    import ctypes
+    for name in ("libzstd.so.1", "libzstd.so"):
+        try:
+            L = ctypes.CDLL(name)
+            L.ZSTD_decompress.restype = ctypes.c_size_t
+            L.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+            L.ZSTD_isError.restype = ctypes.c_uint
+            L.ZSTD_isError.argtypes = [ctypes.c_size_t]
+            L.ZSTD_versionNumber.restype = ctypes.c_uint
+            return L
+        except OSError:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="full_4a", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU")
-    ap.add_argument("--gather", action="store_true", help="include an RCCL gather of the decoded arenas to rank 0 in the step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default 10000; 12500 for mix = BASELINE config 5 at 8 GPUs)")
+    ap.add_argument("--gather", action="store_true", help="also time the step with an RCCL gather of the decoded arenas to rank 0 (reported separately)")
+    ap.add_argument("--no-balance", action="store_true", help="mix on N > 1: keep every rank's contiguous slice instead of dealing frames by algorithmic bytes")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
-    ap.add_argument("--verify", type=int, default=16, help="frames per rank checked against the oracle after the run")
+    ap.add_argument("--no-verify-all", action="store_true", help="check only a sample of the frames against the oracle (default: every frame, by XXH64)")
     ap.add_argument("--no-chain-prepass", action="store_true", help="run the FSE chains inside cz_decode_frames_kernel (single launch)")
+    ap.add_argument("--exec-kernel", action="store_true", help="execute pre-passed frames on cz_exec_frames_kernel (LDS ring, one workgroup per frame)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 12500 if args.workload == "mix" else 10000
 
     # ---- --gpus N without a launcher: start the N ranks ourselves (torch.distributed.run, one
     # process per GPU) BEFORE anything in this process touches the GPU, and exit with their code.
@@ -104,7 +135,7 @@ def main():
     local_dev = local_rank % ngpu
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # device of the tiny control tensors
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")     # device of the control tensors / exchanged bytes
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -112,6 +143,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import cairo_zstd_amd as cz
+    import oracle
     from cairo_zstd_amd import dist as czdist
     from cairo_zstd_amd import synth
 
@@ -121,6 +153,13 @@ def main():
     t0 = time.time()
     batch = synth.generate(args.workload, F, first_index=czdist.shard_first_index(F, rank), nthreads=max(1, min(32, ncpu // max(1, min(world, 8)))))
     gen_s = time.time() - t0
+    balanced = False
+    if world > 1 and args.workload == "mix" and not args.no_balance:
+        # BASELINE config 5: the global batch is dealt to the GPUs by algorithmic bytes (one exchange of compressed bytes, untimed)
+        nb, noff, nlen, nregen, _ = czdist.rebalance_frames(batch.base, batch.off, batch.length, batch.regen, cdev)
+        batch = synth.Batch(nb, noff, nlen, nregen)
+        balanced = True
+    F = batch.n
     out_off, out_cap, out_total = batch.out_layout(256)
     alg_bytes = int(batch.length.sum() + batch.regen.sum())       # compressed bytes read once + decoded bytes written once
     regen_bytes = int(batch.regen.sum())
@@ -137,65 +176,99 @@ def main():
     # the FSE-chain pre-pass pays for long chains in large blocks (configs 4a/4b); on short, irregular
     # blocks (mix) and on blocks without sequences it is measured slower than in-kernel chains
     chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b")
+    arena_bytes = int(batch.length.sum()) * 6 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
     if chain_prepass:
-        ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20))      # 8 B per sequence + 32 B per block
+        ctx.set_chain_arena(arena_bytes)
+        ctx.set_exec_kernel(args.exec_kernel)
 
-    gather_bufs = None
-    if args.gather and world > 1:
-        sizes = czdist.all_sizes(out_total, cdev)
-        if rank == 0:
-            gather_bufs = [torch.empty(sz, dtype=torch.uint8, device=cdev) for sz in sizes]
-
-    def step():
+    def decode():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
                                 t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
-        if args.gather and world > 1:
-            czdist.gather_to_root(t_out if args.dist_backend == "nccl" else t_out.cpu(), gather_bufs, 0)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(step_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        barrier()
+        t_begin = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        barrier()
+        return time.perf_counter() - t_begin
+
+    elapsed = timed(decode)
     # Per-launch kernel durations for the roofline: K more launches of the same step, each read
     # from the hipEvent pair the library records around the kernel on the stream it runs on
     # (reading a pair needs a sync, which must stay out of the timed region above).
-    kernel_ms, chain_ms = [], []
+    kernel_ms, chain_ms, exec_ms = [], [], []
     for _ in range(args.steps):
-        ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
-                                t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
+        decode()
         kernel_ms.append(ctx.last_kernel_ms())
         chain_ms.append(ctx.last_chain_ms())
+        exec_ms.append(ctx.last_exec_ms())
     torch.cuda.synchronize()
 
-    # ---- correctness gate: every frame OK + sizes; a sample bit-exact against the oracle
+    # ---- decode + gather (config 5's exchange step), timed separately
+    gather_leg = None
+    if args.gather and world > 1:
+        sizes = czdist.all_sizes(out_total, cdev)
+        gather_bufs = [torch.empty(sz, dtype=torch.uint8, device=cdev) for sz in sizes] if rank == 0 else None
+
+        def decode_and_gather():
+            decode()
+            czdist.gather_to_root(t_out if args.dist_backend == "nccl" else t_out.cpu(), gather_bufs, 0)
+
+        g_elapsed = czdist.max_over_ranks(timed(decode_and_gather), cdev)
+        gather_leg = {"ms_per_step": g_elapsed / args.steps * 1e3, "gathered_bytes_per_step": int(sum(sizes) - sizes[0]),
+                      "call": "torch.distributed.batch_isend_irecv: every rank isend()s its decoded arena straight to rank 0 (RCCL ncclSend/ncclRecv group over xGMI)"}
+        del gather_bufs
+
+    # ---- correctness gate: ONE more launch into a poisoned output buffer (a match that read its source before it was
+    # written would now find 0xA5, not the previous pass's bytes); every frame OK + sizes; every frame bit-exact
+    # against the CPU oracle by XXH64 (the oracle pass is also the cpu_baseline measurement)
+    t_out.fill_(0xA5)
+    t_res.zero_()
+    torch.cuda.synchronize()
+    decode()
+    torch.cuda.synchronize()
     res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
     ok = bool((res["status"] == 0).all() and (res["bytes_produced"] == batch.regen).all())
-    verified = 0
-    if args.verify:
-        import oracle
-        out_host = t_out.cpu().numpy()
-        for i in np.linspace(0, F - 1, num=min(args.verify, F), dtype=np.int64):
-            st, ref, _ = oracle.decode_frame(batch.frame(int(i)), cap=int(batch.regen[i]) + 16)
-            got = out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])].tobytes()
-            ok = ok and st == 0 and got == ref
+    out_host = t_out.cpu().numpy()
+    verified, cpu_leg = 0, None
+    threads = ncpu
+    if not args.no_verify_all:
+        t1 = time.perf_counter()
+        ref, olen, ost = oracle.decode_batch(batch.base, batch.off, batch.length, out_off, out_cap, out_total, nthreads=threads)
+        oracle_s = time.perf_counter() - t1
+        ok = ok and bool((ost == 0).all() and (olen == batch.regen).all())
+        for i in range(F):
+            lo, hi = int(out_off[i]), int(out_off[i] + batch.regen[i])
+            if oracle.xxh64(out_host[lo:hi]) != oracle.xxh64(ref[lo:hi]):
+                ok = False
+                break
             verified += 1
-        del out_host
+        cpu_leg = {"value": regen_bytes / oracle_s / 1e6, "unit": "MB/s", "cores": threads, "kind": "port",
+                   "sample": f"one pass over this rank's whole batch ({F} frames, {regen_bytes / 1e6:.0f} MB decoded), oracle/zstd_oracle.c (C restatement of "
+                             f"the reference), {threads} pthreads, one frame per task, {oracle_s:.2f} s wall"}
+        del ref
+    else:
+        for i in np.linspace(0, F - 1, num=min(16, F), dtype=np.int64):
+            st, r1, _ = oracle.decode_frame(batch.frame(int(i)), cap=int(batch.regen[i]) + 16)
+            got = out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])].tobytes()
+            ok = ok and st == 0 and got == r1
+            verified += 1
 
     if world > 1:
         elapsed = czdist.max_over_ranks(elapsed, cdev)
-        regen_all, alg_all, ok_cnt = czdist.sum_over_ranks([regen_bytes, alg_bytes, 1.0 if ok else 0.0], cdev)
+        regen_all, alg_all, ok_cnt, frames_all = czdist.sum_over_ranks([regen_bytes, alg_bytes, 1.0 if ok else 0.0, F], cdev)
         ok_all = int(ok_cnt) == world
+        k_ms_all = czdist.max_over_ranks(float(np.mean(kernel_ms)), cdev)
     else:
-        regen_all, alg_all, ok_all = float(regen_bytes), float(alg_bytes), ok
+        regen_all, alg_all, ok_all, frames_all, k_ms_all = float(regen_bytes), float(alg_bytes), ok, F, float(np.mean(kernel_ms))
 
     # ---- the other single-GPU BASELINE configs, measured after the timed region (N=1 only): same
     # step definition, fewer steps; reported under "other_workloads" so the line shows every config
@@ -213,72 +286,68 @@ def main():
         torch.cuda.synchronize()
         copy_ceiling = 2.0 * a.numel() * 5 / (time.perf_counter() - t1) / 1e9
         del a, b2
-        for wl in ("raw_rle", "huf_literals", "full_4a"):
+        for wl in ("raw_rle", "huf_literals", "full_4a", "mix"):
             if wl == args.workload:
                 continue
-            # the chain pre-pass only pays for frames that have sequences sections
-            ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20) if wl in ("full_4a", "full_4b") and not args.no_chain_prepass else 0)
-            ob = synth.generate(wl, F, nthreads=max(1, min(32, ncpu)))
+            nf = 12500 if wl == "mix" else 10000
+            # the chain pre-pass only pays for frames with long sequences sections
+            ob = synth.generate(wl, nf, nthreads=max(1, min(32, ncpu)))
+            ctx.set_chain_arena(int(ob.length.sum()) * 6 + (64 << 20) if wl in ("full_4a", "full_4b") and not args.no_chain_prepass else 0)
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)
             td = [torch.from_numpy(x.astype(np.int64)).to(dev) for x in (ob.off, ob.length, o_off, o_cap)]
             to = torch.empty(o_total, dtype=torch.uint8, device=dev)
-            tr = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            tr = torch.zeros(nf * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             ms = []
             for it in range(3):
-                ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), F, to.data_ptr(), td[2].data_ptr(),
+                ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, to.data_ptr(), td[2].data_ptr(),
                                         td[3].data_ptr(), tr.data_ptr())
                 ms.append(ctx.last_kernel_ms())
             r2 = tr.cpu().numpy().view(cz.RESULT_DTYPE)
             okw = bool((r2["status"] == 0).all() and (r2["bytes_produced"] == ob.regen).all())
             ab = int(ob.length.sum() + ob.regen.sum())
             k = float(np.mean(ms[1:]))
-            others[wl] = {"decompressed_MBps": float(ob.regen.sum()) / (k * 1e-3) / 1e6, "kernel_ms": k,
+            others[wl] = {"frames": nf, "decompressed_MBps": float(ob.regen.sum()) / (k * 1e-3) / 1e6, "kernel_ms": k,
                           "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "all_frames_ok": okw}
             del ti, td, to, tr
+        ctx.set_chain_arena(arena_bytes if chain_prepass else 0)
 
     # ---- the same batch with a content checksum on every frame, XXH64 computed and
     # compared inside cz_decode_frames_kernel (N=1 only, after the timed region)
     cksum_leg = None
     if world == 1 and not args.no_other_workloads:
-        try:
-            import xxhash
-        except ImportError:
-            xxhash = None
-        if xxhash is not None:
-            out_host = t_out.cpu().numpy()
-            n_len = batch.length.astype(np.int64) + 4
-            n_off = np.concatenate(([0], np.cumsum((n_len + 15) & ~15)[:-1])).astype(np.int64)
-            nb = np.zeros(int(n_off[-1] + n_len[-1]) + 16, dtype=np.uint8)
-            for i in range(F):
-                o, l, d = int(batch.off[i]), int(batch.length[i]), int(n_off[i])
-                nb[d:d + l] = batch.base[o:o + l]
-                nb[d + 4] |= 4                                            # Content_Checksum_flag
-                h = xxhash.xxh64_intdigest(out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])]) & 0xFFFFFFFF
-                nb[d + l:d + l + 4] = np.frombuffer(h.to_bytes(4, "little"), np.uint8)
-            del out_host
-            ti = torch.from_numpy(nb).to(dev)
-            tno, tnl = torch.from_numpy(n_off).to(dev), torch.from_numpy(n_len).to(dev)
-            ctx.set_chain_arena(int(batch.length.sum()) * 6 + (64 << 20) if chain_prepass else 0)
-            ctx.set_verify_checksum(True)
-            ms = []
-            for it in range(4):
-                ctx.decode_batch_device(ti.data_ptr(), tno.data_ptr(), tnl.data_ptr(), F, t_out.data_ptr(), t_ooff.data_ptr(),
-                                        t_ocap.data_ptr(), t_res.data_ptr())
-                ms.append(ctx.last_kernel_ms())
-            ctx.set_verify_checksum(False)
-            r2 = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
-            want = cz.RESULT_FINISHED | cz.RESULT_HAS_CHECKSUM | cz.RESULT_CHECKSUM_COMPUTED | cz.RESULT_CHECKSUM_MATCH
-            k = float(np.mean(ms[1:]))
-            cksum_leg = {"kernel_ms": k, "decompressed_MBps": regen_bytes / (k * 1e-3) / 1e6,
-                         "all_frames_ok_and_checksums_match": bool((r2["status"] == 0).all() and ((r2["flags"] & want) == want).all())}
-            del ti, tno, tnl, nb
+        n_len = batch.length.astype(np.int64) + 4
+        n_off = np.concatenate(([0], np.cumsum((n_len + 15) & ~15)[:-1])).astype(np.int64)
+        nb = np.zeros(int(n_off[-1] + n_len[-1]) + 16, dtype=np.uint8)
+        for i in range(F):
+            o, l, d = int(batch.off[i]), int(batch.length[i]), int(n_off[i])
+            nb[d:d + l] = batch.base[o:o + l]
+            nb[d + 4] |= 4                                            # Content_Checksum_flag
+            h = oracle.xxh64(out_host[int(out_off[i]): int(out_off[i] + batch.regen[i])]) & 0xFFFFFFFF
+            nb[d + l:d + l + 4] = np.frombuffer(h.to_bytes(4, "little"), np.uint8)
+        ti = torch.from_numpy(nb).to(dev)
+        tno, tnl = torch.from_numpy(n_off).to(dev), torch.from_numpy(n_len).to(dev)
+        ctx.set_verify_checksum(True)
+        ms = []
+        for it in range(4):
+            ctx.decode_batch_device(ti.data_ptr(), tno.data_ptr(), tnl.data_ptr(), F, t_out.data_ptr(), t_ooff.data_ptr(),
+                                    t_ocap.data_ptr(), t_res.data_ptr())
+            ms.append(ctx.last_kernel_ms())
+        ctx.set_verify_checksum(False)
+        r2 = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
+        want = cz.RESULT_FINISHED | cz.RESULT_HAS_CHECKSUM | cz.RESULT_CHECKSUM_COMPUTED | cz.RESULT_CHECKSUM_MATCH
+        k = float(np.mean(ms[1:]))
+        cksum_leg = {"kernel_ms": k, "decompressed_MBps": regen_bytes / (k * 1e-3) / 1e6,
+                     "all_frames_ok_and_checksums_match": bool((r2["status"] == 0).all() and ((r2["flags"] & want) == want).all())}
+        del ti, tno, tnl, nb
+    del out_host
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        launches = ("cz_chain_kernel + " + ("cz_exec_frames_kernel + " if args.exec_kernel else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
             "value": regen_all * args.steps / elapsed / 1e6,
@@ -286,62 +355,90 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}", "frames_per_gpu": F,
-                       "frames_total": F * world, "compressed_bytes_per_gpu": int(batch.length.sum()),
-                       "decoded_bytes_per_gpu": regen_bytes, "parallelism": f"frames sharded over {world} GPU(s), no data-path collective",
-                       "gather_in_step": bool(args.gather and world > 1),
-                       "launches_per_step": "cz_chain_kernel + cz_decode_frames_kernel" if chain_prepass else "cz_decode_frames_kernel"},
-            "bit_exact": bool(ok_all), "frames_verified_vs_oracle": verified,
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}", "frames_per_gpu": args.frames,
+                       "frames_total": int(frames_all), "compressed_bytes_rank0": int(batch.length.sum()),
+                       "decoded_bytes_rank0": regen_bytes,
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"
+                                      + (", dealt by algorithmic bytes (one untimed all_to_all of compressed bytes)" if balanced else ""),
+                       "launches_per_step": launches},
+            "bit_exact": bool(ok_all), "frames_verified_vs_oracle_rank0": verified,
+            "verification": "last launch decoded into a 0xA5-poisoned buffer; every frame compared with the CPU oracle by XXH64" if not args.no_verify_all else "16-frame sample",
             "algorithmic_GBps_whole_job": alg_all * args.steps / elapsed / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "cz_chain_kernel + cz_decode_frames_kernel (one step)" if chain_prepass else "cz_decode_frames_kernel",
+            "roofline": {"bound": "hbm", "kernel": launches + " (one step)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_mean": k_ms,
                          "kernel_ms_all": [round(float(x), 4) for x in kernel_ms],
-                         "chain_kernel_ms_mean": float(np.mean(chain_ms)), "decode_kernel_ms_mean": k_ms - float(np.mean(chain_ms)),
+                         "chain_kernel_ms_mean": float(np.mean(chain_ms)), "exec_kernel_ms_mean": float(np.mean(exec_ms)),
+                         "decode_kernel_ms_mean": k_ms - float(np.mean(chain_ms)) - float(np.mean(exec_ms)),
+                         "slowest_rank_kernel_ms_mean": k_ms_all,
                          **ctx.launch_info()},
             "synth_seconds": round(gen_s, 2),
         }
-        # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE,
-        # WRITE_SIZE) of this same command and committed under profiles/: bench.py cannot read PMCs itself
-        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_hbm_traffic_full_4a.json")
-        if args.workload == "full_4a" and chain_prepass and F == 10000 and os.path.exists(pmc):
+        if args.workload in ("full_4a", "full_4b"):
+            # what the zstd format itself allows on this config: ONE serial FSE chain per block; with every frame in flight
+            # the chains cannot finish before (sequences per block) x (latency of one dependent LDS table lookup)
+            nseq = 32768 if args.workload == "full_4a" else 65536
+            step_ns = 32.3                                                 # profiles/r2/microbench_chain_step.txt: ffbh + shift + or + address + ds_read, one wave
+            line["roofline"]["serial_chain_floor"] = {"sequences_per_block": nseq, "min_step_ns": step_ns, "floor_ms": nseq * step_ns * 1e-6,
+                                                      "frac_of_hbm_peak_at_floor": alg_bytes / (nseq * step_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                                                      "source": "profiles/r2/microbench_chain_step.txt (variant 6: the dependent table chase alone)"}
+        # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
+        # this same command and committed under profiles/ together with the hash of the kernel sources it was made on
+        pmc = os.path.join(ROOT, "profiles", "r2", f"pmc_hbm_traffic_{args.workload}.json")
+        if os.path.exists(pmc) and world == 1 and F == 10000:
             t = json.load(open(pmc))
-            line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
-            line["roofline"]["traffic_source"] = "profiles/r1/pmc_hbm_traffic_full_4a.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE uncorrected: narrow reads), bytes per step, both kernels"
+            if t.get("kernel_source_hash") == _kernel_source_hash() and t.get("chain_prepass") == chain_prepass and bool(t.get("exec_kernel")) == bool(args.exec_kernel):
+                line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
+                line["roofline"]["traffic_source"] = f"profiles/r2/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
+            else:
+                line["roofline"]["traffic_source"] = "profiles/r2 PMC file is from other kernel sources or launch options: not quoted"
         if copy_ceiling is not None:
             line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling
+        if gather_leg:
+            gather_leg["value_MBps_with_gather"] = regen_all / (gather_leg["ms_per_step"] * 1e-3) / 1e6
+            line["with_gather_to_rank0"] = gather_leg
         if others:
             line["other_workloads"] = others
         if cksum_leg:
             line["with_content_checksum_verified_on_device"] = cksum_leg
         if world == 1 and not args.no_cpu_baseline:
-            import oracle
-            threads = ncpu
-            # bounded sample: grow the frame count until the budget is used
-            n_s = min(F, max(threads * 2, 64))
-            sample_s, done, passes, cpu_regen = 0.0, 0, 0, 0.0
-            t_begin = time.perf_counter()
-            while True:
-                idx = np.arange(done, min(F, done + n_s))
+            if cpu_leg is None:
                 t1 = time.perf_counter()
-                _, olen, ost = oracle.decode_batch(batch.base, batch.off[idx], batch.length[idx], out_off[idx] - out_off[idx[0]],
-                                                   out_cap[idx], int(out_off[idx[-1]] + out_cap[idx[-1]] - out_off[idx[0]]) + 256,
-                                                   nthreads=threads)
-                sample_s += time.perf_counter() - t1
-                assert (ost == 0).all()
-                cpu_regen += float(batch.regen[idx].sum())
-                done += idx.size
-                if done >= F:                                           # many host cores: go over the batch again until the budget is used
-                    done, passes = 0, passes + 1
-                if time.perf_counter() - t_begin > args.cpu_seconds:
-                    break
-                n_s = min(F - done, n_s * 2) if passes == 0 else F
-            frames_done = passes * F + done
-            line["cpu_baseline"] = {"value": cpu_regen / sample_s / 1e6, "unit": "MB/s", "cores": threads, "kind": "port",
-                                    "sample": f"{frames_done} frame decodes ({passes} full passes over the same {F}-frame batch + {done} frames), oracle/zstd_oracle.c "
-                                              f"(C restatement of the reference), {threads} pthreads, one frame per task, {sample_s:.2f} s wall = {sample_s * threads:.0f} core-seconds"}
+                _, olen, ost = oracle.decode_batch(batch.base, batch.off, batch.length, out_off, out_cap, out_total, nthreads=threads)
+                s1 = time.perf_counter() - t1
+                cpu_leg = {"value": regen_bytes / s1 / 1e6, "unit": "MB/s", "cores": threads, "kind": "port",
+                           "sample": f"one pass over the whole batch ({F} frames), oracle/zstd_oracle.c, {threads} pthreads, {s1:.2f} s wall"}
+            # single thread: a bounded prefix of the same batch
+            n1, s1, done1 = 8, 0.0, 0
+            budget = max(2.0, args.cpu_seconds * 0.25)
+            while done1 < F and s1 < budget:
+                idx = np.arange(done1, min(F, done1 + n1))
+                t1 = time.perf_counter()
+                _, olen, ost = oracle.decode_batch(batch.base, batch.off[idx], batch.length[idx], out_off[idx] - out_off[idx[0]], out_cap[idx],
+                                                   int(out_off[idx[-1]] + out_cap[idx[-1]] - out_off[idx[0]]) + 256, nthreads=1)
+                s1 += time.perf_counter() - t1
+                done1 += idx.size
+                n1 *= 2
+            cpu_leg["single_thread"] = {"value": float(batch.regen[:done1].sum()) / s1 / 1e6, "unit": "MB/s", "cores": 1,
+                                        "sample": f"the first {done1} frames of the batch, {s1:.2f} s"}
+            Z = _libzstd()
+            if Z is not None and args.workload in ("raw_rle", "huf_literals", "full_4a", "mix"):
+                dst = np.empty(int(batch.regen.max()) + 64, dtype=np.uint8)
+                zs, zdone, zbytes, zok = 0.0, 0, 0.0, True
+                t_stop = time.perf_counter() + max(2.0, args.cpu_seconds * 0.25)
+                while zdone < F and time.perf_counter() < t_stop:
+                    o, l = int(batch.off[zdone]), int(batch.length[zdone])
+                    t1 = time.perf_counter()
+                    r = Z.ZSTD_decompress(dst.ctypes.data, dst.size, batch.base[o:o + l].ctypes.data, l)
+                    zs += time.perf_counter() - t1
+                    zok = zok and not Z.ZSTD_isError(r) and r == int(batch.regen[zdone])
+                    zbytes += float(batch.regen[zdone])
+                    zdone += 1
+                cpu_leg["libzstd_single_thread"] = {"value": zbytes / zs / 1e6 if zs else None, "unit": "MB/s", "cores": 1, "all_frames_decoded": bool(zok),
+                                                    "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} on the first {zdone} frames, {zs:.2f} s"}
+            line["cpu_baseline"] = cpu_leg
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

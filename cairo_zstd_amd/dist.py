@@ -51,3 +51,53 @@ def gather_to_root(local: torch.Tensor, recv_bufs, root: int = 0):
         ops = [dist.P2POp(dist.isend, local, root)]
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+
+
+def partition_balanced(weights, world: int):
+    """Deals items to `world` ranks so that the sums of `weights` are balanced (sort by expected bytes,
+    deal greedily — longest processing time first).  Deterministic: every rank computes the same assignment.
+    Returns an int array: rank of every item."""
+    import heapq
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    order = np.lexsort((np.arange(w.size), -w))          # heaviest first, index breaks ties
+    heap = [(0.0, r) for r in range(world)]
+    assign = np.empty(w.size, dtype=np.int64)
+    for i in order:
+        load, r = heapq.heappop(heap)
+        assign[i] = r
+        heapq.heappush(heap, (load + float(w[i]), r))
+    return assign
+
+
+def rebalance_frames(base, off, length, regen, device):
+    """Moves frames between ranks so that every rank holds a byte-balanced share of the GLOBAL batch (each rank
+    starts with a contiguous slice).  The weight of a frame is its algorithmic bytes (compressed + decoded).
+    One exchange of the compressed bytes (all_to_all_single: RCCL on the GPUs, gloo in the CPU tests), before any
+    timing.  Returns (base, off, length, regen, global_index) of the frames this rank now owns."""
+    import numpy as np
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = int(length.size)
+    meta = torch.tensor(np.stack([length.astype(np.int64), regen.astype(np.int64)]), dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(gathered, meta)
+    g = np.stack([t.cpu().numpy() for t in gathered])                  # [world, 2, n]
+    glen, gregen = g[:, 0, :].reshape(-1), g[:, 1, :].reshape(-1)
+    assign = partition_balanced(glen + gregen, world)
+    mine = np.arange(rank * n, (rank + 1) * n)
+    send_order = [mine[assign[mine] == q] for q in range(world)]       # my frames, grouped by destination, index order
+    recv_order = [np.arange(q * n, (q + 1) * n)[assign[q * n:(q + 1) * n] == rank] for q in range(world)]
+    sbuf = np.concatenate([base[int(off[i - rank * n]): int(off[i - rank * n] + length[i - rank * n])] for grp in send_order for i in grp]
+                          or [np.zeros(0, np.uint8)])
+    in_split = [int(glen[grp].sum()) for grp in send_order]
+    out_split = [int(glen[grp].sum()) for grp in recv_order]
+    t_in = torch.from_numpy(np.ascontiguousarray(sbuf)).to(device)
+    t_out = torch.empty(sum(out_split), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(t_out, t_in, out_split, in_split)
+    idx = np.concatenate(recv_order) if recv_order else np.zeros(0, np.int64)
+    nlen = glen[idx].astype(np.uint64)
+    noff = np.zeros(idx.size, dtype=np.uint64)
+    if idx.size > 1:
+        noff[1:] = np.cumsum(nlen[:-1])
+    nbase = np.concatenate([t_out.cpu().numpy(), np.zeros(64, np.uint8)])
+    return nbase, noff, nlen, gregen[idx].astype(np.uint64), idx

@@ -80,3 +80,61 @@ def test_two_rank_shard_and_gather():
         want = hashlib.sha256(b"".join(whole.frame(i) for i in range(r * F, (r + 1) * F))).hexdigest()
         assert m[5][0] == want
     assert root[4][0] == float(whole.regen.sum())
+
+
+def test_partition_balanced_is_deterministic_and_balanced():
+    rng = np.random.default_rng(5)
+    w = np.concatenate([rng.integers(1, 300, 900), rng.integers(50_000, 900_000, 100)])    # a corpus-like long tail
+    a = czdist.partition_balanced(w, 8)
+    assert (a == czdist.partition_balanced(w, 8)).all() and a.min() == 0 and a.max() == 7
+    loads = np.array([w[a == r].sum() for r in range(8)], dtype=np.float64)
+    assert loads.max() / loads.mean() < 1.02
+    contiguous = np.array([w[r * 125:(r + 1) * 125].sum() for r in range(8)], dtype=np.float64)
+    assert loads.max() <= contiguous.max()
+
+
+def _rebalance_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = synth.generate("mix", F, first_index=czdist.shard_first_index(F, rank), nthreads=1)
+    nb, noff, nlen, nregen, idx = czdist.rebalance_frames(batch.base, batch.off, batch.length, batch.regen, torch.device("cpu"))
+    frames = [hashlib.sha256(nb[int(o): int(o + l)].tobytes()).hexdigest() for o, l in zip(noff, nlen)]
+    q.put((rank, idx.tolist(), frames, [int(x) for x in nregen], float((nlen + nregen).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_rebalance_by_algorithmic_bytes():
+    """BASELINE config 5's dealing step: after the exchange every frame of the global batch lives on exactly one rank,
+    byte for byte, and the two loads are balanced."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rebalance_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = synth.generate("mix", 2 * F, nthreads=1)
+    seen = sorted(msgs[0][1] + msgs[1][1])
+    assert seen == list(range(2 * F))
+    for rank, idx, frames, regen, load in msgs:
+        for i, h, rg in zip(idx, frames, regen):
+            assert hashlib.sha256(whole.frame(i)).hexdigest() == h and int(whole.regen[i]) == rg
+    loads = [m[4] for m in msgs]
+    heaviest = float((whole.length + whole.regen).max())
+    assert abs(loads[0] - loads[1]) <= heaviest
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_gpus():
+    """python bench.py --gpus N must start N ranks or fail: it never runs one rank and reports it as N."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "needs 2 GPUs" in p.stderr and "n_gpus" not in p.stdout

@@ -573,3 +573,19 @@ def test_more_frames_than_resident_workgroups_with_prepass(cz):
             assert st == 0 and out[int(out_off[i]): int(out_off[i] + b.regen[i])].tobytes() == ref, i
     finally:
         c.close()
+
+
+def test_bench_two_ranks_spawned_by_gpus_flag(cz):
+    """bench.py --gpus 2 starts two ranks by itself (torch.distributed.run) and reports n_gpus 2: rehearsed here over gloo
+    with both ranks on the one GPU of this box (RCCL needs one GPU per rank); mix workload, frames dealt by algorithmic
+    bytes, decode-only and decode+gather timed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "mix", "--frames", "300",
+                        "--steps", "2", "--warmup", "1", "--gather", "--no-other-workloads", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["bit_exact"] is True and line["config"]["frames_total"] == 600
+    assert "dealt by algorithmic bytes" in line["config"]["parallelism"]
+    assert line["with_gather_to_rank0"]["ms_per_step"] >= line["ms_per_step"] * 0.5 and line["with_gather_to_rank0"]["gathered_bytes_per_step"] > 0
