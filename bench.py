@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--no-verify-all", action="store_true", help="check only a sample of the frames against the oracle (default: every frame, by XXH64)")
     ap.add_argument("--no-chain-prepass", action="store_true", help="run the FSE chains inside cz_decode_frames_kernel (single launch)")
+    ap.add_argument("--no-literals-pass", action="store_true", help="decode Huffman literals inside the decode kernel instead of next to the chain pre-pass")
     ap.add_argument("--exec-kernel", action="store_true", help="execute pre-passed frames on cz_exec_frames_kernel (LDS ring, one workgroup per frame)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
@@ -177,9 +178,11 @@ def main():
     # blocks (mix) and on blocks without sequences it is measured slower than in-kernel chains
     chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b")
     arena_bytes = int(batch.length.sum()) * 6 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
+    lit_bytes = regen_bytes + (16 << 20)                               # decoded literal bytes never exceed the decoded size
     if chain_prepass:
         ctx.set_chain_arena(arena_bytes)
         ctx.set_exec_kernel(args.exec_kernel)
+        ctx.set_literal_arena(0 if args.no_literals_pass or args.exec_kernel else lit_bytes)
 
     def decode():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
@@ -292,7 +295,9 @@ def main():
             nf = 12500 if wl == "mix" else 10000
             # the chain pre-pass only pays for frames with long sequences sections
             ob = synth.generate(wl, nf, nthreads=max(1, min(32, ncpu)))
-            ctx.set_chain_arena(int(ob.length.sum()) * 6 + (64 << 20) if wl in ("full_4a", "full_4b") and not args.no_chain_prepass else 0)
+            pre = wl in ("full_4a", "full_4b") and not args.no_chain_prepass
+            ctx.set_chain_arena(int(ob.length.sum()) * 6 + (64 << 20) if pre else 0)
+            ctx.set_literal_arena(int(ob.regen.sum()) + (16 << 20) if pre and not args.no_literals_pass else 0)
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)
             td = [torch.from_numpy(x.astype(np.int64)).to(dev) for x in (ob.off, ob.length, o_off, o_cap)]
@@ -312,6 +317,7 @@ def main():
                           "all_frames_ok": okw}
             del ti, td, to, tr
         ctx.set_chain_arena(arena_bytes if chain_prepass else 0)
+        ctx.set_literal_arena(lit_bytes if chain_prepass and not args.no_literals_pass and not args.exec_kernel else 0)
 
     # ---- the same batch with a content checksum on every frame, XXH64 computed and
     # compared inside cz_decode_frames_kernel (N=1 only, after the timed region)
@@ -347,7 +353,9 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        launches = ("cz_chain_kernel + " + ("cz_exec_frames_kernel + " if args.exec_kernel else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
+        lit_pass = chain_prepass and not args.no_literals_pass and not args.exec_kernel
+        launches = (("cz_chain_kernel || cz_decode_frames_kernel(literals pass) + " if lit_pass else "cz_chain_kernel + ")
+                    + ("cz_exec_frames_kernel + " if args.exec_kernel else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
             "value": regen_all * args.steps / elapsed / 1e6,

@@ -82,6 +82,22 @@ class Context:
             raise CzError(st, "cz_context_last_chain_ms")
         return float(ms.value)
 
+    def set_literal_arena(self, nbytes: int):
+        """Enable (nbytes > 0) / disable (0) the literals pass that runs next to the pre-pass (cz_context_set_literal_arena)."""
+        if not hasattr(lib(), "cz_context_set_literal_arena"):
+            return
+        st = lib().cz_context_set_literal_arena(self._h, nbytes)
+        if st:
+            raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
+
+    def last_literals_tail_ms(self) -> float:
+        """Milliseconds the last launch waited for the literals pass after the chain kernel was done."""
+        if not hasattr(lib(), "cz_context_last_literals_tail_ms"):
+            return 0.0
+        ms = C.c_float(0)
+        lib().cz_context_last_literals_tail_ms(self._h, C.byref(ms))
+        return float(ms.value)
+
     def set_exec_kernel(self, on: bool = True):
         """Frames with chain records run on cz_exec_frames_kernel (default) or on the record path of cz_decode_frames_kernel."""
         lib().cz_context_set_exec_kernel(self._h, 1 if on else 0)

@@ -84,6 +84,12 @@ def lib() -> C.CDLL:
         L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cz_context_set_exec_kernel.restype = C.c_int
         L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
+    if hasattr(L, "cz_context_last_literals_tail_ms"):
+        L.cz_context_last_literals_tail_ms.restype = C.c_int
+        L.cz_context_last_literals_tail_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    if hasattr(L, "cz_context_set_literal_arena"):
+        L.cz_context_set_literal_arena.restype = C.c_int
+        L.cz_context_set_literal_arena.argtypes = [vp, sz]
     L.cz_context_set_chain_min_sequences.restype = C.c_int
     L.cz_context_set_chain_min_sequences.argtypes = [vp, C.c_uint32]
     L.cz_context_read_profile.restype = C.c_int

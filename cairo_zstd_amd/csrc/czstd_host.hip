@@ -47,6 +47,10 @@ struct cz_context {
     unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
     int chain_grid = 0; uint32_t chain_min_nseq = 2048;
+    /* optional literals pass next to the pre-pass, on a stream of its own */
+    uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
+    uint64_t* lit_first = nullptr; size_t lit_first_cap = 0; uint32_t* lit_counter = nullptr;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lit = nullptr; int lit_grid = 0; bool timed_lit = false;
     uint32_t verify_checksum = 0;
 };
 
@@ -109,6 +113,13 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->chain_arena) (void)hipFree(c->chain_arena);
+    if (c->lit_arena) (void)hipFree(c->lit_arena);
+    if (c->lit_top) (void)hipFree(c->lit_top);
+    if (c->lit_first) (void)hipFree(c->lit_first);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_lit) (void)hipEventDestroy(c->ev_lit);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->chain_top) (void)hipFree(c->chain_top);
     if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -177,6 +188,33 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
+/* Enables (bytes > 0) or disables (0) the literals pass: with the pre-pass on, the Huffman-coded literals of the frames
+ * the pre-pass takes are decoded by a second launch of cz_decode_frames_kernel (literals only) that runs NEXT TO
+ * cz_chain_kernel on a stream of its own — the chain kernel is bound by the latency of its serial chains and leaves
+ * most issue slots of the chip idle.  bytes = capacity of the literal arena (decoded literal bytes + 16 per block;
+ * never more than the decoded size of the batch); frames that do not fit decode their literals in the decode kernel. */
+CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
+    if (!c) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->lit_arena) { (void)hipFree(c->lit_arena); c->lit_arena = nullptr; c->lit_capacity = 0; }
+    if (!bytes) return CZ_OK;
+    if (bytes < 4096) bytes = 4096;
+    if (!c->lit_top) { CZ_HIP(c, hipMalloc((void**)&c->lit_top, 64)); c->lit_counter = (uint32_t*)((uint8_t*)c->lit_top + 16); }
+    if (!c->stream2) {
+        CZ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        CZ_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        CZ_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        CZ_HIP(c, hipEventCreate(&c->ev_lit));
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
+        c->lit_grid = c->num_cu * (occ < 8 ? occ : 8);
+    }
+    CZ_HIP(c, hipMalloc((void**)&c->lit_arena, (bytes + 15) & ~(size_t)15));
+    c->lit_capacity = bytes;
+    return CZ_OK;
+}
+
 /* Frames that have chain records run on cz_exec_frames_kernel (default) or on cz_decode_frames_kernel's record path (0). */
 CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; return CZ_OK; }
 
@@ -184,6 +222,17 @@ CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) re
 
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
+
+/* How long the last launch went on waiting for the literals pass after cz_chain_kernel was done (0: no literals pass). */
+CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
+    if (!c || !ms) return CZ_E_INVALID_ARG;
+    *ms = 0.0f;
+    if (!c->timed || !c->timed_lit || !c->timed_chain) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_mid, c->ev_lit));
+    return CZ_OK;
+}
 
 /* Part of the last launch spent in cz_exec_frames_kernel (0 when it did not run). */
 CZ_EXPORT int cz_context_last_exec_ms(cz_context* c, float* ms) {
@@ -225,11 +274,35 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
         a.frame_first = c->frame_first; a.chain_counter = c->chain_counter; a.chain_min_nseq = c->chain_min_nseq;
+        const bool lit_pass = c->lit_arena != nullptr;
+        if (lit_pass) {
+            if (c->lit_first_cap < n) {
+                if (c->lit_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->lit_first); c->lit_first = nullptr; c->lit_first_cap = 0; }
+                CZ_HIP(c, hipMalloc((void**)&c->lit_first, n * 8)); c->lit_first_cap = n;
+            }
+            static const unsigned long long top0[4] = {64, 0, 0, 0};    /* offset 0 = "no node" */
+            CZ_HIP(c, hipMemcpyAsync(c->lit_top, top0, 32, hipMemcpyHostToDevice, c->stream));
+            a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
+        }
         const size_t waves = (n + CZC_SLOTS - 1) / CZC_SLOTS;
         const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
+        if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));   /* everything the literals pass needs is enqueued */
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
+        if (lit_pass) {
+            /* the literals pass on its own stream, next to the chain kernel */
+            CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            cz_batch_args l = a; l.literals_only = 1; l.work_counter = c->lit_counter;
+            const size_t lmax = (size_t)(c->lit_grid < c->lit_slots ? c->lit_grid : c->lit_slots);
+            const int lgrid = (int)(n < lmax ? n : lmax);
+            hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(lgrid), dim3(CZ_WG_THREADS), 0, c->stream2, l);
+            CZ_HIP(c, hipGetLastError());
+            CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* chain kernel done AND literals pass done */
+            c->timed_lit = true;
+        } else c->timed_lit = false;
         c->timed_chain = true;
         c->timed_exec = false;
         if (c->exec_kernel && !a.verify_checksum && (size_t)c->grid_max >= (size_t)c->exec_grid) {
@@ -242,7 +315,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
             c->timed_exec = true;
         }
-    } else { c->timed_chain = false; c->timed_exec = false; }
+    } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, a);

@@ -372,7 +372,11 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
         if (e) return e;
         if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
         cz_fse_build(sh.a.t1.wtab, sh.a.t1.probs0, nprobs, log, sh.a.t1.counters0, sh.b.c.llml, 3);
-        CzRBits rb; cz_rb_init(rb, g + goff + 1 + fse_bytes, header - fse_bytes);       /* :190-202 */
+        /* the weight bitstream (<= 127 bytes) is read from the LDS stage when it lies inside it: one dependent global
+           load per refill otherwise */
+        const uint32_t wlo = goff + 1 + fse_bytes, whi = goff + 1 + header;
+        const uint8_t* wbase = (wlo >= stage_lo && whi <= stage_hi) ? (const uint8_t*)sh.a.t1.stage + (wlo - stage_lo) : (const uint8_t*)(g + wlo);
+        CzRBits rb; cz_rb_init(rb, wbase, header - fse_bytes);          /* :190-202 */
         if (cz_rb_skip_padding(rb)) return CZ_E_HUF_EXTRA_PADDING;      /* :206-225 */
         uint32_t d1 = sh.a.t1.wtab[cz_rb_get(rb, log)];                    /* :227 */
         uint32_t d2 = sh.a.t1.wtab[cz_rb_get(rb, log)];                    /* :233 */
@@ -505,7 +509,7 @@ __device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, u
 /* LiteralsSection::parse_from_header (literals_section.cairo:81-175) + the serial parts of
  * decompress_literals (literals_section_decoder.cairo:58-117) + SequencesHeader::parse_from_header
  * (sequence_section.cairo:77-114).  Lane 0; results in sh.bc. */
-__device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, uint32_t bsize, uint32_t stage_hi) {
+__device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, uint32_t bsize, uint32_t stage_hi, int have_literals = 0) {
     CzBroadcast& bc = sh.bc;
     CzFBits fb; fb.g = blk; fb.stage = sh.a.t1.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
     if (bsize == 0) return CZ_E_LS_GETBITS;                             /* :84-90 */
@@ -526,7 +530,8 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, 
     const uint32_t upper = type >= 2 ? comp : (type == 1 ? 1u : regen); /* block_decoder.cairo:160-172 */
     if (bsize - need < upper) return CZ_E_MALFORMED_SECTION_HEADER;     /* block_decoder.cairo:174 */
     bc.lit_type = type; bc.regen = regen; bc.nstreams = streams; bc.lit_total = need + upper; bc.huf_fill = 0;
-    if (type >= 2) {                                                    /* literals_section_decoder.cairo:64-117 */
+    if (type >= 2 && !have_literals) {                                  /* literals_section_decoder.cairo:64-117 (skipped when the literals pass
+                                                                           already decoded this block's literals, tree included) */
         uint32_t off = need, left = comp;
         if (type == 2) {
             uint32_t used, nsym;
@@ -1392,15 +1397,20 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref
 
 /* ------------------------------------------------------------------ one compressed block */
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
+/* Literal nodes of a frame.  Decoding: arena + cursor = node of the next Huffman-coded block (cursor 0 = this frame has
+ * none: decode literals here).  Literals pass (lit_out != nullptr): cursor = the last node written, first = the first. */
+struct CzLitPass { cz_gptr arena; uint64_t cursor, first; uint32_t last_nseq; };
 __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, cz_gptr lit_scratch,
-                                           cz_gptr16 huf_global, int last_block, cz_gcptr64 arena, uint64_t& chain_cursor) {
+                                           cz_gptr16 huf_global, int last_block, cz_gcptr64 arena, uint64_t& chain_cursor, CzLitPass& lp,
+                                           const cz_batch_args* lit_out = nullptr) {
     CzBroadcast& bc = sh.bc;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
     const uint32_t stage_hi = bsize < 512 ? bsize : 512;
     for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.a.t1.stage[i] = blk[i];
     __syncthreads();
-    if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi);
+    const int have_literals = !lit_out && lp.cursor != 0;
+    if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals);
     __syncthreads();
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
     CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
@@ -1409,7 +1419,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         if (!last_block) {                                              /* carried for later Treeless blocks */
             for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)huf_global)[i] = ((const uint32_t*)sh.a.huf)[i];
         }
-    } else if (bc.lit_type == 3) {                                      /* Treeless: bring the carried table back */
+    } else if (bc.lit_type == 3 && !have_literals) {                    /* Treeless: bring the carried table back */
         for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)sh.a.huf)[i] = ((CZ_GLOBAL const uint32_t*)huf_global)[i];
         __syncthreads();
     }
@@ -1421,9 +1431,39 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     const uint32_t lt = cz_uni(bc.lit_type), nseq_early = seq_hdr_err ? 1u : nseq;
     if (lt == 0) { lit.p = blk + (lit_total - regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
     else if (lt == 1) { lit.rle = 1; lit.byte = blk[lit_total - 1]; } /* RLE :43-46 */
-    else {
+    else if (have_literals) {
+        /* decoded by the literals pass: node = {next, regen, 0, bytes} */
+        CZ_GLOBAL const uint64_t* node = (CZ_GLOBAL const uint64_t*)(lp.arena + lp.cursor);
+        const uint64_t nxt = node[0], meta = node[1];
+        if ((uint32_t)meta != regen) return CZ_E_INVALID_ARG;           /* cannot happen: both passes read the same header */
+        lit.p = (cz_gcptr)(lp.arena + lp.cursor + 16);
+        lp.cursor = cz_uni64(nxt);
+        if (nseq_early == 0) {
+            if (x.produced + regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
+            cz_coop_copy(x.out + x.produced, lit.p, regen);
+        }
+    } else {
         cz_gptr target = lit_scratch;
-        if (nseq_early == 0) {                                          /* no sequences: decode straight into the output */
+        if (lit_out) {
+            /* literals pass: a node of the literal arena (one bump allocation per block) */
+            if (LANE == 0) {
+                const unsigned long long need = 16ull + ((regen + 15u) & ~15u);
+                const unsigned long long at = atomicAdd(lit_out->lit_top, need);
+                bc.d0 = at + need <= lit_out->lit_capacity ? at : 0;
+            }
+            __syncthreads();
+            const uint64_t at = cz_uni64(bc.d0);
+            __syncthreads();
+            if (!at) return CZ_E_OUTPUT_TOO_SMALL;
+            if (LANE == 0) {
+                CZ_GLOBAL uint64_t* node = (CZ_GLOBAL uint64_t*)(lit_out->lit_arena + at);
+                node[0] = 0; node[1] = regen;
+                if (lp.cursor) *(CZ_GLOBAL uint64_t*)(lit_out->lit_arena + lp.cursor) = at;   /* link the previous node */
+            }
+            if (!lp.first) lp.first = at;
+            lp.cursor = at;
+            target = (cz_gptr)(lit_out->lit_arena + at + 16);
+        } else if (nseq_early == 0) {                                   /* no sequences: decode straight into the output */
             if (x.produced + regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
             target = x.out + x.produced;
         } else if (regen > CZ_LIT_SCRATCH_BYTES) return CZ_E_UNSUPPORTED;
@@ -1432,6 +1472,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         lit.p = target;
         __syncthreads();
     }
+    if (lit_out) { lp.last_nseq = nseq; return seq_hdr_err ? seq_hdr_err : 0; }   /* literals pass: nothing else to do in this block */
     CZ_PROF_ACC(CZ_P_HUFDEC);
     if (seq_hdr_err) return seq_hdr_err;                                /* block_decoder.cairo:198-204 */
     if (nseq == 0) {                                                 /* :229-232 */
@@ -1537,7 +1578,7 @@ struct CzFrameIO {
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
 __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 huf_global, CZ_GLOBAL cz_frame_result* res,
-                                    cz_gcptr64 arena, uint64_t chain_cursor) {
+                                    cz_gcptr64 arena, uint64_t chain_cursor, CzLitPass lp) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0, hdr_ok = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
     CZ_PROF_DECL; CZ_PROF_T0();
@@ -1585,7 +1626,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
             x.produced += bsize;
         } else {
             CZ_PROF_ACC(CZ_P_HDR);
-            err = cz_decompress_block(io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor);
+            err = cz_decompress_block(io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor, lp);
             CZ_PROF_T0();
             if (err) break;
         }
@@ -1622,6 +1663,42 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
     __syncthreads();
 }
 
+/* Literals pass over one frame (args.literals_only): walks the frame's blocks and decodes the Huffman-coded literals of
+ * every compressed block into nodes of the literal arena — the part of decompress_block (block_decoder.cairo:139-196) that
+ * needs neither the sequences nor the window, so it can run next to cz_chain_kernel.  All or nothing per frame: on any
+ * irregularity, on a first sequences section shorter than chain_min_nseq (the pre-pass will not take the frame) or when
+ * the arena is full, lit_first[f] stays 0 and the decode kernel does the frame's literals itself. */
+__device__ static uint64_t cz_run_frame_literals(const cz_batch_args& a, cz_gcptr src, uint64_t src_len, cz_gptr lit_scratch) {
+    CzBroadcast& bc = sh.bc;
+    if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(src, src_len, bc); }
+    __syncthreads();
+    int err = cz_unii(bc.err);
+    uint64_t pos = cz_uni(bc.hdr_len);
+    __syncthreads();
+    if (err) return 0;
+    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0;
+    CzLitPass lp; lp.arena = nullptr; lp.cursor = 0; lp.first = 0; lp.last_nseq = 0;
+    uint64_t no_chain = 0; int seen_seq = 0;
+    for (;;) {
+        if (src_len - pos < 3) return 0;
+        const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
+        const uint32_t btype = (b0 >> 1) & 3, bsize = (b0 >> 3) | (b1 << 5) | (b2 << 13), blast = b0 & 1;
+        if (btype == 3 || bsize > 128u * 1024u) return 0;
+        const uint64_t body = pos + 3; const uint32_t content = btype == 1 ? 1u : bsize;
+        if (src_len - body < content) return 0;
+        if (btype == 2) {
+            lp.last_nseq = 0;
+            err = cz_decompress_block(src + body, bsize, x, lit_scratch, (cz_gptr16)(lit_scratch + CZ_LIT_SCRATCH_BYTES), (int)blast, nullptr, no_chain, lp, &a);
+            if (err) return 0;
+            if (!seen_seq && lp.last_nseq) { seen_seq = 1; if (lp.last_nseq < a.chain_min_nseq) return 0; }
+        }
+        __syncthreads();
+        pos = body + content;
+        if (blast) break;
+    }
+    return seen_seq ? lp.first : 0;
+}
+
 __device__ static void cz_state_reset() {                   /* scratch.cairo:23-40 */
     if (LANE == 0) {
         sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
@@ -1643,6 +1720,13 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         __syncthreads();
         const uint32_t f = cz_uni(sh.frame_idx);
         if (f >= a.n) break;
+        if (a.literals_only) {
+            cz_state_reset();
+            __syncthreads();
+            const uint64_t first = cz_run_frame_literals(a, (cz_gcptr)(a.in_base + a.in_off[f]), a.in_len[f], lit_scratch);
+            if (LANE == 0) a.lit_first[f] = first;
+            continue;
+        }
         if (!a.tasks && a.chain_arena && cz_uni64(a.frame_first[f]) == 0xFFFFFFFFFFFFFFFFull) continue;   /* finished by cz_exec_frames_kernel */
         CzFrameIO io;
         if (a.tasks) {
@@ -1659,7 +1743,8 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
                 sh.huf_max_bits = gs->huf_max_bits;
             }
             __syncthreads();
-            cz_run_frame(io, lit_scratch, (cz_gptr16)gs->huf, (CZ_GLOBAL cz_frame_result*)&a.results[f], nullptr, 0);
+            CzLitPass nolit; nolit.arena = nullptr; nolit.cursor = 0; nolit.first = 0; nolit.last_nseq = 0;
+            cz_run_frame(io, lit_scratch, (cz_gptr16)gs->huf, (CZ_GLOBAL cz_frame_result*)&a.results[f], nullptr, 0, nolit);
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = CZ_FSE_LL[i]; gs->fse[2][i] = CZ_FSE_ML[i]; }
             for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = CZ_FSE_OF[i];
             if (LANE == 0) {
@@ -1672,8 +1757,10 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
             io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum;
             cz_state_reset();
             __syncthreads();
+            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0;
+            lp.cursor = a.lit_arena ? cz_uni64(a.lit_first[f]) : 0;
             cz_run_frame(io, lit_scratch, (cz_gptr16)(lit_scratch + CZ_LIT_SCRATCH_BYTES), (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena,
-                         a.chain_arena ? cz_uni64(a.frame_first[f]) : 0);
+                         a.chain_arena ? cz_uni64(a.frame_first[f]) : 0, lp);
 #ifdef CZ_PROFILE
             if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
 #endif

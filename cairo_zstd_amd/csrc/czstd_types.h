@@ -55,6 +55,12 @@ typedef struct cz_batch_args {
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
     uint32_t* chain_counter; uint32_t chain_min_nseq;
     uint32_t* exec_counter;                   /* work counter of cz_exec_frames_kernel */
+    /* optional literals pass (cz_decode_frames_kernel with literals_only = 1, launched next to cz_chain_kernel): the
+       Huffman-coded literals of every frame the pre-pass takes are decoded into lit_arena — per block a node
+       {u64 offset of the next node | 0, u32 regenerated size, u32 0, bytes...}; lit_first[f] = offset of frame f's
+       first node, 0 = none: the decode kernels then decode that frame's literals themselves */
+    uint8_t* lit_arena; uint64_t lit_capacity; unsigned long long* lit_top; uint64_t* lit_first;
+    uint32_t literals_only;
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
 } cz_batch_args;
 

@@ -100,6 +100,12 @@ int cz_decode_batch_host(cz_context* ctx,
  * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, that are
  * irregular in any way, or whose chains are short, are decoded entirely by cz_decode_frames_kernel. */
 int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
+/* Enables (bytes > 0) or disables (0) the literals pass that goes with the pre-pass: the Huffman-coded literals of the
+ * frames the pre-pass takes are decoded (tree description, table, streams: literals_section_decoder.cairo:58-243) by a
+ * literals-only launch of cz_decode_frames_kernel on a stream of its own, NEXT TO cz_chain_kernel, into an arena of
+ * `bytes` (decoded literal bytes + 16 per block; at most the decoded size of the batch).  The decode kernels then read
+ * the literals from the arena; frames that did not fit, or that are irregular in any way, decode theirs as before. */
+int cz_context_set_literal_arena(cz_context* ctx, size_t bytes);
 /* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 2048:
  * the pre-pass only pays for long chains). */
 int cz_context_set_chain_min_sequences(cz_context* ctx, uint32_t n);
@@ -116,6 +122,8 @@ int cz_context_set_verify_checksum(cz_context* ctx, int on);
 int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
 /* The part of it spent in the FSE-chain pre-pass kernel (0 when the pre-pass is off). */
 int cz_context_last_chain_ms(cz_context* ctx, float* ms);
+/* How long that launch went on waiting for the literals pass after the chain kernel was done (0: no literals pass). */
+int cz_context_last_literals_tail_ms(cz_context* ctx, float* ms);
 /* The part of it spent in cz_exec_frames_kernel (0 when it did not run). */
 int cz_context_last_exec_ms(cz_context* ctx, float* ms);
 /* With the pre-pass on, frames that got chain records run on cz_decode_frames_kernel's record path (one wave per

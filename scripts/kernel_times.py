@@ -27,16 +27,21 @@ def child(kind, n):
     ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
     if os.environ.get("CZ_PREPASS", "1") == "1":
         ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
-    tot, ch, ex = [], [], []
+        if os.environ.get("CZ_LITPASS", "1") == "1":
+            ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
+        if os.environ.get("CZ_EXEC", "0") == "1":
+            ctx.set_exec_kernel(True)
+    tot, ch, ex, lt = [], [], [], []
     for it in range(5):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
         tot.append(ctx.last_kernel_ms())
         ch.append(ctx.last_chain_ms())
         ex.append(ctx.last_exec_ms())
+        lt.append(ctx.last_literals_tail_ms())
     res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
     ok = bool((res["status"] == 0).all() and (res["bytes_produced"] == b.regen).all())
     print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
-          f"exec {np.mean(ex[2:]):8.3f} ms  main {np.mean(tot[2:]) - np.mean(ch[2:]) - np.mean(ex[2:]):8.3f} ms  ok={ok}", flush=True)
+          f"lit tail {np.mean(lt[2:]):6.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  main {np.mean(tot[2:]) - np.mean(ch[2:]) - np.mean(ex[2:]):8.3f} ms  ok={ok}", flush=True)
     ctx.close()
 
 

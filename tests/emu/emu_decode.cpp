@@ -47,7 +47,7 @@ static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a); else cz_decode_frames_kernel(la->a);
+    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a); else cz_decode_frames_kernel(la->a);   /* 1 decode, 3 literals pass */
     emu_lane_done[la->lane] = 1;
     return nullptr;
 }
@@ -91,21 +91,34 @@ int main(int argc, char** argv) {
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
     for (int w = 0; w < EMU_MAX_WAVES; w++) pthread_barrier_init(&emu_wbar[w], nullptr, 64);
     uint32_t exec_counter = 0; a.exec_counter = &exec_counter;
+    /* EMU_LIT=<bytes>: literals pass (literals_only launch of the decode kernel) with an arena of that many bytes */
+    unsigned long long lit_top[4] = {64, 0, 0, 0}; std::vector<uint64_t> lit_first(n ? n : 1, 0); uint8_t* lit_arena = nullptr;
+    const size_t lit_bytes = arena && getenv("EMU_LIT") ? (size_t)atoll(getenv("EMU_LIT")) : 0;
+    if (lit_bytes) { lit_arena = (uint8_t*)malloc(lit_bytes); a.lit_arena = lit_arena; a.lit_capacity = lit_bytes; a.lit_top = lit_top; a.lit_first = lit_first.data(); }
     /* passes: [chain pre-pass, [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int with_exec = arena && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
-    for (int pass = arena ? 0 : 1; pass < 3; pass++) {
-        const int which = pass == 0 ? 0 : (pass == 1 ? 2 : 1);
+    if (with_exec) a.verify_checksum = 0;                               /* as the host library: cz_exec_frames_kernel does not hash */
+    for (int pass = arena ? 0 : 1; pass < 4; pass++) {
+        const int which = pass == 0 ? 0 : (pass == 1 ? 3 : (pass == 2 ? 2 : 1));   /* chain, literals, exec, decode */
         if (which == 2 && !with_exec) continue;
+        if (which == 3 && !lit_bytes) continue;
         const int nthreads = which == 2 ? CZX_THREADS : 64;
         emu_nthreads = nthreads;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
         for (int b = 0; b < grid; b++) {
             std::vector<pthread_t> th((size_t)nthreads); std::vector<lane_arg> la((size_t)nthreads);
-            for (int l = 0; l < nthreads; l++) { la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which; pthread_create(&th[l], nullptr, lane_main, &la[l]); }
+            uint32_t lit_counter = 0;
+            for (int l = 0; l < nthreads; l++) {
+                la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which;
+                if (which == 3) { la[l].a.literals_only = 1; la[l].a.work_counter = &lit_counter; if (b) continue; }
+                pthread_create(&th[l], nullptr, lane_main, &la[l]);
+            }
+            if (which == 3 && b) continue;                              /* one workgroup does the whole literals pass */
             for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);
         }
         pthread_barrier_destroy(&emu_barrier);
     }
+    if (lit_bytes) { unsigned long long nl = 0; for (uint64_t i = 0; i < n; i++) nl += lit_first[i] != 0; fprintf(stderr, "EMU_LIT: %llu frames have literal nodes, arena top %llu\n", nl, lit_top[0]); free(lit_arena); }
     if (with_exec) { unsigned long long donef = 0; for (uint64_t i = 0; i < n; i++) donef += frame_first[i] == ~0ull; fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_exec_frames_kernel\n", donef); }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {

@@ -11,8 +11,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False):
-    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel)
+def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -20,8 +20,8 @@ def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False):
             bad.append((i, status.name(r["status"]), status.name(st)))
         elif st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"]):
             bad.append((i, "DATA"))
-        elif st == 0 and info["has_checksum"]:
-            # the emulator always runs with content-checksum verification on
+        elif st == 0 and info["has_checksum"] and not exec_kernel:
+            # the emulator runs with content-checksum verification on (except next to cz_exec_frames_kernel, like the library)
             want = oracle.xxh64(ref) & 0xFFFFFFFF
             if not (r["flags"] & 4) or int(r["calculated_checksum"]) != want or bool(r["flags"] & 8) != (want == info["checksum"]):
                 bad.append((i, "XXH64", hex(int(r["calculated_checksum"])), hex(want)))
@@ -69,26 +69,29 @@ def test_emu_content_checksum_lengths():
 def test_emu_chain_prepass():
     """cz_chain_kernel + the record-driven path of cz_decode_frames_kernel under ASan/UBSan: corpus frames
     (multi-block, Repeat/RLE/predefined tables), synthetic frames, malformed frames (the pre-pass must
-    leave them to the decoder, which reports the reference's status), and an arena that is far too small."""
+    leave them to the decoder, which reports the reference's status), an arena that is far too small, and the
+    literals pass (a literals-only launch of the decode kernel) feeding the decode kernel, with room and without."""
     frames, caps = [], []
-    for name, z, orig in corpus_pairs(max_orig=9000):
+    for name, z, orig in corpus_pairs(max_orig=6000):
         frames.append(z)
         caps.append(len(orig) + 16)
     b = synth.generate("mix", 24, first_index=4242, nthreads=2)
-    keep = [i for i in range(b.n) if b.regen[i] < 50000][:10]
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:6]
     frames += [b.frame(i) for i in keep]
     caps += [int(b.regen[i]) + 8 for i in keep]
-    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=900)):
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=700)):
         rng = np.random.default_rng(100 + idx)
-        for _ in range(4):
+        for _ in range(2):
             a = bytearray(z)
             a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
             frames.append(bytes(a))
             caps.append(len(orig) * 2 + 4096)
         frames.append(z[: len(z) // 2])
         caps.append(len(orig) * 2 + 4096)
-    _run_and_compare(frames, caps, chain_bytes=8 << 20)
-    _run_and_compare(frames[:20], caps[:20], chain_bytes=4096)
+    _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20)
+    assert "frames have literal nodes" in emu_runner.run.last_stderr
+    _run_and_compare(frames[::3], caps[::3], chain_bytes=8 << 20)
+    _run_and_compare(frames[:12], caps[:12], chain_bytes=4096, lit_bytes=6000)
 
 
 def test_emu_exec_kernel():
@@ -96,20 +99,19 @@ def test_emu_exec_kernel():
     order behind done flags) under ASan/UBSan, 4 waves per workgroup: corpus frames, synthetic frames, malformed
     frames (it must leave them to cz_decode_frames_kernel)."""
     frames, caps = [], []
-    for name, z, orig in corpus_pairs(max_orig=9000):
+    for name, z, orig in corpus_pairs(max_orig=5000):
         frames.append(z)
         caps.append(len(orig) + 16)
     b = synth.generate("mix", 24, first_index=4242, nthreads=2)
-    keep = [i for i in range(b.n) if b.regen[i] < 50000][:10]
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:5]
     frames += [b.frame(i) for i in keep]
     caps += [int(b.regen[i]) + 8 for i in keep]
-    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=900)):
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=600)):
         rng = np.random.default_rng(300 + idx)
-        for _ in range(3):
-            a = bytearray(z)
-            a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
-            frames.append(bytes(a))
-            caps.append(len(orig) * 2 + 4096)
+        a = bytearray(z)
+        a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+        frames.append(bytes(a))
+        caps.append(len(orig) * 2 + 4096)
     _run_and_compare(frames, caps, chain_bytes=8 << 20, exec_kernel=True)
     assert "frames finished by cz_exec_frames_kernel" in emu_runner.run.last_stderr
 

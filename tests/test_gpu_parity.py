@@ -258,13 +258,14 @@ def test_device_pointer_batch_full_size(cz, ctx):
     c2.close()
 
 
-@pytest.mark.parametrize("arena_mb", [0.02, 256])
-def test_chain_prepass_matches_oracle(cz, arena_mb):
+@pytest.mark.parametrize("arena_mb,lit_mb", [(0.02, 0), (256, 0), (256, 256), (256, 0.05)])
+def test_chain_prepass_matches_oracle(cz, arena_mb, lit_mb):
     """cz_chain_kernel + cz_decode_frames_kernel (two-pass pipeline) == oracle, also when the record
     arena is far too small (frames fall back to in-kernel chains) and on malformed frames."""
     from cairo_zstd_amd import synth
     c = cz.Context(0)
     c.set_chain_arena(int(arena_mb * (1 << 20)), min_sequences=0)      # pre-pass every frame, however short its chains
+    c.set_literal_arena(int(lit_mb * (1 << 20)))                       # literals pass next to it (0 = off; 0.05 MB: most frames do not fit)
     try:
         frames, caps = [], []
         for kind, n in (("full_4a", 12), ("full_4b", 4), ("mix", 800), ("huf_literals", 4), ("raw_rle", 4)):
@@ -435,6 +436,7 @@ def test_corpus_large_frames_vs_manifest(cz, mode):
         if mode != "single_kernel":
             c.set_chain_arena(512 << 20, min_sequences=0)
             c.set_exec_kernel(mode == "prepass_exec_kernel")
+            c.set_literal_arena((64 << 20) if mode == "prepass" else 0)
         if mode != "prepass_exec_kernel":
             c.set_verify_checksum(True)
         got = cz.decode_batch_host([z for _, z, _ in files], [e["orig_len"] + 64 for _, _, e in files], c)
@@ -511,6 +513,7 @@ def test_bench_configuration_all_frames(cz):
     torch.cuda.synchronize()
     c = cz.Context(0, torch.cuda.current_stream().cuda_stream)
     c.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
+    c.set_literal_arena(int(b.regen.sum()) + (16 << 20))
     try:
         c.decode_batch_device(t_in.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), n, t_out.data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t_res.data_ptr())
         torch.cuda.synchronize()
