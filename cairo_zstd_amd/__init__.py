@@ -90,6 +90,13 @@ class Context:
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
 
+    def last_prepass_counts(self, n: int):
+        """(frames with chain records, frames with literal nodes) of the last batch launch of n frames."""
+        a, b = C.c_size_t(), C.c_size_t()
+        if hasattr(lib(), "cz_context_last_prepass_counts"):
+            lib().cz_context_last_prepass_counts(self._h, n, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def last_literals_tail_ms(self) -> float:
         """Milliseconds the last launch waited for the literals pass after the chain kernel was done."""
         if not hasattr(lib(), "cz_context_last_literals_tail_ms"):

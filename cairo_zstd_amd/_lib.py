@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
         L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.cz_context_set_exec_kernel.restype = C.c_int
         L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
+    if hasattr(L, "cz_context_last_prepass_counts"):
+        L.cz_context_last_prepass_counts.restype = C.c_int
+        L.cz_context_last_prepass_counts.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
     if hasattr(L, "cz_context_last_literals_tail_ms"):
         L.cz_context_last_literals_tail_ms.restype = C.c_int
         L.cz_context_last_literals_tail_ms.argtypes = [vp, C.POINTER(C.c_float)]

@@ -23,8 +23,7 @@
  * bits, resolve offsets and execute the sequences without tables, bitstream or chain.
  *
  * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
- * table error, invalid code, overrun, left-over bits, more than 32 extra bits in a sequence,
- * arena overflow, > 64 symbols in a table description) — and for frames whose first sequences
+ * table error, invalid code, overrun, left-over bits, arena overflow, > 64 symbols in a table description) — and for frames whose first sequences
  * section is short (chain_min_nseq), where it would not pay — it marks the whole frame "no chain info"
  * (frame_first[f] = 0) and the main kernel decodes that frame entirely by itself, producing the
  * reference's status codes in the reference's order.  Nothing here reports errors.
@@ -38,7 +37,8 @@ static_assert(CZC_SLOTS * CZC_LPS <= 64, "quads of one wave");
 #define CZC_RING 512u       /* fits in the build scratch it is overlaid with; filled at most 256 bytes per top-up */
 #define CZC_STEPS 32u       /* steps per group (the asm block is unrolled for exactly this many) */
 static_assert(((CZC_STEPS * 58u + 7u) / 8u + 12u) + 12u <= 256u + 12u, "a top-up adds at most 256 bytes: one must be enough for the next group");
-#define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor */
+#define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor;
+                                                          also covers CZC_WIDE_STEPS (16) steps of czc_step at 89 bits (63 extra bits) each */
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML + 256 B OF */
 /* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
    main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
@@ -64,7 +64,7 @@ struct CzChainSlot {
             uint16_t counters_ml[CZC_MAXSYM];
         };
         struct {
-            __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[8..15] == the last 8 bytes of ring */
+            __attribute__((aligned(16))) uint8_t mirror[16];   /* mirror[4..15] == the last 12 bytes of ring */
             uint8_t ring[CZC_RING];                      /* reversed bitstream, indexed by absolute address & (CZC_RING - 1) */
         };
     };
@@ -147,7 +147,7 @@ __device__ static inline void czc_commit(CzChainSlot& sk, int has_slot, intptr_t
         if (c < cnt) {
             const uint32_t slot = (uint32_t)(((uintptr_t)old_lo - 16u * (c + 1)) & (CZC_RING - 1));
             *(uint4*)&sk.ring[slot] = pre.v[r];
-            if (slot == CZC_RING - 16) { *(uint32_t*)&sk.mirror[8] = pre.v[r].z; *(uint32_t*)&sk.mirror[12] = pre.v[r].w; }
+            if (slot == CZC_RING - 16) { *(uint32_t*)&sk.mirror[4] = pre.v[r].y; *(uint32_t*)&sk.mirror[8] = pre.v[r].z; *(uint32_t*)&sk.mirror[12] = pre.v[r].w; }
         }
     }
 }
@@ -170,7 +170,7 @@ struct CzcLane {
     int32_t  u;              /* ring-space bit address just above the next unread bit */
     uint32_t ph;             /* u & 31 */
     uint32_t w0, w1, w2;     /* ring words at ((u >> 5) & 127) - 2, - 1, - 0 */
-    uint32_t slow;           /* largest number of extra bits seen in one sequence (> 32: the frame is left alone) */
+    uint32_t slow;           /* largest number of extra bits seen in one sequence of the current asm group (> 32: the group is redone by czc_step) */
 };
 struct CzcRole {
     const uint16_t* tb;      /* this lane's table (LDS) */
@@ -178,6 +178,7 @@ struct CzcRole {
     uint32_t m1, m2;         /* 0xFF00 where the LL / ML state bits precede this lane's in the stream */
     uint32_t sh;             /* position of this lane's state in the record's high word */
     uint32_t lane0;          /* lane 0 of its quad */
+    uint32_t sbits;          /* ring-space bit address of the start of the block's bitstream (u - sbits = bits still unread) */
 };
 #define CZC_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 template <int CTRL> __device__ static inline uint32_t czc_qp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
@@ -187,9 +188,20 @@ __device__ static inline void czc_ring_words(CzcLane& c, const CzcRole& ro) {
     c.w0 = *(const uint32_t*)ba; c.w1 = *(const uint32_t*)(ba + 4); c.w2 = *(const uint32_t*)(ba + 8);
     c.ph = (uint32_t)c.u & 31u;
 }
+/* 32 stream bits below ring-space bit address v, straight from the slot's ring */
+__device__ static inline uint32_t czc_bits32(const CzcRole& ro, uint32_t v) {
+    const uint8_t* ba = ro.ringm8 + (__builtin_amdgcn_ubfe(v, 5, 7) << 2);
+    return __builtin_amdgcn_alignbit(*(const uint32_t*)(ba + 8), *(const uint32_t*)(ba + 4), v & 31u);
+}
 /* One step (sequence_section_decoder.cairo:223-286, serial core) in plain C++: all 64 lanes call it
  * together.  `act`: this lane's chain takes the step; `last`: it is the block's last sequence (no
- * state update, :258); `store`: this lane writes the record.  The asm block below is this, scheduled. */
+ * state update, :258); `store`: this lane writes the record.  The asm block below is this, scheduled — for
+ * sequences of at most 32 extra bits.  This version takes any sequence (up to 16 + 16 + 31 extra bits): the record
+ * of a wider one carries, instead of the 32 stream bits, the bit position of the sequence (bit 31 of the high word
+ * set), and the decode kernel reads the extra bits from the bitstream itself.  Callers keep
+ * CZC_WIDE_STEPS x 89 bits below the cursor staged. */
+#define CZC_WIDE_STEPS 16u
+static_assert((CZC_WIDE_STEPS * 89u + 7u) / 8u + 12u <= CZC_NEED && CZC_STEPS % CZC_WIDE_STEPS == 0, "a redone asm group is whole wide groups, each within the staged bytes");
 __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL uint64_t* rec, int act, int last, int store) {
     const uint32_t n = (uint32_t)__builtin_clz(c.E);                    /* E != 0 in a built table */
     const uint32_t x = __builtin_amdgcn_ubfe(c.E, 16, 5);
@@ -199,15 +211,14 @@ __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL 
     const uint32_t incl = (t1 + t2 + p) >> 8;                           /* state bits up to and including this lane's */
     const uint32_t a_ = T & 0xFFu;
     /* 32 stream bits that follow the a_ extra bits (read order: extras first, :239) */
-    const uint32_t sel = c.ph >= a_;
-    const uint32_t xh = __builtin_amdgcn_alignbit(sel ? c.w2 : c.w1, sel ? c.w1 : c.w0, (c.ph - a_) & 31u);
+    const uint32_t xh = czc_bits32(ro, (uint32_t)c.u - a_);
     const uint32_t bits = __builtin_amdgcn_ubfe(xh, (0u - incl) & 31u, n);
-    const uint32_t window = __builtin_amdgcn_alignbit(c.w2, c.w1, c.ph);
+    const uint32_t window = czc_bits32(ro, (uint32_t)c.u);
     const uint32_t cS = c.S << ro.sh;
     const uint32_t H = cS + czc_qp<CZC_QP(1, 2, 0, 3)>(cS) + czc_qp<CZC_QP(2, 0, 1, 3)>(cS);
     if (act) {
-        if (store) *rec = (uint64_t)window | ((uint64_t)H << 32);
-        c.slow = c.slow > a_ ? c.slow : a_;
+        if (store) *rec = a_ <= 32 ? ((uint64_t)window | ((uint64_t)H << 32))
+                                   : ((uint64_t)((uint32_t)c.u - ro.sbits) | ((uint64_t)(H | CZC_REC_WIDE) << 32));
         if (last) c.u -= (int32_t)a_;
         else {
             c.S = (((c.E >> 22) << n) | bits) & 511u;                  /* (v << num_bits) carries the marker to bit 9 */
@@ -322,6 +333,86 @@ __device__ static inline void czc_group_asm(CzcLane& c, const CzcRole& ro, CZ_GL
           "v100", "v101", "v102", "v103", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
           "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125");
     c.S -= 512u;
+}
+
+/* The same group for blocks that hold sequences of more than 32 extra bits (up to 16 + 16 + 31): FOUR ring words are kept
+ * (v[124:127] = words -3 .. 0 at the cursor), the 32 bits behind the extra bits are picked from three word pairs instead of
+ * two, and the record of a wide sequence carries its bit position (low word) and the CZC_REC_WIDE flag instead of the
+ * stream bits.  About eight instructions per step more than the narrow group: a block switches to it at its first wide
+ * sequence (the narrow group that met it is redone).  v119 position, v128 record flag, s[12:13] "this sequence is wide". */
+#define CZC_ASMW_HEAD(WIN) \
+    "s_waitcnt lgkmcnt(2)\n" \
+    "v_ffbh_u32 v100, %[E]\n" \
+    "v_and_or_b32 v101, %[E], %[XM], %[K64]\n" \
+    "v_sub_u32 v102, v101, v100\n" \
+    "v_lshrrev_b32 v103, 22, %[E]\n" \
+    "v_sub_u32 v119, %[U], %[SB]\n"               /* bits still unread before this sequence */ \
+    "v_add_u32_dpp v105, v102, v102 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_and_b32_dpp v106, v102, %[M1] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n" \
+    "v_and_b32_dpp v107, v102, %[M2] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp v105, v102, v105 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add3_u32 v109, v106, v107, v102\n" \
+    "v_bfe_u32 v108, v105, 16, 8\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_cmp_ge_u32 vcc, %[PH], v108\n" \
+    "v_sub_u32 v110, %[PH], v108\n" \
+    "v_alignbit_b32 " WIN ", v127, v126, %[PH]\n" \
+    "v_cndmask_b32 v111, v126, v127, vcc\n" \
+    "v_cndmask_b32 v112, v125, v126, vcc\n" \
+    "v_cmp_gt_i32 vcc, %[N32], v110\n"            /* the 32 bits start more than one word below the cursor word */ \
+    "v_cmp_lt_u32_e64 s[12:13], 32, v108\n" \
+    "s_nop 0\n" \
+    "v_cndmask_b32 v111, v111, v125, vcc\n" \
+    "v_cndmask_b32 v112, v112, v124, vcc\n" \
+    "v_alignbit_b32 v113, v111, v112, v110\n" \
+    "v_bfe_u32 v116, v113, v109, v100\n" \
+    "v_lshl_or_b32 %[S], v103, v100, v116\n" \
+    "v_lshl_add_u32 v117, %[S], 1, %[TB]\n" \
+    "ds_read_u16_d16_hi %[E], v117\n"
+#define CZC_ASMW_TAIL(STORE, WIN, H, NEXTH) \
+    "v_cndmask_b32_e64 " WIN ", " WIN ", v119, s[12:13]\n" \
+    "v_cndmask_b32_e64 v128, 0, %[FL], s[12:13]\n" \
+    "v_or_b32 " H ", " H ", v128\n" \
+    STORE \
+    "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n" \
+    "v_dot4c_i32_i8_e32 %[U], 0x01ff0001, v105\n" \
+    "v_and_b32 v129, 31, v108\n" \
+    "v_add_u32_dpp " NEXTH ", v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp " NEXTH ", v118, " NEXTH " quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_bfe_u32 v114, %[U], 5, 7\n" \
+    "v_and_b32 %[PH], 31, %[U]\n" \
+    "v_lshl_add_u32 v115, v114, 2, %[RB]\n" \
+    "ds_read2_b32 v[124:125], v115 offset1:1\n" \
+    "ds_read2_b32 v[126:127], v115 offset0:2 offset1:3\n"
+#define CZC_ASMW_EVEN(OFF) CZC_ASMW_HEAD("v120") CZC_ASMW_TAIL("", "v120", "v121", "v123")
+#define CZC_ASMW_ODD(OFF) CZC_ASMW_HEAD("v122") CZC_ASMW_TAIL(CZC_ASM_STORE(OFF), "v122", "v123", "v121")
+#define CZC_ASMW_PAIR(A) CZC_ASMW_EVEN(A) CZC_ASMW_ODD(A)
+__device__ static inline void czc_group_asm_wide(CzcLane& c, const CzcRole& ro, CZ_GLOBAL uint64_t* rec) {
+    const uint32_t tb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)ro.tb;
+    const uint32_t rb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)ro.ringm8 - 4u;   /* ring - 12: four words end at the cursor word */
+    const uint32_t tbm = tb32 - 1024u, nk = 0u - (512u << ro.sh), k64 = ro.lane0 ? 0x40000040u : 0x40u;
+    c.S += 512u;
+    asm volatile(
+        "v_bfe_u32 v114, %[U], 5, 7\n"
+        "v_lshl_add_u32 v115, v114, 2, %[RB]\n"
+        "ds_read2_b32 v[124:125], v115 offset1:1\n"
+        "ds_read2_b32 v[126:127], v115 offset0:2 offset1:3\n"
+        /* state word of the first record */
+        "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp v121, v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n"
+        "v_add_u32_dpp v121, v118, v121 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n"
+        CZC_ASMW_PAIR(0) CZC_ASMW_PAIR(16) CZC_ASMW_PAIR(32) CZC_ASMW_PAIR(48) CZC_ASMW_PAIR(64) CZC_ASMW_PAIR(80) CZC_ASMW_PAIR(96) CZC_ASMW_PAIR(112)
+        CZC_ASMW_PAIR(128) CZC_ASMW_PAIR(144) CZC_ASMW_PAIR(160) CZC_ASMW_PAIR(176) CZC_ASMW_PAIR(192) CZC_ASMW_PAIR(208) CZC_ASMW_PAIR(224) CZC_ASMW_PAIR(240)
+        "s_waitcnt lgkmcnt(0)\n"
+        : [E] "+v"(c.E), [S] "+v"(c.S), [U] "+v"(c.u), [PH] "+v"(c.ph)
+        : [TB] "v"(tbm), [RB] "v"(rb32), [M1] "v"(ro.m1 ? 0xFFu : 0u), [M2] "v"(ro.m2 ? 0xFFu : 0u), [SH] "v"(ro.sh), [NK] "v"(nk), [K64] "v"(k64),
+          [SB] "v"(ro.sbits), [FL] "v"(CZC_REC_WIDE), [XM] "s"(0x1F0000u), [N32] "s"(-32), [RP] "v"(rec)
+        : "memory", "vcc", "s12", "s13",
+          "v100", "v101", "v102", "v103", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129");
+    c.S -= 512u;
+    czc_ring_words(c, ro);                                              /* the three words the narrow group and its callers keep */
 }
 #endif
 
@@ -523,34 +614,34 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
             }
             /* ---- initial states (owner), handed to the lanes of the quad */
-            int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0, slow0 = 0;
+            int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0, bad0 = 0;
             if (have) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
                 for (;;) {                                              /* padding :46-64 */
                     const uint32_t b = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> 63) : 0; p -= 1; skipped++;
                     if (b == 1 || skipped > 8) break;
                 }
-                if (skipped > 8) slow0 = 64;
+                if (skipped > 8) bad0 = 1;
                 uint32_t stv[3] = {0, 0, 0};
                 for (int t = 0; t < 3; t++) {                           /* init order LL, OF, ML (:207-218) */
                     if (rles[t] >= 0) continue;
                     stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - logs[t])) : 0; p -= (int32_t)logs[t];
                 }
                 st_ll = stv[0]; st_of = stv[1]; st_ml = stv[2];
-                if (p < 0) slow0 = 64;
+                if (p < 0) bad0 = 1;
                 u0 = (int32_t)sbits + p;
             }
             CzcLane c;
             {
                 const uint32_t qll = czc_q0(st_ll), qml = czc_q0(st_ml), qof = czc_q0(st_of);
-                c.u = (int32_t)czc_q0((uint32_t)u0); c.slow = czc_q0(slow0);
+                c.u = (int32_t)czc_q0((uint32_t)u0); c.slow = 0; ro.sbits = sbits;
                 c.S = ql == 0 ? qll : (ql == 1 ? qml : (ql == 2 ? qof : 0u));
                 if (!qhave || ql == 3) { ro.tb = cs.idle; c.S = 0; } else ro.tb = my_table;
                 c.E = (uint32_t)ro.tb[c.S] << 16;
                 czc_ring_words(c, ro);
             }
             CZ_GLOBAL uint64_t* rec = (CZ_GLOBAL uint64_t*)(a.chain_arena + czc_q0_64(hdr) + 4 + CZC_MAP_WORDS);
-            uint32_t done = 0;
+            uint32_t done = 0; int wide = 0;                         /* wide: this wave met a sequence of > 32 extra bits in this round of blocks */
             int chain_live = qhave;
             CZC_PROF_ACC(1);
             while (__ballot(chain_live)) {
@@ -574,17 +665,31 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     }
                 }
                 {
-                    /* uniform choice of the loop flavour for this group of CZC_STEPS steps */
+                    /* uniform choice of the loop flavour: the scheduled asm group of CZC_STEPS steps unless a chain is near its
+                       end or the last asm group met a sequence of more than 32 extra bits (then that stretch is redone here) */
                     const uint32_t left = qnseq - done;
                     const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
-                    const uint32_t steps = !chain_live ? 0u : (left < CZC_STEPS ? left : CZC_STEPS);
-                    (void)tail;
+                    int ran_asm = 0;
+                    (void)tail; (void)wide;
 #if defined(__HIP_DEVICE_COMPILE__)
-                    if (!tail) czc_group_asm(c, ro, chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8));
-                    else
+                    if (!tail) {
+                        CZ_GLOBAL uint64_t* rp = chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8);
+                        if (!wide) {
+                            const CzcLane sv = c;
+                            c.slow = 0;
+                            czc_group_asm(c, ro, rp);
+                            if (__ballot(chain_live && ql < 3 && c.slow > 32)) { c = sv; wide = 1; }   /* redo this group, and the rest of the block, wide */
+                        }
+                        if (wide) czc_group_asm_wide(c, ro, rp);
+                        if (chain_live) done += CZC_STEPS;
+                        ran_asm = 1;
+                    }
 #endif
-                    for (uint32_t i = 0; i < CZC_STEPS; i++) czc_step(c, ro, rec + done + i, i < steps, done + i + 1 == qnseq, ql == 0);
-                    done += steps;
+                    if (!ran_asm) {
+                        const uint32_t steps = !chain_live ? 0u : (left < CZC_WIDE_STEPS ? left : CZC_WIDE_STEPS);
+                        for (uint32_t i = 0; i < CZC_WIDE_STEPS; i++) czc_step(c, ro, rec + done + i, i < steps, done + i + 1 == qnseq, ql == 0);
+                        done += steps;
+                    }
                     if (chain_live && done >= qnseq) { chain_live = 0; ro.tb = cs.idle; c.S = 0; c.E = (uint32_t)CZC_E16_IDLE << 16; }
                     CZC_PROF_ACC(3); CZC_PROF_CNT(6);
                 }
@@ -593,9 +698,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             if (have) {
                 /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
 #ifdef CZ_EMU_DEBUG
-                fprintf(stderr, "chain f=%u nseq=%u slow=%u rem=%d\n", f, nseq, c.slow, c.u - (int32_t)sbits);
+                fprintf(stderr, "chain f=%u nseq=%u bad0=%u rem=%d\n", f, nseq, bad0, c.u - (int32_t)sbits);
 #endif
-                if (c.slow > 32 || c.u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* > 32 extra bits / overrun / ExtraBits */
+                if (bad0 || c.u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* padding / overrun / ExtraBits */
                 else {
                     uint64_t* h = a.chain_arena + hdr;
                     h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;

@@ -99,17 +99,24 @@ __device__ static inline CzxXf czx_xf_compose(const CzxXf& f, const CzxXf& g) {
 #define CZX_XF_ID 0x24u   /* slot k = entering slot k */
 
 /* codes -> values for the record of this lane (sequence_section_decoder.cairo:239-256) */
-__device__ static inline void czx_decode_record(uint64_t r, int active, uint32_t& ll, uint32_t& ml, uint32_t& ov) {
+__device__ static inline void czx_decode_record(uint64_t r, int active, cz_gcptr bits, uint32_t& ll, uint32_t& ml, uint32_t& ov) {
     const uint8_t* mapll = (const uint8_t*)CZ_FSE_LL; const uint8_t* mapml = mapll + 512; const uint8_t* mapof = mapll + 1024;
     ll = 0; ml = 0; ov = 4;
     if (active) {
         const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
         const uint32_t oc = mapof[(st >> 18) & 255];
         const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
-        const uint32_t mx = tm >> 24, lx = tl >> 24;                    /* <= 32 in total (the pre-pass leaves other frames alone) */
-        ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);       /* :243 */
-        ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);             /* :249-256 */
-        ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+        const uint32_t mx = tm >> 24, lx = tl >> 24;
+        if (!(st & CZC_REC_WIDE)) {
+            ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */
+            ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);         /* :249-256 */
+            ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+        } else {                                                        /* more than 32 extra bits: the record says where they are in the bitstream */
+            const uint64_t W = cz_stream_window64(bits, xt);
+            ov = (1u << oc) + cz_field(W, 0, oc);
+            ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);
+            ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
+        }
     }
 }
 
@@ -442,10 +449,11 @@ __device__ static int czx_run_frame(const cz_batch_args& a, uint32_t f, cz_gptr 
             CzxBlock B; B.out = out; B.cap = cap; B.blk_start = produced;
             B.lit.rle = 0; B.lit.byte = 0; B.lit.len = regen; B.lit.p = blk;
             /* chain records of this block */
-            cz_gcptr64 rec = nullptr; uint32_t mapflags = 0;
+            cz_gcptr64 rec = nullptr; uint32_t mapflags = 0; cz_gcptr seqbits = blk;
             if (nseq) {
                 if (!cursor) return 1;
-                const uint64_t w0 = arena[cursor], w2 = arena[cursor + 2];
+                const uint64_t w0 = arena[cursor], w1 = arena[cursor + 1], w2 = arena[cursor + 2];
+                seqbits = blk + cz_uni((uint32_t)w1);
                 cz_gcptr64 maps = arena + cursor + 4;
                 rec = maps + CZ_CHAIN_MAP_WORDS;
                 cursor = cz_uni64(w2);
@@ -505,7 +513,7 @@ __device__ static int czx_run_frame(const cz_batch_args& a, uint32_t f, cz_gptr 
                         const int active = (uint32_t)LANE < cnt;
                         const uint64_t r = active ? rec[first + (uint32_t)LANE] : 0;
                         uint32_t ll, ml, ov;
-                        czx_decode_record(r, active, ll, ml, ov);
+                        czx_decode_record(r, active, seqbits, ll, ml, ov);
                         const CzxXf xf = czx_history_symbolic(cnt, ll, ov);
                         const uint32_t sl = cz_readlane(cz_wave_incl_scan(ll), 63), st = cz_readlane(cz_wave_incl_scan(ll + ml), 63);
                         if (LANE == 0) { CzxSum& s = CZX_SUMS[c]; s.a = sl; s.b = st; s.sel = xf.sel; s.v[0] = xf.v0; s.v[1] = xf.v1; s.v[2] = xf.v2; }
@@ -580,7 +588,7 @@ __device__ static int czx_run_frame(const cz_batch_args& a, uint32_t f, cz_gptr 
                         const int active = (uint32_t)LANE < cnt;
                         const uint64_t r = active ? rec[first + (uint32_t)LANE] : 0;
                         uint32_t ll, ml, ov;
-                        czx_decode_record(r, active, ll, ml, ov);
+                        czx_decode_record(r, active, seqbits, ll, ml, ov);
                         const CzxSum s = CZX_SUMS[c];
                         uint32_t e0 = cz_uni(s.v[0]), e1 = cz_uni(s.v[1]), e2 = cz_uni(s.v[2]);
                         const uint32_t actual = cz_history(cnt, ll, ov, e0, e1, e2);

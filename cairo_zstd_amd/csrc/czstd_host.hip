@@ -223,6 +223,26 @@ CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) re
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
 
+/* Diagnostics of the last batch launch (synchronises): how many of its n frames got chain records from the pre-pass,
+ * and how many got literal nodes from the literals pass. */
+CZ_EXPORT int cz_context_last_prepass_counts(cz_context* c, size_t n, size_t* with_chain, size_t* with_literals) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (with_chain) *with_chain = 0;
+    if (with_literals) *with_literals = 0;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> h(n);
+    if (with_chain && c->chain_arena && c->frame_first && n <= c->frame_first_cap) {
+        CZ_HIP(c, hipMemcpy(h.data(), c->frame_first, n * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) *with_chain += h[i] != 0;
+    }
+    if (with_literals && c->lit_arena && c->lit_first && n <= c->lit_first_cap) {
+        CZ_HIP(c, hipMemcpy(h.data(), c->lit_first, n * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) *with_literals += h[i] != 0;
+    }
+    return CZ_OK;
+}
+
 /* How long the last launch went on waiting for the literals pass after cz_chain_kernel was done (0: no literals pass). */
 CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;

@@ -1327,8 +1327,19 @@ __device__ static int cz_sequences(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, c
  * ML and OF tables.  This pass needs neither decoding tables nor the bitstream, only the maps (kept in
  * the LDS that holds the FSE tables otherwise; they persist over Repeat-mode blocks). */
 #define CZ_CHAIN_MAP_WORDS 160u   /* LL 512 B, ML 512 B, OF 256 B */
+#define CZC_REC_WIDE 0x80000000u /* record of a sequence with more than 32 extra bits: low word = bits of the stream still unread before it */
+/* 64 stream bits below bit p of the reversed bitstream that starts at S (zero below bit 0); rare path of the record-driven decode */
+__device__ static inline uint64_t cz_stream_window64(cz_gcptr S, uint32_t p) {
+    if (p == 0) return 0;
+    const int32_t hb = (int32_t)((p - 1) >> 3);
+    uint64_t v = 0;
+    for (int k = 0; k < 8; k++) if (hb - k >= 0) v |= (uint64_t)S[hb - k] << (56 - 8 * k);
+    const uint32_t drop = 7u - ((p - 1) & 7u);
+    if (drop) { const uint32_t lo = hb - 8 >= 0 ? S[hb - 8] : 0u; v = (v << drop) | (lo >> (8 - drop)); }
+    return v;
+}
 __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& lit, cz_gcptr64 maps, cz_gcptr64 rec,
-                                                   uint32_t nseq, uint32_t mapflags) {
+                                                   uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
     uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapml = mapll + 512; uint8_t* mapof = mapll + 1024;
     CZ_PROF_DECL; CZ_PROF_T0();
     __syncthreads();
@@ -1349,10 +1360,17 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
             const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
             const uint32_t oc = mapof[(st >> 18) & 255];
             const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
-            const uint32_t mx = tm >> 24, lx = tl >> 24;                /* <= 32 in total (the pre-pass leaves other frames alone) */
-            ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */
-            ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);         /* :249-256 */
-            ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+            const uint32_t mx = tm >> 24, lx = tl >> 24;
+            if (!(st & CZC_REC_WIDE)) {                                 /* <= 32 extra bits: they are the top of the record's low word */
+                ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */
+                ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);     /* :249-256 */
+                ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+            } else {                                                    /* the low word says where the extra bits are in the bitstream */
+                const uint64_t W = cz_stream_window64(bits, xt);
+                ov = (1u << oc) + cz_field(W, 0, oc);
+                ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);
+                ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
+            }
         }
         const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
         return cz_chunk_plan(x, produced, lit_used, lit, cnt, ll, ml, actual);
@@ -1386,11 +1404,11 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
 /* Not inlined: the chunk loop gets the whole register budget to itself.  The execution context is
  * worked on in registers (wave-uniform) and written back once. */
 __device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec,
-                                                                 uint32_t nseq, uint32_t mapflags) {
+                                                                 uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
     CzExecCtx x = xref;
     x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
     x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
-    const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags);
+    const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags, bits);
     xref.produced = x.produced; xref.lit_used = x.lit_used;
     return e;
 }
@@ -1486,7 +1504,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     }
     if (chain_cursor) {
         /* cz_chain_kernel already ran this block's FSE chain: header = {nseq|map flags, bitstream_off, next}, code maps, records */
-        const uint64_t w0 = arena[chain_cursor], w2 = arena[chain_cursor + 2];
+        const uint64_t w0 = arena[chain_cursor], w1 = arena[chain_cursor + 1], w2 = arena[chain_cursor + 2];
         cz_gcptr64 maps = arena + chain_cursor + 4;
         cz_gcptr64 rec = maps + CZ_CHAIN_MAP_WORDS;
         chain_cursor = cz_uni64(w2);
@@ -1494,7 +1512,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         if (rn != nseq) return CZ_E_INVALID_ARG;                        /* cannot happen: both passes walk the same bytes */
         x.lit_used = 0;
         CZ_PROF_ACC(CZ_P_SEQTAB);
-        return cz_sequences_rec(x, lit, maps, rec, nseq, mapflags);
+        return cz_sequences_rec(x, lit, maps, rec, nseq, mapflags, blk + cz_uni((uint32_t)w1));
     }
     /* sequence tables */
     const uint32_t so = cz_uni(bc.seq_body_off);

@@ -122,6 +122,9 @@ int cz_context_set_verify_checksum(cz_context* ctx, int on);
 int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
 /* The part of it spent in the FSE-chain pre-pass kernel (0 when the pre-pass is off). */
 int cz_context_last_chain_ms(cz_context* ctx, float* ms);
+/* Diagnostics of the most recent batch launch of n frames (synchronises): frames that got chain records from the
+ * pre-pass, frames that got literal nodes from the literals pass. */
+int cz_context_last_prepass_counts(cz_context* ctx, size_t n, size_t* with_chain, size_t* with_literals);
 /* How long that launch went on waiting for the literals pass after the chain kernel was done (0: no literals pass). */
 int cz_context_last_literals_tail_ms(cz_context* ctx, float* ms);
 /* The part of it spent in cz_exec_frames_kernel (0 when it did not run). */
