@@ -107,7 +107,7 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
             else bl = (k - dbl) * width;
         }
         table[i] = CZC_E16(nb, bl, xb);
-        map[i] = (uint8_t)s;
+        if (map) map[i] = (uint8_t)s;
     }
     return 0;
 }
@@ -430,6 +430,199 @@ __device__ static inline void czc_group_asm_wide(CzcLane& c, const CzcRole& ro, 
 __device__ static inline uint32_t czc_q0(uint32_t v) { return (uint32_t)__shfl((int)v, LANE & ~3); }
 __device__ static inline uint64_t czc_q0_64(uint64_t v) { return ((uint64_t)czc_q0((uint32_t)(v >> 32)) << 32) | czc_q0((uint32_t)v); }
 
+/* ---- cz_scan_kernel: the block list ----------------------------------------------------------------
+ * The blocks of a frame are chained for EXECUTION (window, offset history), but the FSE chain of a block only needs that
+ * block's bitstream and its three tables — described in the block itself or, in Repeat mode, in an earlier block of the
+ * frame.  So the pre-pass works on blocks, not frames: one lane per frame walks the frame's block headers (no decoding:
+ * block header, literals-section header, sequences header: block_decoder.cairo:237-321, literals_section.cairo:81-175,
+ * sequence_section.cairo:77-114) and lists every compressed block that has sequences.  Two passes over the same walk:
+ *   pass 0  counts the blocks per size class (bit length of the sequence count) and the arena units per frame
+ *   pass 1  places each block's entry in descending size-class order (blocks of similar chain length end up in the same
+ *           waves of cz_chain_kernel), allocates the frame's records in the chain arena, links the per-block headers
+ *           in frame order and sets frame_first[f]
+ * A frame is listed up to its first irregularity (malformed header, truncated block, Repeat of a table nothing
+ * defined, first sequences section shorter than chain_min_nseq ...) and then NOT pre-passed: frame_first[f] = 0, its
+ * entries void.  Nothing here reports errors. */
+struct CzsBlk { uint32_t blk_off, bsize, nseq, sbody, modes; };
+/* the walk of one lane over its frame; cz_scan_kernel advances all lanes of a wave together, one listed block at a time,
+   so that the counters they share are bumped once per wave and size class (and the CPU emulator sees uniform control flow) */
+struct CzsWalk { const uint8_t* src; uint64_t len, pos; uint32_t defined; int first, active, ok; };
+__device__ static inline void czs_begin(CzsWalk& w, const uint8_t* src, uint64_t len, int valid) {
+    w.src = src; w.len = len; w.pos = 0; w.defined = 0; w.first = 1; w.active = 0; w.ok = 0;
+    if (!valid || len < 5 || len >= 0xFFFFFFF0ull) return;              /* block offsets are 32 bits */
+    const uint32_t magic = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
+    const uint32_t d = src[4];
+    const uint32_t single = (d >> 5) & 1, didf = d & 3, dl = didf == 3 ? 4 : didf, flag = d >> 6;
+    const uint32_t fl = flag == 0 ? (single ? 1u : 0u) : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
+    const uint32_t hl = 5 + (single ? 0 : 1) + dl + fl;
+    if (magic != 0xFD2FB528u || len < hl) return;                       /* frame.cairo:152-284: only the header's length and validity matter here */
+    if (!single) { const uint32_t wd = src[5]; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) return; }
+    w.pos = hl; w.active = 1;
+}
+/* advances to the next compressed block that has sequences: 1 with `b` filled, or 0 — the walk is over (w.active = 0) and
+   w.ok says whether the frame was regular to its end */
+__device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBlk& b) {
+    const uint8_t* src = w.src; const uint64_t len = w.len;
+    if (!w.active) return 0;
+    for (;;) {                                                          /* block_decoder.cairo:237-321 */
+        uint64_t pos = w.pos;
+        if (pos == ~0ull) { w.active = 0; w.ok = !w.first; return 0; }   /* the last block was the frame's last: a frame without sequences has nothing to pre-pass */
+        if (len - pos < 3) break;
+        const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
+        const uint32_t type = (b0 >> 1) & 3, size = (b0 >> 3) | (b1 << 5) | (b2 << 13), blast = b0 & 1;
+        if (type == 3 || size > 128u * 1024u) break;
+        const uint64_t body = pos + 3; const uint32_t content = type == 1 ? 1u : size;
+        if (len - body < content) break;
+        w.pos = blast ? ~0ull : body + content;
+        if (type != 2) continue;
+        /* literals section header (literals_section.cairo:81-175): sizes only */
+        const uint8_t* p = src + body;
+        if (size == 0) break;
+        const uint32_t l0 = p[0], lt = l0 & 3, fmt = (l0 >> 2) & 3;
+        const uint32_t need = lt <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
+        if (size < need) break;
+        const uint32_t l1 = need > 1 ? p[1] : 0, l2 = need > 2 ? p[2] : 0, l3 = need > 3 ? p[3] : 0, l4 = need > 4 ? p[4] : 0;
+        uint32_t upper;
+        if (lt <= 1) { const uint32_t regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
+        else upper = fmt <= 1 ? (l1 >> 6) + (l2 << 2) : (fmt == 2 ? (l2 >> 2) + (l3 << 6) : (l2 >> 6) + (l3 << 2) + (l4 << 10));
+        if (size - need < upper) break;
+        const uint32_t so = need + upper, sl_ = size - so;              /* sequence_section.cairo:77-114 */
+        if (sl_ == 0) break;
+        const uint32_t s0 = p[so];
+        uint32_t n = 0, hb = 0;
+        if (s0 == 0) { }
+        else if (s0 <= 127) { if (sl_ < 2) break; n = s0; hb = 1; }
+        else if (s0 <= 254) { if (sl_ < 3) break; n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
+        else { if (sl_ < 4) break; n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
+        if (!n) continue;                                               /* (128, 0: no sequences but a modes byte) */
+        if (w.first && n < chain_min_nseq) break;
+        b.blk_off = (uint32_t)body; b.bsize = size; b.nseq = n; b.modes = p[so + hb]; b.sbody = so + hb + 1;
+        int undefined = 0;
+        for (int t = 0; t < 3; t++) {                                   /* Repeat of a table nothing defined (sequence_section_decoder.cairo:483,551,643) */
+            const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
+            if (md == 3) { if (!((w.defined >> t) & 1u)) undefined = 1; } else w.defined |= 1u << t;
+        }
+        if (undefined) break;
+        w.first = 0;
+        return 1;
+    }
+    w.active = 0; w.ok = 0;                                             /* irregular: the frame is listed up to here and not pre-passed */
+    return 0;
+}
+__device__ static inline uint32_t czs_class(uint32_t nseq) { return cz_hbs(nseq); }   /* 1..17 */
+/* counters[cls] += 1 for every lane with `has`, one atomic per wave and class; returns the lane's ticket */
+__device__ static inline uint32_t czs_ticket(uint32_t* counters, int has, uint32_t cls) {
+    uint32_t ticket = 0;
+    for (unsigned long long rem = __ballot(has); rem;) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t c0 = (uint32_t)__shfl((int)cls, leader);
+        const unsigned long long m = __ballot(has && cls == c0);
+        uint32_t base = 0;
+        if (LANE == leader) base = atomicAdd(&counters[c0], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (has && cls == c0) ticket = base + (uint32_t)__popcll(m & ((1ull << LANE) - 1ull));
+        rem &= ~m;
+    }
+    return ticket;
+}
+
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_batch_args a) {
+    const uint32_t f = blockIdx.x * CZ_WG_THREADS + (uint32_t)LANE;
+    const int valid = f < a.n;
+    CzsWalk w;
+    czs_begin(w, valid ? a.in_base + a.in_off[f] : nullptr, valid ? a.in_len[f] : 0, valid);
+    CzsBlk b; b.blk_off = b.bsize = b.nseq = b.sbody = b.modes = 0;
+    if (a.scan_pass == 0) {
+        uint64_t units = 0;
+        while (__ballot(w.active)) {
+            const int has = czs_next(w, a.chain_min_nseq, b);
+            czs_ticket(a.scan_ctl, has, has ? czs_class(b.nseq) : 0u);
+            if (has) units += 4ull + CZC_MAP_WORDS + b.nseq;
+        }
+        if (valid) a.frame_first[f] = w.ok ? units : 0;                 /* between the passes: arena units the frame needs */
+        return;
+    }
+    /* pass 1: the frames of the wave get their share of the arena with one atomic */
+    const uint64_t units = valid ? a.frame_first[f] : 0;
+    uint64_t at = 0;
+    {
+        uint64_t incl = units;                                          /* inclusive prefix over the lanes */
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t lo = __shfl_up((uint32_t)incl, (unsigned)d), hi = __shfl_up((uint32_t)(incl >> 32), (unsigned)d); if (LANE >= d) incl += ((uint64_t)hi << 32) | lo; }
+        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63);
+        uint64_t wbase = 0;
+        if (LANE == 0 && total) wbase = atomicAdd(a.chain_top, (unsigned long long)total);
+        wbase = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(wbase >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0);
+        if (units) { at = 64ull + wbase + (incl - units); if (at + units > a.chain_capacity) at = 0; }   /* indices 0..63 are reserved: 0 = none, 8..39 = the sink of czc_group_asm */
+    }
+    uint32_t base[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { base[c] = run; run += a.scan_ctl[c]; } }   /* larger classes first */
+    uint64_t first_hdr = 0, prev_hdr = 0; uint32_t defidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; int placed = at != 0;
+    while (__ballot(w.active)) {
+        const int has = czs_next(w, a.chain_min_nseq, b);
+        const uint32_t cls = has ? czs_class(b.nseq) : 0u;
+        const uint32_t ticket = czs_ticket(a.scan_ctl + 32, has, cls);
+        if (!has) continue;
+        uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == cls) bb = base[c];
+        const uint32_t idx = bb + ticket;
+        if (idx >= a.blk_capacity) { placed = 0; continue; }
+        cz_blk_desc d; d.frame = f; d.blk_off = b.blk_off; d.bsize = b.bsize; d.nseq = at ? b.nseq : 0u; d.sbody = b.sbody; d.modes = b.modes; d.pad = 0; d.hdr = at;
+        for (int t = 0; t < 3; t++) {
+            const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
+            d.def[t] = md == 3 ? defidx[t] : 0xFFFFFFFFu;
+            if (md != 3) defidx[t] = idx;
+        }
+        a.blk_desc[idx] = d;
+        if (at) {
+            a.chain_arena[at + 2] = 0;
+            if (prev_hdr) a.chain_arena[prev_hdr + 2] = at; else first_hdr = at;
+            prev_hdr = at; at += 4ull + CZC_MAP_WORDS + b.nseq;
+        }
+    }
+    if (valid) a.frame_first[f] = placed ? first_hdr : 0;
+}
+
+/* ---- cz_chain_kernel ---------------------------------------------------------------------------------
+ * Table descriptions of one block (sequence_section_decoder.cairo:405-647), serial, by the slot's owner lane.
+ * want = tables to read (bit t: LL, OF, ML).  For a table in Predefined / FSE mode the normalised counts go to
+ * probs[t] and info gets (symbols - 1) | log << 6 at bits 10 t; for RLE mode rle[t] = the symbol; Repeat leaves all
+ * as they are.  stage: LDS copy of the content from offset sbody (stage_n bytes), or nullptr.  Returns 0 / 1 (irregular). */
+__device__ static int czc_parse_tables(cz_gcptr blk, uint32_t bsize, uint32_t sbody, uint32_t modes, uint32_t want, const uint8_t* stage, uint32_t stage_n,
+                                       int16_t (*probs)[CZC_MAXSYM], uint32_t* info, int32_t* rle, uint32_t* bitoff) {
+    uint32_t off = sbody;
+    for (int t = 0; t < 3; t++) {                                       /* LL, OF, ML */
+        const uint32_t md = (modes >> (6 - 2 * t)) & 3, max_log = t == 1 ? 8u : 9u;
+        const int take = (want >> t) & 1u;
+        if (md == 0) {
+            if (take) {
+                const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
+                const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u, lg = t == 1 ? 5u : 6u;
+                for (uint32_t s = 0; s < n; s++) probs[t][s] = d[s];
+                *info = (*info & ~(0x3FFu << (10 * t))) | (((n - 1) | (lg << 6)) << (10 * t));
+                rle[t] = -1;
+            }
+        } else if (md == 1) {
+            if (off >= bsize) return 1;
+            const uint32_t sym = blk[off]; off += 1;
+            if (take) {
+                if (sym >= (t == 0 ? 36u : (t == 1 ? 32u : 53u))) return 1;
+                rle[t] = (int32_t)sym; *info &= ~(0x3FFu << (10 * t));
+            }
+        } else if (md == 2) {
+            CzFBits br; br.g = (cz_gcptr)(blk + off); br.len = bsize - off; br.idx = 0; br.stage = stage; br.stage_lo = 0; br.stage_hi = 0;
+            if (stage && off - sbody < stage_n) { br.stage = stage + (off - sbody); br.stage_hi = stage_n - (off - sbody); }
+            uint32_t np, lg, used;
+            /* a description that is only stepped over is parsed into the counts of the (later) wanted table, which its own parse overwrites */
+            const int into = take ? t : (want & 2u ? 1 : 2);
+            if (cz_fse_read_probs(br, max_log, probs[into], &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM || np == 0) return 1;
+            if (take) { *info = (*info & ~(0x3FFu << (10 * t))) | (((np - 1) | (lg << 6)) << (10 * t)); rle[t] = -1; }
+            off += used;
+            if (off > bsize) return 1;
+        }
+        if ((want >> (t + 1)) == 0) break;                              /* nothing behind this table is wanted */
+    }
+    *bitoff = off;
+    return 0;
+}
+
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
     __shared__ CzChainShared cs;
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) cs.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
@@ -438,281 +631,206 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
     __syncthreads();
     const uint32_t qk = (uint32_t)LANE >> 2, ql = (uint32_t)LANE & 3u;  /* slot, lane of the quad: 0 LL (owner), 1 ML, 2 OF, 3 idle */
     const int has_slot = qk < CZC_SLOTS;
-    const int owner = has_slot && ql == 0;                              /* does the serial parsing of its slot's frame */
+    const int owner = has_slot && ql == 0;                              /* does the serial parsing of its slot's block */
     CzChainSlot& sl = cs.slot[has_slot ? qk : 0];
     const uint32_t kind = ql == 0 ? 0u : (ql == 1 ? 2u : 1u);           /* table of this lane in LL, OF, ML numbering */
     CzcRole ro;
-    ro.ringm8 = sl.ring - 8;
+    ro.ringm8 = sl.ring - 8; ro.tb = cs.idle; ro.sbits = 0;
     ro.m1 = (ql == 1 || ql == 2) ? 0xFF00u : 0u; ro.m2 = ql == 2 ? 0xFF00u : 0u; ro.sh = ql == 3 ? 0u : 9u * ql; ro.lane0 = ql == 0;
     const uint16_t* my_table = ql == 0 ? sl.t_ll : (ql == 1 ? sl.t_ml : sl.t_of);
 #ifdef CZ_PROFILE
     unsigned long long cprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
 #endif
+    uint32_t ndesc = 0; for (int c = 0; c < 20; c++) ndesc += a.scan_ctl[c];
+    if (ndesc > a.blk_capacity) ndesc = a.blk_capacity;
+    /* per slot (the same values in the four lanes of its quad, except where noted) */
+    int chain_live = 0, wide = 0, exhausted = 0;                        /* exhausted: owner lanes */
+    uint32_t qnseq = 0, done = 0, sbits = 0;
+    uintptr_t S = 0, E = 0; intptr_t ring_base = 0, loaded_lo = 0;
+    CZ_GLOBAL uint64_t* rec = nullptr;
+    /* owner lanes: the block in hand */
+    uint32_t o_frame = 0, o_nseq = 0, o_mapflags = 0, o_bitoff = 0, o_bad0 = 0; uint64_t o_hdr = 0; int o_have = 0;
+    CzcLane c; c.E = (uint32_t)CZC_E16_IDLE << 16; c.S = 0; c.u = 0; c.ph = 0; c.w0 = c.w1 = c.w2 = 0; c.slow = 0;
+    CzcPre pre;
+    for (uint32_t r = 0; r < CZC_PF; r++) pre.v[r] = uint4{0, 0, 0, 0};
     for (;;) {
-        /* ---- one frame per slot (owner lane; the other lanes of the quad follow through broadcasts) */
-        uint32_t f = 0xFFFFFFFFu;
-        if (owner) f = atomicAdd(a.chain_counter, 1u);
-        int frame_live = owner && f < a.n;
-        if (!__ballot(frame_live)) break;
-        const uint8_t* src = nullptr; uint64_t len = 0, pos = 0;
-        int punt = 0;
-        uint32_t logs[3] = {0, 0, 0}; int32_t rles[3] = {-1, -1, -1};       /* carried across the frame's blocks (Repeat mode) */
-        uint64_t first_hdr = 0, prev_hdr = 0;
-        if (frame_live) {
-            src = a.in_base + a.in_off[f]; len = a.in_len[f];
-            /* frame header (frame.cairo:152-284): only its length and validity matter here */
-            if (len < 5) punt = 1;
-            else {
-                const uint32_t magic = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
-                const uint32_t d = src[4];
-                const uint32_t single = (d >> 5) & 1, didf = d & 3, dl = didf == 3 ? 4 : didf, flag = d >> 6;
-                const uint32_t fl = flag == 0 ? (single ? 1u : 0u) : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
-                const uint32_t hl = 5 + (single ? 0 : 1) + dl + fl;
-                if (magic != 0xFD2FB528u || len < hl) punt = 1;
-                else if (!single) { const uint32_t wd = src[5]; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) punt = 1; }
-                pos = hl;
-            }
-            if (punt) frame_live = 0;
-        }
-        int frame_done = !frame_live;                                   /* owner lanes only */
-        /* ---- blocks: every slot advances to its next block that has sequences */
-        while (__ballot(!frame_done)) {
-            const uint8_t* blk = nullptr; uint32_t bsize = 0, nseq = 0, modes = 0, sbody = 0, blast = 0;
-            int have = 0;
-            if (!frame_done) {
-                for (;;) {                                              /* block_decoder.cairo:237-321 */
-                    if (len - pos < 3) { punt = 1; break; }
-                    const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
-                    const uint32_t type = (b0 >> 1) & 3, size = (b0 >> 3) | (b1 << 5) | (b2 << 13);
-                    blast = b0 & 1;
-                    if (type == 3 || size > 128u * 1024u) { punt = 1; break; }
-                    const uint64_t body = pos + 3; const uint32_t content = type == 1 ? 1u : size;
-                    if (len - body < content) { punt = 1; break; }
-                    if (type != 2) { pos = body + content; if (blast) break; continue; }
-                    /* literals section header (literals_section.cairo:81-175): sizes only */
-                    const uint8_t* p = src + body;
-                    if (size == 0) { punt = 1; break; }
-                    const uint32_t l0 = p[0], lt = l0 & 3, fmt = (l0 >> 2) & 3;
-                    const uint32_t need = lt <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
-                    if (size < need) { punt = 1; break; }
-                    const uint32_t l1 = need > 1 ? p[1] : 0, l2 = need > 2 ? p[2] : 0, l3 = need > 3 ? p[3] : 0, l4 = need > 4 ? p[4] : 0;
-                    uint32_t upper;
-                    if (lt <= 1) { const uint32_t regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
-                    else upper = fmt <= 1 ? (l1 >> 6) + (l2 << 2) : (fmt == 2 ? (l2 >> 2) + (l3 << 6) : (l2 >> 6) + (l3 << 2) + (l4 << 10));
-                    if (size - need < upper) { punt = 1; break; }
-                    const uint32_t so = need + upper, sl_ = size - so;  /* sequence_section.cairo:77-114 */
-                    if (sl_ == 0) { punt = 1; break; }
-                    const uint32_t s0 = p[so];
-                    if (s0 == 0) { pos = body + content; if (blast) break; continue; }
-                    uint32_t n = 0, hb = 0;
-                    if (s0 <= 127) { if (sl_ < 2) { punt = 1; break; } n = s0; hb = 1; }
-                    else if (s0 <= 254) { if (sl_ < 3) { punt = 1; break; } n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
-                    else { if (sl_ < 4) { punt = 1; break; } n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
-                    if (n == 0) { pos = body + content; if (blast) break; continue; }   /* 128,0: sequences = 0 but a modes byte */
-                    if (first_hdr == 0 && n < a.chain_min_nseq) { punt = 1; break; }
-                    blk = p; bsize = size; nseq = n; modes = p[so + hb]; sbody = so + hb + 1;
-                    pos = body + content; have = 1;
+        /* ---- slots without a block take the next one of the list */
+        if (__ballot(owner && !o_have && !exhausted)) {
+            cz_gcptr blk = nullptr; uint32_t bsize = 0, sbody = 0, modes = 0; uint32_t def[3] = {0, 0, 0};
+            int got = 0;
+            if (owner && !o_have && !exhausted) {
+                for (;;) {
+                    const uint32_t idx = atomicAdd(&a.scan_ctl[64], 1u);
+                    if (idx >= ndesc) { exhausted = 1; break; }
+                    const cz_blk_desc d = a.blk_desc[idx];
+                    if (!d.nseq) continue;                              /* void entry: its frame is not pre-passed */
+                    blk = (cz_gcptr)(a.in_base + a.in_off[d.frame] + d.blk_off); bsize = d.bsize; sbody = d.sbody; modes = d.modes;
+                    def[0] = d.def[0]; def[1] = d.def[1]; def[2] = d.def[2];
+                    o_frame = d.frame; o_nseq = d.nseq; o_hdr = d.hdr; o_have = 1; got = 1;
                     break;
                 }
-                if (punt || !have) frame_done = 1;
             }
-            /* ---- stage the head of the sequences section (table descriptions) linearly: 256 bytes */
+            /* stage the head of the sequences section (table descriptions) linearly: 256 bytes */
             {
-                const unsigned long long hm = __ballot(have);
-                if (hm) {
-                    const uintptr_t base = (uintptr_t)blk + sbody;
-                    const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk), Ek = Sk + czc_q0(bsize);
-                    if (czc_q0((uint32_t)have) && has_slot) for (uint32_t c = ql; c < 16; c += CZC_LPS) *(uint4*)&sl.stage[16 * c] = czc_load16(bk + 16 * c, Sk, Ek);
-                    __syncthreads();
+                const uintptr_t base = (uintptr_t)blk + sbody;
+                const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk), Ek = Sk + czc_q0(bsize);
+                __syncthreads();                                        /* the slot's ring (same LDS) is no longer read */
+                if (czc_q0((uint32_t)got) && has_slot) for (uint32_t cc = ql; cc < 16; cc += CZC_LPS) *(uint4*)&sl.stage[16 * cc] = czc_load16(bk + 16 * cc, Sk, Ek);
+                __syncthreads();
+            }
+            /* tables (sequence_section_decoder.cairo:405-647), serial per owner lane; a Repeat mode reads the description of
+               the block that defined the table (the tables in LDS belong to whatever block this slot had before) */
+            uint32_t binfo = 0; int32_t rles[3] = {-1, -1, -1}; int bad = 0;
+            if (got) {
+                o_mapflags = 0;
+                for (int t = 0; t < 3; t++) if (((modes >> (6 - 2 * t)) & 3) != 3) o_mapflags |= 1u << t;
+                bad = czc_parse_tables(blk, bsize, sbody, modes, 7u, sl.stage, 256u, sl.probs, &binfo, rles, &o_bitoff);
+                for (int t = 0; t < 3 && !bad; t++) if (((modes >> (6 - 2 * t)) & 3) == 3) {
+                    if (def[t] >= ndesc) { bad = 1; break; }
+                    const cz_blk_desc dd = a.blk_desc[def[t]];
+                    uint32_t dummy;
+                    bad = dd.frame != o_frame || czc_parse_tables((cz_gcptr)(a.in_base + a.in_off[dd.frame] + dd.blk_off), dd.bsize, dd.sbody, dd.modes, 1u << t, nullptr, 0,
+                                                                 sl.probs, &binfo, rles, &dummy);
                 }
-            }
-            /* ---- tables (sequence_section_decoder.cairo:405-647), serial per owner lane */
-            uint32_t bitoff = 0, mapflags = 0; uint64_t hdr = 0;
-            if (have) {                                                 /* arena: 4-word header + code maps + nseq records */
-                const unsigned long long units = 4ull + CZC_MAP_WORDS + nseq;
-                hdr = 64ull + atomicAdd(a.chain_top, units);         /* indices 0..63 are reserved: 0 = none, 8..39 = the sink of czc_group_asm */
-                if (hdr + units > a.chain_capacity) { punt = 1; have = 0; frame_done = 1; }
-            }
-            uint32_t binfo = 0;                                         /* per table, 10 bits: (symbols - 1) | log << 6; log 0 = nothing to build */
-            if (have) {
-                uint32_t off = sbody;
-                uint8_t* maps = (uint8_t*)(a.chain_arena + hdr + 4);
-                for (int t = 0; t < 3 && !punt; t++) {                  /* LL, OF, ML */
+                if (!bad) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
-                    uint8_t* map = t == 0 ? maps : (t == 2 ? maps + 512 : maps + 1024);
-                    const uint32_t md = (modes >> (6 - 2 * t)) & 3, max_log = t == 1 ? 8u : 9u;
-                    if (md != 3) mapflags |= 1u << t;
-                    if (md == 0) {
-                        const int8_t* d = t == 0 ? CZ_LL_DEFAULT : t == 1 ? CZ_OF_DEFAULT : CZ_ML_DEFAULT;
-                        const uint32_t n = t == 0 ? 36u : t == 1 ? 29u : 53u, lg = t == 1 ? 5u : 6u;
-                        for (uint32_t s = 0; s < n; s++) sl.probs[t][s] = d[s];
-                        binfo |= ((n - 1) | (lg << 6)) << (10 * t);
-                        logs[t] = lg; rles[t] = -1;
-                    } else if (md == 1) {
-                        /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
-                        if (off >= bsize) { punt = 1; break; }
-                        const uint32_t sym = blk[off]; off += 1;
-                        if (sym >= (t == 0 ? 36u : (t == 1 ? 32u : 53u))) { punt = 1; break; }
-                        table[0] = CZC_E16(0u, 0u, t == 1 ? sym : (cs.llml[(t == 2 ? 40u : 0u) + sym] >> 24));
-                        map[0] = (uint8_t)sym;
-                        rles[t] = (int32_t)sym;
-                    } else if (md == 2) {
-                        CzFBits br; br.g = (cz_gcptr)(blk + off); br.len = bsize - off; br.idx = 0; br.stage = sl.stage; br.stage_lo = 0; br.stage_hi = 0;
-                        if (off - sbody < 256) { br.stage = sl.stage + (off - sbody); br.stage_hi = 256 - (off - sbody); }
-                        uint32_t np, lg, used;
-                        if (cz_fse_read_probs(br, max_log, sl.probs[t], &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM) { punt = 1; break; }
-                        if (np == 0) { punt = 1; break; }
-                        binfo |= ((np - 1) | (lg << 6)) << (10 * t);
-                        logs[t] = lg; rles[t] = -1; off += used;
-                        if (off > bsize) { punt = 1; break; }
-                    } else if (rles[t] < 0 && logs[t] == 0) { punt = 1; break; }     /* Repeat of nothing */
+                    table[0] = CZC_E16(0u, 0u, t == 1 ? (uint32_t)rles[t] : (cs.llml[(t == 2 ? 40u : 0u) + (uint32_t)rles[t]] >> 24));
+                    if ((o_mapflags >> t) & 1u) ((uint8_t*)(a.chain_arena + o_hdr + 4))[t == 0 ? 0 : (t == 2 ? 512 : 1024)] = (uint8_t)rles[t];
                 }
-                bitoff = off;
-                if (punt) { have = 0; frame_done = 1; }
+                if (bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
             }
-            /* ---- build the tables: the LL, ML and OF table of a slot on lanes 0, 1, 2 of its quad, side by side */
+            /* build the tables: the LL, ML and OF table of a slot on lanes 0, 1, 2 of its quad, side by side */
             {
                 __syncthreads();                                        /* descriptions read: `stage` may become counters */
-                const uint32_t info = (czc_q0(have ? binfo : 0u) >> (10 * kind)) & 0x3FFu;
-                const uint64_t hk = czc_q0_64(hdr);
-                int bad = 0;
+                const uint32_t info = (czc_q0(got ? binfo : 0u) >> (10 * kind)) & 0x3FFu;
+                const uint64_t hk = czc_q0_64(o_hdr); const uint32_t mf = czc_q0(o_mapflags);
+                int tbad = 0;
                 if (has_slot && ql < 3 && (info >> 6)) {
                     uint16_t* table = kind == 0 ? sl.t_ll : (kind == 1 ? sl.t_of : sl.t_ml);
                     uint16_t* counters = kind == 0 ? (uint16_t*)sl.stage : (kind == 1 ? (uint16_t*)sl.stage + CZC_MAXSYM : sl.counters_ml);
                     uint8_t* maps = (uint8_t*)(a.chain_arena + hk + 4);
-                    uint8_t* map = kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024);
-                    bad = czc_fse_build16(table, sl.probs[kind], (info & 63u) + 1u, info >> 6, counters, cs.llml, kind, map);
+                    uint8_t* map = !((mf >> kind) & 1u) ? nullptr : (kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024));   /* Repeat: the decode kernel keeps the earlier map */
+                    tbad = czc_fse_build16(table, sl.probs[kind], (info & 63u) + 1u, info >> 6, counters, cs.llml, kind, map);
                 }
                 __syncthreads();
                 const int q0 = LANE & ~3;
-                const int anybad = __shfl(bad, q0) | __shfl(bad, q0 + 1) | __shfl(bad, q0 + 2);
-                if (have && anybad) { punt = 1; have = 0; frame_done = 1; }
+                const int anybad = __shfl(tbad, q0) | __shfl(tbad, q0 + 1) | __shfl(tbad, q0 + 2);
+                if (got && anybad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
             }
             CZC_PROF_ACC(0);
-            /* ---- bit ring: fill every live slot's ring with the top 256 bytes of its stream.  From here on
-                    every lane of a quad holds its slot's values. */
-            const int qhave = (int)czc_q0((uint32_t)have) && has_slot;
-            const uint32_t qnseq = czc_q0(nseq);
-            const uintptr_t qblk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk);
-            const uint32_t qbitoff = czc_q0(bitoff), qbsize = czc_q0(bsize);
-            const uintptr_t S = qhave ? qblk + qbitoff : 0, E = qhave ? qblk + qbsize : 0;
-            const uint32_t sbits = (uint32_t)(S & (CZC_RING - 1)) * 8u;
-            const intptr_t ring_base = (intptr_t)(S & ~(uintptr_t)(CZC_RING - 1));          /* ring-space bit u <-> byte ring_base + (u >> 3) */
-            intptr_t loaded_lo = 0;
-            CzcPre pre;
-            for (uint32_t r = 0; r < CZC_PF; r++) pre.v[r] = uint4{0, 0, 0, 0};
-            {
-                const unsigned long long hm = __ballot(qhave);
-                __syncthreads();
-                if (hm) {
-                    const intptr_t hi = (intptr_t)((E + 15) & ~(uintptr_t)15);
-                    loaded_lo = qhave ? hi - 256 : 0;
-                    czc_prefetch(pre, qhave, qhave ? hi : 0, S, E);
-                    czc_commit(sl, qhave, qhave ? hi : 0, loaded_lo, pre);
-                    __syncthreads();
-                    czc_prefetch(pre, qhave, loaded_lo, S, E);        /* the next 256 bytes: in registers long before they are needed */
-                }
+            /* the bit ring of the new blocks: the top 256 bytes of the stream; from here on every lane of a quad holds its slot's values */
+            const int qgot = (int)czc_q0((uint32_t)got) && has_slot;
+            const uint32_t gn = czc_q0(o_nseq);
+            const uintptr_t gblk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk);
+            const uint32_t gbitoff = czc_q0(o_bitoff), gbsize = czc_q0(bsize);
+            if (qgot) {
+                S = gblk + gbitoff; E = gblk + gbsize; qnseq = gn; done = 0; wide = 0;
+                sbits = (uint32_t)(S & (CZC_RING - 1)) * 8u;
+                ring_base = (intptr_t)(S & ~(uintptr_t)(CZC_RING - 1));   /* ring-space bit u <-> byte ring_base + (u >> 3) */
+                const intptr_t hi = (intptr_t)((E + 15) & ~(uintptr_t)15);
+                loaded_lo = hi - 256;
+                czc_prefetch(pre, 1, hi, S, E);
+                czc_commit(sl, 1, hi, loaded_lo, pre);
             }
-            /* ---- initial states (owner), handed to the lanes of the quad */
-            int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0, bad0 = 0;
-            if (have) {
+            __syncthreads();
+            if (qgot) czc_prefetch(pre, 1, loaded_lo, S, E);               /* the next 256 bytes: in registers long before they are needed */
+            /* initial states (owner), handed to the lanes of the quad */
+            int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0;
+            if (got) {
                 int32_t p = (int32_t)(E - S) * 8; int skipped = 0;
+                o_bad0 = 0;
                 for (;;) {                                              /* padding :46-64 */
                     const uint32_t b = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> 63) : 0; p -= 1; skipped++;
                     if (b == 1 || skipped > 8) break;
                 }
-                if (skipped > 8) bad0 = 1;
+                if (skipped > 8) o_bad0 = 1;
                 uint32_t stv[3] = {0, 0, 0};
                 for (int t = 0; t < 3; t++) {                           /* init order LL, OF, ML (:207-218) */
                     if (rles[t] >= 0) continue;
-                    stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - logs[t])) : 0; p -= (int32_t)logs[t];
+                    const uint32_t lg = (binfo >> (10 * t + 6)) & 15u;
+                    stv[t] = p > 0 ? (uint32_t)(czc_window(sl, (int32_t)sbits + p) >> (64 - lg)) : 0; p -= (int32_t)lg;
                 }
                 st_ll = stv[0]; st_of = stv[1]; st_ml = stv[2];
-                if (p < 0) bad0 = 1;
+                if (p < 0) o_bad0 = 1;
                 u0 = (int32_t)sbits + p;
             }
-            CzcLane c;
             {
-                const uint32_t qll = czc_q0(st_ll), qml = czc_q0(st_ml), qof = czc_q0(st_of);
-                c.u = (int32_t)czc_q0((uint32_t)u0); c.slow = 0; ro.sbits = sbits;
-                c.S = ql == 0 ? qll : (ql == 1 ? qml : (ql == 2 ? qof : 0u));
-                if (!qhave || ql == 3) { ro.tb = cs.idle; c.S = 0; } else ro.tb = my_table;
-                c.E = (uint32_t)ro.tb[c.S] << 16;
-                czc_ring_words(c, ro);
+                const uint32_t qll = czc_q0(st_ll), qml = czc_q0(st_ml), qof = czc_q0(st_of), qu = czc_q0((uint32_t)u0);
+                const uint64_t qh = czc_q0_64(o_hdr);
+                if (qgot) {
+                    c.u = (int32_t)qu; c.slow = 0; ro.sbits = sbits;
+                    c.S = ql == 0 ? qll : (ql == 1 ? qml : (ql == 2 ? qof : 0u));
+                    if (ql == 3) { ro.tb = cs.idle; c.S = 0; } else ro.tb = my_table;
+                    c.E = (uint32_t)ro.tb[c.S] << 16;
+                    czc_ring_words(c, ro);
+                    rec = (CZ_GLOBAL uint64_t*)(a.chain_arena + qh + 4 + CZC_MAP_WORDS);
+                    chain_live = 1;
+                }
             }
-            CZ_GLOBAL uint64_t* rec = (CZ_GLOBAL uint64_t*)(a.chain_arena + czc_q0_64(hdr) + 4 + CZC_MAP_WORDS);
-            uint32_t done = 0; int wide = 0;                         /* wide: this wave met a sequence of > 32 extra bits in this round of blocks */
-            int chain_live = qhave;
             CZC_PROF_ACC(1);
-            while (__ballot(chain_live)) {
-                /* keep CZC_NEED bytes below every live cursor staged; when one slot runs low, all top up */
-                {
-                    const int32_t uq = (int32_t)czc_qp<CZC_QP(0, 0, 0, 0)>((uint32_t)c.u);   /* lane 3 of a quad does not follow the cursor */
-                    const intptr_t curb = ring_base + ((uq > 0 ? uq - 1 : 0) >> 3);    /* byte that holds the next unread bit */
-                    const int need = chain_live && (curb - (intptr_t)CZC_NEED < loaded_lo);
-                    if (__ballot(need)) {
-                        /* lowest start whose 512 bytes still cover the word at the cursor */
-                        intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
-                        if (new_lo > loaded_lo) new_lo = loaded_lo;
-                        if (new_lo < loaded_lo - 256) new_lo = loaded_lo - 256;      /* czc_topup moves at most 16 pieces */
-                        __syncthreads();
-                        czc_commit(sl, chain_live, loaded_lo, new_lo, pre);
-                        loaded_lo = new_lo;
-                        __syncthreads();
-                        czc_prefetch(pre, chain_live, loaded_lo, S, E);
-                        if (chain_live) czc_ring_words(c, ro);            /* the words under the cursor may just have arrived */
-                        CZC_PROF_ACC(2); CZC_PROF_CNT(5);
-                    }
-                }
-                {
-                    /* uniform choice of the loop flavour: the scheduled asm group of CZC_STEPS steps unless a chain is near its
-                       end or the last asm group met a sequence of more than 32 extra bits (then that stretch is redone here) */
-                    const uint32_t left = qnseq - done;
-                    const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
-                    int ran_asm = 0;
-                    (void)tail; (void)wide;
-#if defined(__HIP_DEVICE_COMPILE__)
-                    if (!tail) {
-                        CZ_GLOBAL uint64_t* rp = chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8);
-                        if (!wide) {
-                            const CzcLane sv = c;
-                            c.slow = 0;
-                            czc_group_asm(c, ro, rp);
-                            if (__ballot(chain_live && ql < 3 && c.slow > 32)) { c = sv; wide = 1; }   /* redo this group, and the rest of the block, wide */
-                        }
-                        if (wide) czc_group_asm_wide(c, ro, rp);
-                        if (chain_live) done += CZC_STEPS;
-                        ran_asm = 1;
-                    }
-#endif
-                    if (!ran_asm) {
-                        const uint32_t steps = !chain_live ? 0u : (left < CZC_WIDE_STEPS ? left : CZC_WIDE_STEPS);
-                        for (uint32_t i = 0; i < CZC_WIDE_STEPS; i++) czc_step(c, ro, rec + done + i, i < steps, done + i + 1 == qnseq, ql == 0);
-                        done += steps;
-                    }
-                    if (chain_live && done >= qnseq) { chain_live = 0; ro.tb = cs.idle; c.S = 0; c.E = (uint32_t)CZC_E16_IDLE << 16; }
-                    CZC_PROF_ACC(3); CZC_PROF_CNT(6);
-                }
-            }
-            /* ---- finalize the block (owner) */
-            if (have) {
-                /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
-#ifdef CZ_EMU_DEBUG
-                fprintf(stderr, "chain f=%u nseq=%u bad0=%u rem=%d\n", f, nseq, bad0, c.u - (int32_t)sbits);
-#endif
-                if (bad0 || c.u - (int32_t)sbits != 0) { punt = 1; frame_done = 1; }   /* padding / overrun / ExtraBits */
-                else {
-                    uint64_t* h = a.chain_arena + hdr;
-                    h[0] = ((uint64_t)nseq << 32) | mapflags; h[1] = bitoff; h[2] = 0; h[3] = 0;
-                    if (prev_hdr) a.chain_arena[prev_hdr + 2] = hdr; else first_hdr = hdr;
-                    prev_hdr = hdr;
-                    if (blast) frame_done = 1;
-                }
-            } else if (!frame_done && blast) frame_done = 1;
-            __syncthreads();
         }
-        if (owner && f < a.n) a.frame_first[f] = punt ? 0 : first_hdr;
-        CZC_PROF_ACC(4);
+        if (!__ballot(chain_live)) { if (!__ballot(owner && !exhausted)) break; continue; }
+        /* ---- keep CZC_NEED bytes below every live cursor staged; when one slot runs low, all top up */
+        {
+            const int32_t uq = (int32_t)czc_qp<CZC_QP(0, 0, 0, 0)>((uint32_t)c.u);   /* lane 3 of a quad does not follow the cursor */
+            const intptr_t curb = ring_base + ((uq > 0 ? uq - 1 : 0) >> 3);    /* byte that holds the next unread bit */
+            const int need = chain_live && (curb - (intptr_t)CZC_NEED < loaded_lo);
+            if (__ballot(need)) {
+                /* lowest start whose 512 bytes still cover the word at the cursor */
+                intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
+                if (new_lo > loaded_lo) new_lo = loaded_lo;
+                if (new_lo < loaded_lo - 256) new_lo = loaded_lo - 256;      /* czc_commit moves at most 16 pieces */
+                __syncthreads();
+                czc_commit(sl, chain_live, loaded_lo, new_lo, pre);
+                loaded_lo = new_lo;
+                __syncthreads();
+                czc_prefetch(pre, chain_live, loaded_lo, S, E);
+                if (chain_live) czc_ring_words(c, ro);                    /* the words under the cursor may just have arrived */
+                CZC_PROF_ACC(2); CZC_PROF_CNT(5);
+            }
+        }
+        /* ---- one group of steps */
+        {
+            /* uniform choice of the loop flavour: the scheduled asm group of CZC_STEPS steps unless a chain is near its end;
+               a block that met a sequence of more than 32 extra bits goes on with the wide asm group (the narrow one is redone) */
+            const uint32_t left = qnseq - done;
+            const int tail = __ballot(chain_live && left <= CZC_STEPS) != 0;
+            int ran_asm = 0;
+            (void)tail; (void)wide;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (!tail) {
+                CZ_GLOBAL uint64_t* rp = chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8);
+                if (!__ballot(chain_live && wide)) {
+                    const CzcLane sv = c;
+                    c.slow = 0;
+                    czc_group_asm(c, ro, rp);
+                    const int hit = chain_live && ql < 3 && c.slow > 32;
+                    if (__ballot(hit)) { wide |= (int)czc_q0((uint32_t)hit); c = sv; }   /* redo this group wide; the slots that met a wide sequence stay wide for their block */
+                }
+                if (__ballot(chain_live && wide)) czc_group_asm_wide(c, ro, rp);
+                if (chain_live) done += CZC_STEPS;
+                ran_asm = 1;
+            }
+#endif
+            if (!ran_asm) {
+                const uint32_t steps = !chain_live ? 0u : (left < CZC_WIDE_STEPS ? left : CZC_WIDE_STEPS);
+                for (uint32_t i = 0; i < CZC_WIDE_STEPS; i++) czc_step(c, ro, rec + done + i, i < steps, done + i + 1 == qnseq, ql == 0);
+                done += steps;
+            }
+            CZC_PROF_ACC(3); CZC_PROF_CNT(6);
+        }
+        /* ---- finished chains: finalize the block (owner) and free the slot */
+        if (__ballot(chain_live && done >= qnseq)) {
+            const int fin = chain_live && done >= qnseq;
+            if (fin && owner) {
+                /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
+                if (o_bad0 || c.u - (int32_t)sbits != 0) a.frame_first[o_frame] = 0;    /* padding / overrun / ExtraBits: the frame is not pre-passed */
+                else { uint64_t* h = a.chain_arena + o_hdr; h[0] = ((uint64_t)o_nseq << 32) | o_mapflags; h[1] = o_bitoff; h[3] = 0; }
+                o_have = 0;
+            }
+            if (fin) { chain_live = 0; wide = 0; ro.tb = cs.idle; c.S = 0; c.E = (uint32_t)CZC_E16_IDLE << 16; }
+            CZC_PROF_ACC(4);
+        }
     }
 #ifdef CZ_PROFILE
     if (LANE == 0 && a.prof) for (int i = 0; i < 8; i++) atomicAdd(&a.prof[32 + i], cprof[i]);

@@ -46,6 +46,7 @@ struct cz_context {
     uint64_t* chain_arena = nullptr; uint64_t chain_capacity = 0;   /* 8-byte units */
     unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
+    cz_blk_desc* blk_desc = nullptr; uint32_t blk_capacity = 0; uint32_t* scan_ctl = nullptr;   /* block list of the pre-pass */
     int chain_grid = 0; uint32_t chain_min_nseq = 2048;
     /* optional literals pass next to the pre-pass, on a stream of its own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
@@ -122,6 +123,8 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->chain_top) (void)hipFree(c->chain_top);
     if (c->frame_first) (void)hipFree(c->frame_first);
+    if (c->blk_desc) (void)hipFree(c->blk_desc);
+    if (c->scan_ctl) (void)hipFree(c->scan_ctl);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
@@ -182,6 +185,11 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     }
     CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
     c->chain_capacity = bytes / 8;
+    /* every listed block takes at least 4 + CZ_CHAIN_MAP_WORDS + 1 arena units: that bounds the block list */
+    if (c->blk_desc) { (void)hipFree(c->blk_desc); c->blk_desc = nullptr; }
+    c->blk_capacity = (uint32_t)(c->chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
+    CZ_HIP(c, hipMalloc((void**)&c->blk_desc, (size_t)c->blk_capacity * sizeof(cz_blk_desc)));
+    if (!c->scan_ctl) CZ_HIP(c, hipMalloc((void**)&c->scan_ctl, CZ_SCAN_CTL_WORDS * 4));
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_chain_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 2;
     c->chain_grid = c->num_cu * occ;
@@ -304,9 +312,17 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             CZ_HIP(c, hipMemcpyAsync(c->lit_top, top0, 32, hipMemcpyHostToDevice, c->stream));
             a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
         }
-        const size_t waves = (n + CZC_SLOTS - 1) / CZC_SLOTS;
-        const int cgrid = (int)(waves < (size_t)c->chain_grid ? waves : (size_t)c->chain_grid);
-        if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));   /* everything the literals pass needs is enqueued */
+        /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
+        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl;
+        CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
+        const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
+        a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        CZ_HIP(c, hipGetLastError());
+        /* the literals pass may start when the chain kernel does (not before: it would take the LDS the chain kernel's
+           workgroups need and hold them up) */
+        if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));

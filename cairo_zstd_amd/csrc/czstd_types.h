@@ -39,6 +39,20 @@ typedef struct cz_device_task {
     cz_device_frame_state* state;             /* in/out */
 } cz_device_task;
 
+/* One compressed block that has sequences, as cz_scan_kernel lists it for cz_chain_kernel. */
+typedef struct cz_blk_desc {
+    uint32_t frame;           /* batch entry the block belongs to */
+    uint32_t blk_off;         /* offset of the block's content (behind its 3-byte header) in the frame */
+    uint32_t bsize;           /* size of the content */
+    uint32_t nseq;            /* sequences in the block; 0 = the entry is void (its frame is not pre-passed) */
+    uint32_t sbody;           /* offset in the content of the first table description (behind the sequences header) */
+    uint32_t modes;           /* the modes byte (sequence_section.cairo:47-57) */
+    uint32_t def[3];          /* LL, OF, ML: entry of the earlier block of the frame whose description a Repeat mode refers to; ~0 = not Repeat */
+    uint32_t pad;
+    uint64_t hdr;             /* index of the block's header in the chain arena */
+} cz_blk_desc;
+#define CZ_SCAN_CTL_WORDS 72   /* scan_ctl: [0..31] blocks per size class (class = bit length of nseq), [32..63] fill counters, [64] block work counter */
+
 typedef struct cz_batch_args {
     const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
     uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
@@ -54,6 +68,7 @@ typedef struct cz_batch_args {
        frame has no chain info and cz_decode_frames_kernel runs the chains itself */
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
     uint32_t* chain_counter; uint32_t chain_min_nseq;
+    cz_blk_desc* blk_desc; uint32_t blk_capacity; uint32_t* scan_ctl; uint32_t scan_pass;   /* block list of the pre-pass (cz_scan_kernel) */
     uint32_t* exec_counter;                   /* work counter of cz_exec_frames_kernel */
     /* optional literals pass (cz_decode_frames_kernel with literals_only = 1, launched next to cz_chain_kernel): the
        Huffman-coded literals of every frame the pre-pass takes are decoded into lit_arena — per block a node

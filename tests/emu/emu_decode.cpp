@@ -47,7 +47,9 @@ static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a); else cz_decode_frames_kernel(la->a);   /* 1 decode, 3 literals pass */
+    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a);
+    else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
+    else cz_decode_frames_kernel(la->a);                                /* 1 decode, 3 literals pass */
     emu_lane_done[la->lane] = 1;
     return nullptr;
 }
@@ -98,22 +100,30 @@ int main(int argc, char** argv) {
     /* passes: [chain pre-pass, [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int with_exec = arena && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
     if (with_exec) a.verify_checksum = 0;                               /* as the host library: cz_exec_frames_kernel does not hash */
-    for (int pass = arena ? 0 : 1; pass < 4; pass++) {
-        const int which = pass == 0 ? 0 : (pass == 1 ? 3 : (pass == 2 ? 2 : 1));   /* chain, literals, exec, decode */
+    std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0);
+    if (arena) {
+        blk_desc.resize(a.chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
+        a.blk_desc = blk_desc.data(); a.blk_capacity = (uint32_t)blk_desc.size(); a.scan_ctl = scan_ctl.data();
+    }
+    /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
+    const int order[6] = {4, 5, 0, 3, 2, 1};
+    for (int pi = arena ? 0 : 5; pi < 6; pi++) {
+        const int which = order[pi];
         if (which == 2 && !with_exec) continue;
         if (which == 3 && !lit_bytes) continue;
         const int nthreads = which == 2 ? CZX_THREADS : 64;
+        const int nblocks = which >= 4 ? (int)((n + 63) / 64) : (which == 3 ? 1 : grid);
         emu_nthreads = nthreads;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
-        for (int b = 0; b < grid; b++) {
+        uint32_t lit_counter = 0;
+        for (int b = 0; b < nblocks; b++) {
             std::vector<pthread_t> th((size_t)nthreads); std::vector<lane_arg> la((size_t)nthreads);
-            uint32_t lit_counter = 0;
             for (int l = 0; l < nthreads; l++) {
                 la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which;
-                if (which == 3) { la[l].a.literals_only = 1; la[l].a.work_counter = &lit_counter; if (b) continue; }
+                if (which == 3) { la[l].a.literals_only = 1; la[l].a.work_counter = &lit_counter; }
+                if (which >= 4) la[l].a.scan_pass = (uint32_t)(which - 4);
                 pthread_create(&th[l], nullptr, lane_main, &la[l]);
             }
-            if (which == 3 && b) continue;                              /* one workgroup does the whole literals pass */
             for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);
         }
         pthread_barrier_destroy(&emu_barrier);
