@@ -3,17 +3,31 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload full_4a|huf_literals|raw_rle|full_4b|mix]
 
-A "step" is one pass of the hot path (cz_decode_batch_device: one persistent-grid launch of
-cz_decode_frames_kernel) over one batch of synthetic frames that already sits in HBM.
-Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full
-compressed 128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
-Frames shard by rank with no data-path collective (weak scaling: 10 000 frames per GPU).
+A "step" is one pass of the hot path (one cz_decode_batch_device call) over one batch of synthetic
+frames that already sits in HBM.  With the pre-pass on (full_4a, full_4b, mix) the call launches
+    cz_scan_kernel x2  ->  cz_chain_kernel  ||  cz_decode_frames_kernel(literals pass, second stream)
+                       ->  cz_decode_frames_kernel
+and without it (raw_rle, huf_literals) the one persistent-grid cz_decode_frames_kernel.
+Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full compressed
+128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
+
+--gpus N > 1 started by hand re-launches itself as N ranks under torch.distributed.run (a child
+process, before anything touches the GPU) and fails loudly when the box has fewer GPUs; under the
+driver's own torchrun launch the ranks find RANK/WORLD_SIZE in the environment.  Frames shard by
+rank with no data-path collective (weak scaling: 10 000 frames per GPU); the mix is first dealt by
+algorithmic bytes (one untimed all_to_all of compressed bytes), and --gather times the RCCL gather
+of the decoded bytes to rank 0 as a separate leg.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
-  roofline      achieved = algorithmic bytes / mean kernel duration (hipEvents around the kernel
-                on the stream it runs on), against the 8 TB/s HBM peak
-  cpu_baseline  the CPU oracle (a port of the reference algorithm) timed on a bounded sample of
-                the same frames on this host's cores (rank 0, N=1 only)
+  roofline      achieved = algorithmic bytes / mean duration of the step's kernels (hipEvents inside
+                the library, on the streams the kernels run on), against the 8 TB/s HBM peak;
+                serial_chain_floor = what one FSE chain per block allows at the measured minimum
+                step latency; traffic = PMC bytes from profiles/r2 when that file was measured on
+                these very kernel sources (kernel_source_hash), else null
+  cpu_baseline  the CPU oracle (a port of the reference algorithm) on all host cores over the whole
+                batch, on one thread over a bounded sample, and libzstd on one thread (rank 0, N=1)
+  bit_exact     the last launch decodes into a 0xA5-poisoned buffer and EVERY frame is compared
+                with the oracle's output by XXH64
 """
 import argparse
 import json
@@ -174,10 +188,9 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
-    # the FSE-chain pre-pass pays for long chains in large blocks (configs 4a/4b); on short, irregular
-    # blocks (mix) and on blocks without sequences it is measured slower than in-kernel chains
-    chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b")
-    arena_bytes = int(batch.length.sum()) * 6 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
+    # the FSE-chain pre-pass (block-parallel: cz_scan_kernel + cz_chain_kernel) for every workload that has sequences
+    chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b", "mix")
+    arena_bytes = int(batch.length.sum()) * 8 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
     lit_bytes = regen_bytes + (16 << 20)                               # decoded literal bytes never exceed the decoded size
     if chain_prepass:
         ctx.set_chain_arena(arena_bytes)
@@ -295,8 +308,8 @@ def main():
             nf = 12500 if wl == "mix" else 10000
             # the chain pre-pass only pays for frames with long sequences sections
             ob = synth.generate(wl, nf, nthreads=max(1, min(32, ncpu)))
-            pre = wl in ("full_4a", "full_4b") and not args.no_chain_prepass
-            ctx.set_chain_arena(int(ob.length.sum()) * 6 + (64 << 20) if pre else 0)
+            pre = wl in ("full_4a", "full_4b", "mix") and not args.no_chain_prepass
+            ctx.set_chain_arena(int(ob.length.sum()) * 8 + (64 << 20) if pre else 0)
             ctx.set_literal_arena(int(ob.regen.sum()) + (16 << 20) if pre and not args.no_literals_pass else 0)
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)
@@ -354,7 +367,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         lit_pass = chain_prepass and not args.no_literals_pass and not args.exec_kernel
-        launches = (("cz_chain_kernel || cz_decode_frames_kernel(literals pass) + " if lit_pass else "cz_chain_kernel + ")
+        launches = (("cz_scan_kernel x2 + cz_chain_kernel || cz_decode_frames_kernel(literals pass) + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
                     + ("cz_exec_frames_kernel + " if args.exec_kernel else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
@@ -369,6 +382,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"
                                       + (", dealt by algorithmic bytes (one untimed all_to_all of compressed bytes)" if balanced else ""),
                        "launches_per_step": launches},
+            "kernel_source_hash": _kernel_source_hash(), "chain_prepass": bool(chain_prepass), "exec_kernel": bool(args.exec_kernel),
+            "literals_pass": bool(lit_pass),
             "bit_exact": bool(ok_all), "frames_verified_vs_oracle_rank0": verified,
             "verification": "last launch decoded into a 0xA5-poisoned buffer; every frame compared with the CPU oracle by XXH64" if not args.no_verify_all else "16-frame sample",
             "algorithmic_GBps_whole_job": alg_all * args.steps / elapsed / 1e9,
@@ -396,7 +411,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r2", f"pmc_hbm_traffic_{args.workload}.json")
         if os.path.exists(pmc) and world == 1 and F == 10000:
             t = json.load(open(pmc))
-            if t.get("kernel_source_hash") == _kernel_source_hash() and t.get("chain_prepass") == chain_prepass and bool(t.get("exec_kernel")) == bool(args.exec_kernel):
+            if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel):
                 line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
                 line["roofline"]["traffic_source"] = f"profiles/r2/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
             else:

@@ -74,8 +74,8 @@ struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; uint16_t 
 /* build_decoding_table (fse_decoder.cairo:156-256) into 16-bit chain entries + the state->code map
  * (global, bytes).  kind 0 LL, 1 OF, 2 ML.  Returns 1 if the table holds a code the sequence decoder
  * rejects (LL >= 36, OF >= 32, ML >= 53): such frames are left to the main kernel. */
-__device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log,
-                                                                uint16_t* counters, const uint32_t* llml, uint32_t kind, uint8_t* map) {
+__device__ static inline __attribute__((always_inline)) int czc_fse_build16(uint16_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log,
+                                                                uint16_t* counters, const uint32_t* llml, uint32_t kind, cz_gptr map) {
     const uint32_t size = 1u << log, lim = kind == 0 ? 36u : (kind == 1 ? 32u : 53u);
     uint32_t neg = size; int bad = 0;
     for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
@@ -84,13 +84,16 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
         if (probs[s] == -1) { neg--; table[neg] = (uint16_t)s; }
     }
     if (bad) return 1;
+    /* :190-226 as ONE flat loop over the `neg` cells of the positive counts: many lanes of a wave build different tables side by
+       side, and a loop nest whose inner trip count is the symbol's own count would make every lane wait for the largest count
+       of ANY lane at every symbol */
     uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
-    for (uint32_t s = 0; s < nprobs; s++) {                             /* :190-226 */
-        const int32_t p = probs[s];
-        for (int32_t j = 0; j < p; j++) {
-            table[pos] = (uint16_t)s;
-            do { pos = (pos + step) & mask; } while (pos >= neg);
-        }
+    uint32_t s = 0; int32_t left = 0;
+    for (uint32_t i = 0; i < neg; i++) {
+        while (left <= 0 && s < nprobs) { left = probs[s]; s++; }       /* s = symbol being spread + 1 (at most nprobs steps over the whole loop) */
+        table[pos] = (uint16_t)(s - 1);
+        left--;
+        do { pos = (pos + step) & mask; } while (pos >= neg);
     }
     for (uint32_t i = 0; i < size; i++) {                               /* :231-255, :377-400 */
         const uint32_t s = table[i];
@@ -101,7 +104,7 @@ __device__ static __attribute__((noinline)) int czc_fse_build16(uint16_t* table,
             const uint32_t n = (uint32_t)probs[s], k = counters[s];
             counters[s] = (uint16_t)(k + 1);
             const uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
-            const uint32_t dbl = slices - n, single = n - dbl, width = size / slices;
+            const uint32_t dbl = slices - n, single = n - dbl, width = size >> (cz_hbs(slices) - 1);   /* slices is a power of two: no integer division */
             nb = cz_hbs(width) - 1;
             if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
             else bl = (k - dbl) * width;
@@ -532,6 +535,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
     CzsWalk w;
     czs_begin(w, valid ? a.in_base + a.in_off[f] : nullptr, valid ? a.in_len[f] : 0, valid);
     CzsBlk b; b.blk_off = b.bsize = b.nseq = b.sbody = b.modes = 0;
+    /* the order in which the decode kernels take the frames: by size class of the compressed frame, largest first (one wave
+       per frame there: the longest frames must not start last) */
+    const uint32_t fcls = valid ? cz_hbs((uint32_t)(a.in_len[f] > 0xFFFFFFFFull ? 0xFFFFFFFFull : a.in_len[f])) : 0u;   /* 0..32 -> 0..31 */
+    const uint32_t ft = czs_ticket(a.scan_ctl + (a.scan_pass == 0 ? 72 : 104), valid, fcls > 31 ? 31u : fcls);
+    if (a.scan_pass == 1 && valid) {
+        uint32_t fb = 0; for (uint32_t cc = 31; cc > (fcls > 31 ? 31u : fcls); cc--) fb += a.scan_ctl[72 + cc];
+        a.frame_order[fb + ft] = f;
+    }
     if (a.scan_pass == 0) {
         uint64_t units = 0;
         while (__ballot(w.active)) {
@@ -585,7 +596,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
  * want = tables to read (bit t: LL, OF, ML).  For a table in Predefined / FSE mode the normalised counts go to
  * probs[t] and info gets (symbols - 1) | log << 6 at bits 10 t; for RLE mode rle[t] = the symbol; Repeat leaves all
  * as they are.  stage: LDS copy of the content from offset sbody (stage_n bytes), or nullptr.  Returns 0 / 1 (irregular). */
-__device__ static int czc_parse_tables(cz_gcptr blk, uint32_t bsize, uint32_t sbody, uint32_t modes, uint32_t want, const uint8_t* stage, uint32_t stage_n,
+__device__ static inline __attribute__((always_inline)) int czc_parse_tables(cz_gcptr blk, uint32_t bsize, uint32_t sbody, uint32_t modes, uint32_t want, const uint8_t* stage, uint32_t stage_n,
                                        int16_t (*probs)[CZC_MAXSYM], uint32_t* info, int32_t* rle, uint32_t* bitoff) {
     uint32_t off = sbody;
     for (int t = 0; t < 3; t++) {                                       /* LL, OF, ML */
@@ -612,7 +623,7 @@ __device__ static int czc_parse_tables(cz_gcptr blk, uint32_t bsize, uint32_t sb
             uint32_t np, lg, used;
             /* a description that is only stepped over is parsed into the counts of the (later) wanted table, which its own parse overwrites */
             const int into = take ? t : (want & 2u ? 1 : 2);
-            if (cz_fse_read_probs(br, max_log, probs[into], &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM || np == 0) return 1;
+            if (cz_fse_read_probs_inl(br, max_log, probs[into], &np, &lg, &used, 100, CZC_MAXSYM) || np > CZC_MAXSYM || np == 0) return 1;
             if (take) { *info = (*info & ~(0x3FFu << (10 * t))) | (((np - 1) | (lg << 6)) << (10 * t)); rle[t] = -1; }
             off += used;
             if (off > bsize) return 1;
@@ -639,7 +650,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
     ro.m1 = (ql == 1 || ql == 2) ? 0xFF00u : 0u; ro.m2 = ql == 2 ? 0xFF00u : 0u; ro.sh = ql == 3 ? 0u : 9u * ql; ro.lane0 = ql == 0;
     const uint16_t* my_table = ql == 0 ? sl.t_ll : (ql == 1 ? sl.t_ml : sl.t_of);
 #ifdef CZ_PROFILE
-    unsigned long long cprof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
+    unsigned long long cprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
 #endif
     uint32_t ndesc = 0; for (int c = 0; c < 20; c++) ndesc += a.scan_ctl[c];
     if (ndesc > a.blk_capacity) ndesc = a.blk_capacity;
@@ -678,6 +689,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 if (czc_q0((uint32_t)got) && has_slot) for (uint32_t cc = ql; cc < 16; cc += CZC_LPS) *(uint4*)&sl.stage[16 * cc] = czc_load16(bk + 16 * cc, Sk, Ek);
                 __syncthreads();
             }
+            CZC_PROF_ACC(8); CZC_PROF_CNT(13);
             /* tables (sequence_section_decoder.cairo:405-647), serial per owner lane; a Repeat mode reads the description of
                the block that defined the table (the tables in LDS belong to whatever block this slot had before) */
             uint32_t binfo = 0; int32_t rles[3] = {-1, -1, -1}; int bad = 0;
@@ -685,20 +697,41 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 o_mapflags = 0;
                 for (int t = 0; t < 3; t++) if (((modes >> (6 - 2 * t)) & 3) != 3) o_mapflags |= 1u << t;
                 bad = czc_parse_tables(blk, bsize, sbody, modes, 7u, sl.stage, 256u, sl.probs, &binfo, rles, &o_bitoff);
-                for (int t = 0; t < 3 && !bad; t++) if (((modes >> (6 - 2 * t)) & 3) == 3) {
-                    if (def[t] >= ndesc) { bad = 1; break; }
-                    const cz_blk_desc dd = a.blk_desc[def[t]];
-                    uint32_t dummy;
-                    bad = dd.frame != o_frame || czc_parse_tables((cz_gcptr)(a.in_base + a.in_off[dd.frame] + dd.blk_off), dd.bsize, dd.sbody, dd.modes, 1u << t, nullptr, 0,
-                                                                 sl.probs, &binfo, rles, &dummy);
+            }
+            CZC_PROF_ACC(9);
+            /* Repeat modes: the description is in the block that defined the table; its head is staged like the block's own
+               (three uniform rounds, one per table; byte loads from global memory would cost a round trip each) */
+            for (int t = 0; t < 3; t++) {
+                const int rep = got && !bad && ((modes >> (6 - 2 * t)) & 3) == 3;
+                if (!__ballot(rep)) continue;
+                cz_gcptr dblk = nullptr; uint32_t dbsize = 0, dsbody = 0, dmodes = 0;
+                if (rep) {
+                    if (def[t] >= ndesc) bad = 1;
+                    else {
+                        const cz_blk_desc dd = a.blk_desc[def[t]];
+                        if (dd.frame != o_frame) bad = 1;
+                        else { dblk = (cz_gcptr)(a.in_base + a.in_off[dd.frame] + dd.blk_off); dbsize = dd.bsize; dsbody = dd.sbody; dmodes = dd.modes; }
+                    }
                 }
+                const int go = rep && !bad;
+                {
+                    const uintptr_t base = (uintptr_t)dblk + dsbody;
+                    const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)dblk), Ek = Sk + czc_q0(dbsize);
+                    __syncthreads();
+                    if (czc_q0((uint32_t)go) && has_slot) for (uint32_t cc = ql; cc < 16; cc += CZC_LPS) *(uint4*)&sl.stage[16 * cc] = czc_load16(bk + 16 * cc, Sk, Ek);
+                    __syncthreads();
+                }
+                if (go) { uint32_t dummy; bad = czc_parse_tables(dblk, dbsize, dsbody, dmodes, 1u << t, sl.stage, 256u, sl.probs, &binfo, rles, &dummy); }
+            }
+            if (got) {
                 if (!bad) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
                     table[0] = CZC_E16(0u, 0u, t == 1 ? (uint32_t)rles[t] : (cs.llml[(t == 2 ? 40u : 0u) + (uint32_t)rles[t]] >> 24));
-                    if ((o_mapflags >> t) & 1u) ((uint8_t*)(a.chain_arena + o_hdr + 4))[t == 0 ? 0 : (t == 2 ? 512 : 1024)] = (uint8_t)rles[t];
+                    if ((o_mapflags >> t) & 1u) ((cz_gptr)(a.chain_arena + o_hdr + 4))[t == 0 ? 0 : (t == 2 ? 512 : 1024)] = (uint8_t)rles[t];
                 }
                 if (bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
             }
+            CZC_PROF_ACC(10);
             /* build the tables: the LL, ML and OF table of a slot on lanes 0, 1, 2 of its quad, side by side */
             {
                 __syncthreads();                                        /* descriptions read: `stage` may become counters */
@@ -708,8 +741,8 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 if (has_slot && ql < 3 && (info >> 6)) {
                     uint16_t* table = kind == 0 ? sl.t_ll : (kind == 1 ? sl.t_of : sl.t_ml);
                     uint16_t* counters = kind == 0 ? (uint16_t*)sl.stage : (kind == 1 ? (uint16_t*)sl.stage + CZC_MAXSYM : sl.counters_ml);
-                    uint8_t* maps = (uint8_t*)(a.chain_arena + hk + 4);
-                    uint8_t* map = !((mf >> kind) & 1u) ? nullptr : (kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024));   /* Repeat: the decode kernel keeps the earlier map */
+                    cz_gptr maps = (cz_gptr)(a.chain_arena + hk + 4);
+                    cz_gptr map = !((mf >> kind) & 1u) ? (cz_gptr)nullptr : (kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024));   /* Repeat: the decode kernel keeps the earlier map */
                     tbad = czc_fse_build16(table, sl.probs[kind], (info & 63u) + 1u, info >> 6, counters, cs.llml, kind, map);
                 }
                 __syncthreads();
@@ -717,7 +750,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 const int anybad = __shfl(tbad, q0) | __shfl(tbad, q0 + 1) | __shfl(tbad, q0 + 2);
                 if (got && anybad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
             }
-            CZC_PROF_ACC(0);
+            CZC_PROF_ACC(11);
             /* the bit ring of the new blocks: the top 256 bytes of the stream; from here on every lane of a quad holds its slot's values */
             const int qgot = (int)czc_q0((uint32_t)got) && has_slot;
             const uint32_t gn = czc_q0(o_nseq);
@@ -833,6 +866,6 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
         }
     }
 #ifdef CZ_PROFILE
-    if (LANE == 0 && a.prof) for (int i = 0; i < 8; i++) atomicAdd(&a.prof[32 + i], cprof[i]);
+    if (LANE == 0 && a.prof) { for (int i = 0; i < 8; i++) atomicAdd(&a.prof[32 + i], cprof[i]); for (int i = 8; i < 14; i++) atomicAdd(&a.prof[50 + i - 8], cprof[i]); }
 #endif
 }

@@ -651,8 +651,9 @@ extern "C" __global__ void __launch_bounds__(CZX_THREADS, 1) cz_exec_frames_kern
         __syncthreads();
         if (threadIdx.x == 0) CZX_CTL[CZX_C_FRAME] = atomicAdd(a.exec_counter, 1u);
         __syncthreads();
-        const uint32_t f = cz_uni(CZX_CTL[CZX_C_FRAME]);
-        if (f >= a.n) break;
+        const uint32_t fi = cz_uni(CZX_CTL[CZX_C_FRAME]);
+        if (fi >= a.n) break;
+        const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
         const uint64_t first = cz_uni64(a.frame_first[f]);
         if (first == 0 || first == CZX_DONE) continue;
 #ifdef CZ_EMU_DEBUG

@@ -47,7 +47,8 @@ struct cz_context {
     unsigned long long* chain_top = nullptr; uint32_t* chain_counter = nullptr;
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
     cz_blk_desc* blk_desc = nullptr; uint32_t blk_capacity = 0; uint32_t* scan_ctl = nullptr;   /* block list of the pre-pass */
-    int chain_grid = 0; uint32_t chain_min_nseq = 2048;
+    uint32_t* frame_order = nullptr;                                    /* n entries, allocated with frame_first */
+    int chain_grid = 0; uint32_t chain_min_nseq = 0;
     /* optional literals pass next to the pre-pass, on a stream of its own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
     uint64_t* lit_first = nullptr; size_t lit_first_cap = 0; uint32_t* lit_counter = nullptr;
@@ -101,7 +102,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
     (void)hipMemset(c->d_prof, 0, sizeof tmp);
     int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
     for (int i = 0; i < n; i++) out[i] = tmp[i];
-    for (int i = 32; i < 50 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
+    for (int i = 32; i < 58 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
     return n;
 }
 
@@ -125,6 +126,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->blk_desc) (void)hipFree(c->blk_desc);
     if (c->scan_ctl) (void)hipFree(c->scan_ctl);
+    if (c->frame_order) (void)hipFree(c->frame_order);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
@@ -228,7 +230,8 @@ CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return
 
 CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
 
-/* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 2048). */
+/* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 0: every frame that has
+ * sequences is; with the block-parallel pre-pass that measured fastest on the corpus-like mix too). */
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
 
 /* Diagnostics of the last batch launch (synchronises): how many of its n frames got chain records from the pre-pass,
@@ -298,6 +301,9 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         if (c->frame_first_cap < n) {
             if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
             CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8)); c->frame_first_cap = n;
+            if (c->frame_order) (void)hipFree(c->frame_order);
+            c->frame_order = nullptr;
+            CZ_HIP(c, hipMalloc((void**)&c->frame_order, n * 4));
         }
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
@@ -313,7 +319,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
         }
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
-        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl;
+        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order;
         CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
         a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);

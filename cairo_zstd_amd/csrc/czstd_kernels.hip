@@ -289,7 +289,9 @@ __device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_
 }
 
 /* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
-__device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
+/* (the body is force-inlined where the callers' pointers are known to be LDS: a generic pointer that crosses a function call makes
+   every access a flat_* instruction, which waits for global memory too — cz_chain_kernel's table set-up calls the _inl form) */
+__device__ static inline __attribute__((always_inline)) int cz_fse_read_probs_inl(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
                                         uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above, uint32_t cap = 256) {
     uint32_t v;
     if (cz_fb_get(br, 4, &v)) return CZ_E_FSE_GETBITS;                  /* :265-268 */
@@ -319,6 +321,10 @@ __device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, u
     *nprobs = n; *acc_log = log; *bytes_read = (br.idx + 7) >> 3;       /* :361-365 */
     return 0;
 }
+__device__ static __attribute__((noinline)) int cz_fse_read_probs(CzFBits& br, uint32_t max_log, int16_t* probs, uint32_t* nprobs,
+                                        uint32_t* acc_log, uint32_t* bytes_read, int unsupported_above, uint32_t cap = 256) {
+    return cz_fse_read_probs_inl(br, max_log, probs, nprobs, acc_log, bytes_read, unsupported_above, cap);
+}
 /* build_decoding_table (fse_decoder.cairo:156-256).  One lane per table; lanes 0..2 run it
  * side by side on different tables. */
 __device__ static __attribute__((noinline)) void cz_fse_build(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint16_t* counters,
@@ -341,7 +347,7 @@ __device__ static __attribute__((noinline)) void cz_fse_build(uint32_t* table, c
         uint32_t s = table[i] >> 24, n = (uint32_t)probs[s], k = counters[s];
         counters[s] = (uint16_t)(k + 1);
         uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
-        uint32_t dbl = slices - n, single = n - dbl, width = size / slices, nb = cz_hbs(width) - 1, bl;
+        uint32_t dbl = slices - n, single = n - dbl, width = size >> (cz_hbs(slices) - 1), nb = cz_hbs(width) - 1, bl;   /* slices is a power of two */
         if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
         else bl = (k - dbl) * width;
         table[i] = CZ_FSE_PACK(s, nb, bl) | cz_fse_code_bits(llml, kind, s);
@@ -1736,8 +1742,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         __syncthreads();
         if (LANE == 0) sh.frame_idx = atomicAdd(a.work_counter, 1u);
         __syncthreads();
-        const uint32_t f = cz_uni(sh.frame_idx);
-        if (f >= a.n) break;
+        const uint32_t fi = cz_uni(sh.frame_idx);
+        if (fi >= a.n) break;
+        const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;   /* the pre-pass sorted the frames: longest first */
         if (a.literals_only) {
             cz_state_reset();
             __syncthreads();

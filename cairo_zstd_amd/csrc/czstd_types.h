@@ -51,7 +51,8 @@ typedef struct cz_blk_desc {
     uint32_t pad;
     uint64_t hdr;             /* index of the block's header in the chain arena */
 } cz_blk_desc;
-#define CZ_SCAN_CTL_WORDS 72   /* scan_ctl: [0..31] blocks per size class (class = bit length of nseq), [32..63] fill counters, [64] block work counter */
+#define CZ_SCAN_CTL_WORDS 136  /* scan_ctl: [0..31] blocks per size class (class = bit length of nseq), [32..63] fill counters, [64] block work counter,
+                                  [72..103] frames per size class (bit length of the compressed size), [104..135] fill counters */
 
 typedef struct cz_batch_args {
     const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
@@ -69,6 +70,7 @@ typedef struct cz_batch_args {
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
     uint32_t* chain_counter; uint32_t chain_min_nseq;
     cz_blk_desc* blk_desc; uint32_t blk_capacity; uint32_t* scan_ctl; uint32_t scan_pass;   /* block list of the pre-pass (cz_scan_kernel) */
+    uint32_t* frame_order;                    /* NULL, or the order in which the decode kernels take the frames: largest compressed size first (cz_scan_kernel) */
     uint32_t* exec_counter;                   /* work counter of cz_exec_frames_kernel */
     /* optional literals pass (cz_decode_frames_kernel with literals_only = 1, launched next to cz_chain_kernel): the
        Huffman-coded literals of every frame the pre-pass takes are decoded into lit_arena — per block a node

@@ -106,8 +106,8 @@ int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
  * `bytes` (decoded literal bytes + 16 per block; at most the decoded size of the batch).  The decode kernels then read
  * the literals from the arena; frames that did not fit, or that are irregular in any way, decode theirs as before. */
 int cz_context_set_literal_arena(cz_context* ctx, size_t bytes);
-/* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 2048:
- * the pre-pass only pays for long chains). */
+/* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 0: every frame
+ * with sequences takes it — the pre-pass works block by block, so short chains cost little). */
 int cz_context_set_chain_min_sequences(cz_context* ctx, uint32_t n);
 
 /* Batch decodes also compute the XXH64 content checksum of every frame that carries one, on the

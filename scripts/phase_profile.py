@@ -52,6 +52,9 @@ def main():
         print(f"  top-up events {cv[5]}  ({cv[2] / max(cv[5], 1):.0f} ticks each), groups {cv[6]} ({cv[3] / max(cv[6], 1):.1f} ticks each; 1 tick = 10 ns)")
 
 
+    rv = [buf[50 + i] for i in range(6)]
+    if sum(rv[:4]):
+        print(f"  refill events {rv[5]}: pull+stage {rv[0] / max(rv[5], 1):.0f}, own tables {rv[1] / max(rv[5], 1):.0f}, repeat rounds {rv[2] / max(rv[5], 1):.0f}, build {rv[3] / max(rv[5], 1):.0f} ticks each")
     xv = [buf[40 + i] for i in range(9)]
     if sum(xv):
         xt = sum(xv)

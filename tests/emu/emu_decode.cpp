@@ -100,10 +100,11 @@ int main(int argc, char** argv) {
     /* passes: [chain pre-pass, [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int with_exec = arena && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
     if (with_exec) a.verify_checksum = 0;                               /* as the host library: cz_exec_frames_kernel does not hash */
-    std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0);
+    std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order;
     if (arena) {
         blk_desc.resize(a.chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
         a.blk_desc = blk_desc.data(); a.blk_capacity = (uint32_t)blk_desc.size(); a.scan_ctl = scan_ctl.data();
+        frame_order.resize(n ? n : 1); a.frame_order = frame_order.data();
     }
     /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int order[6] = {4, 5, 0, 3, 2, 1};

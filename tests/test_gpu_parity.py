@@ -566,7 +566,8 @@ def test_more_frames_than_resident_workgroups_with_prepass(cz):
     n = 9000
     b = synth.generate("mix", n, first_index=100000)
     c = cz.Context(0)
-    c.set_chain_arena(int(b.length.sum()) * 8 + (16 << 20))
+    c.set_chain_arena(int(b.length.sum()) * 8 + (16 << 20), min_sequences=2048)   # a gate: only frames whose first sequences section is long
+    c.set_literal_arena(int(b.regen.sum()) + (16 << 20))
     try:
         out_off, out_cap, total = b.out_layout()
         out, res = c.decode_batch_host(b.base, b.off, b.length, out_off, out_cap, total)
