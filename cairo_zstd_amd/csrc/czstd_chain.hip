@@ -72,45 +72,89 @@ struct CzChainSlot {
 struct CzChainShared { CzChainSlot slot[CZC_SLOTS]; uint32_t llml[96]; uint16_t idle[2]; };
 
 /* build_decoding_table (fse_decoder.cairo:156-256) into 16-bit chain entries + the state->code map
- * (global, bytes).  kind 0 LL, 1 OF, 2 ML.  Returns 1 if the table holds a code the sequence decoder
- * rejects (LL >= 36, OF >= 32, ML >= 53): such frames are left to the main kernel. */
-__device__ static inline __attribute__((always_inline)) int czc_fse_build16(uint16_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log,
-                                                                uint16_t* counters, const uint32_t* llml, uint32_t kind, cz_gptr map) {
-    const uint32_t size = 1u << log, lim = kind == 0 ? 36u : (kind == 1 ? 32u : 53u);
-    uint32_t neg = size; int bad = 0;
-    for (uint32_t s = 0; s < nprobs; s++) {                             /* :169-188 */
-        counters[s] = 0;
-        if (probs[s] != 0 && s >= lim) bad = 1;
-        if (probs[s] == -1) { neg--; table[neg] = (uint16_t)s; }
+ * (global, bytes), by the whole wave: all 64 lanes call this together, and the tables of the refilled
+ * slots are built one after the other.  kind 0 LL, 1 OF, 2 ML.  Returns 1 (uniform) if the table holds a
+ * code the sequence decoder rejects (LL >= 36, OF >= 32, ML >= 53): such frames are left to the main kernel.
+ * (One lane per table, three tables side by side, was measured at ~600 clocks per cell: every step of those
+ * loops is a dependent LDS round trip on a lone wave.)
+ *   A  lane = symbol: "less than one" symbols go to the top cells (:169-188), an exclusive scan of the positive counts gives
+ *      every symbol the rank of its first cell in spreading order;
+ *   B  symof[rank] = symbol by a prefix maximum over the marks symof[first rank of s] = s, then lane = step j of the
+ *      spreading walk: cell (j * step) & mask, skipped when it is a top cell, takes the symbol of its rank among the
+ *      cells not skipped (:190-226; the walk visits every cell exactly once because step is odd);
+ *   C  lane = cell, 64 cells at a time in ascending order: k = how many lower cells hold the same symbol (lanes of equal
+ *      symbol are matched with six ballots, earlier chunks are in counters[]), then the entry as above (:231-255).
+ * symof: size bytes of scratch, counters: 64 halfwords. */
+__device__ static inline __attribute__((always_inline)) int czc_fse_build_wave(uint16_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log,
+                                                                   uint8_t* symof, uint16_t* counters, const uint32_t* llml, uint32_t kind, cz_gptr map) {
+    const uint32_t size = 1u << log, mask = size - 1, lim = kind == 0 ? 36u : (kind == 1 ? 32u : 53u);
+    const uint32_t lane = (uint32_t)LANE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    /* A */
+    const int32_t p = lane < nprobs ? (int32_t)probs[lane] : 0;
+    if (__ballot(p != 0 && lane >= lim)) return 1;
+    const unsigned long long lowm = __ballot(p == -1);
+    const uint32_t neg = size - (uint32_t)__popcll(lowm);
+    if (p == -1) table[size - 1u - (uint32_t)__popcll(lowm & lt)] = (uint16_t)lane;
+    counters[lane] = 0;
+    const uint32_t cnt = p > 0 ? (uint32_t)p : 0u;
+    const uint32_t cum = cz_wave_incl_scan(cnt) - cnt;
+    for (uint32_t i = 4u * lane; i < size; i += 256u) *(uint32_t*)(symof + i) = 0u;
+    cz_wave_sync();
+    if (cnt && cum < size) symof[cum] = (uint8_t)lane;
+    cz_wave_sync();
+    /* B: prefix maximum, `per` consecutive bytes per lane */
+    {
+        const uint32_t per = size >= 64u ? size >> 6 : 1u, b0 = lane * per;
+        const int act = b0 < size;
+        uint32_t run = 0, vals[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) { if (act && j < per) { const uint32_t v = symof[b0 + j]; run = v > run ? v : run; } vals[j] = run; }
+        uint32_t inc = act ? run : 0u;
+#define CZC_MAX_STEP(CTRL, RM) do { const uint32_t o_ = cz_dpp<CTRL, RM>(0u, inc); inc = o_ > inc ? o_ : inc; } while (0)
+        CZC_MAX_STEP(CZ_DPP_SHR1, 0xF); CZC_MAX_STEP(CZ_DPP_SHR2, 0xF); CZC_MAX_STEP(CZ_DPP_SHR4, 0xF); CZC_MAX_STEP(CZ_DPP_SHR8, 0xF);
+        CZC_MAX_STEP(CZ_DPP_BCAST15, 0xA); CZC_MAX_STEP(CZ_DPP_BCAST31, 0xC);
+#undef CZC_MAX_STEP
+        const uint32_t exc = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0u, inc);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) if (act && j < per) symof[b0 + j] = (uint8_t)(vals[j] > exc ? vals[j] : exc);
     }
-    if (bad) return 1;
-    /* :190-226 as ONE flat loop over the `neg` cells of the positive counts: many lanes of a wave build different tables side by
-       side, and a loop nest whose inner trip count is the symbol's own count would make every lane wait for the largest count
-       of ANY lane at every symbol */
-    uint32_t pos = 0; const uint32_t step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
-    uint32_t s = 0; int32_t left = 0;
-    for (uint32_t i = 0; i < neg; i++) {
-        while (left <= 0 && s < nprobs) { left = probs[s]; s++; }       /* s = symbol being spread + 1 (at most nprobs steps over the whole loop) */
-        table[pos] = (uint16_t)(s - 1);
-        left--;
-        do { pos = (pos + step) & mask; } while (pos >= neg);
+    cz_wave_sync();
+    {
+        const uint32_t step = (size >> 1) + (size >> 3) + 3u;
+        uint32_t running = 0;
+        for (uint32_t j0 = 0; j0 < size; j0 += 64u) {
+            const uint32_t j = j0 + lane, pos = (j * step) & mask;
+            const int valid = j < size && pos < neg;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) table[pos] = symof[running + (uint32_t)__popcll(vm & lt)];
+            running += (uint32_t)__popcll(vm);
+        }
     }
-    for (uint32_t i = 0; i < size; i++) {                               /* :231-255, :377-400 */
-        const uint32_t s = table[i];
+    cz_wave_sync();
+    /* C */
+    for (uint32_t i0 = 0; i0 < size; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const int in = i < size, cell = in && i < neg;
+        const uint32_t s = in ? (uint32_t)table[i] : 0u;
+        unsigned long long same = __ballot(cell);
+#pragma unroll
+        for (uint32_t b = 0; b < 6; b++) { const int bit = (int)((s >> b) & 1u); const unsigned long long m = __ballot(bit); same &= bit ? m : ~m; }
+        const uint32_t n = cell ? (uint32_t)probs[s] : 1u;
+        const uint32_t k = (cell ? (uint32_t)counters[s] : 0u) + (uint32_t)__popcll(same & lt);
+        cz_wave_sync();                                                 /* every lane has read counters[] */
+        if (cell && (same >> lane) == 1ull) counters[s] = (uint16_t)(k + 1u);   /* the highest lane of the group */
         const uint32_t xb = kind == 1 ? s : (llml[(kind == 2 ? 40u : 0u) + s] >> 24);
-        uint32_t nb, bl;
-        if (i >= neg) { nb = log; bl = 0; }
-        else {
-            const uint32_t n = (uint32_t)probs[s], k = counters[s];
-            counters[s] = (uint16_t)(k + 1);
+        uint32_t nb = log, bl = 0;
+        if (cell) {
             const uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
-            const uint32_t dbl = slices - n, single = n - dbl, width = size >> (cz_hbs(slices) - 1);   /* slices is a power of two: no integer division */
+            const uint32_t dbl = slices - n, single = n - dbl, width = size >> (cz_hbs(slices) - 1);
             nb = cz_hbs(width) - 1;
             if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
             else bl = (k - dbl) * width;
         }
-        table[i] = CZC_E16(nb, bl, xb);
-        if (map) map[i] = (uint8_t)s;
+        if (in) { table[i] = CZC_E16(nb, bl, xb); if (map) map[i] = (uint8_t)s; }
+        cz_wave_sync();
     }
     return 0;
 }
@@ -644,7 +688,6 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
     const int has_slot = qk < CZC_SLOTS;
     const int owner = has_slot && ql == 0;                              /* does the serial parsing of its slot's block */
     CzChainSlot& sl = cs.slot[has_slot ? qk : 0];
-    const uint32_t kind = ql == 0 ? 0u : (ql == 1 ? 2u : 1u);           /* table of this lane in LL, OF, ML numbering */
     CzcRole ro;
     ro.ringm8 = sl.ring - 8; ro.tb = cs.idle; ro.sbits = 0;
     ro.m1 = (ql == 1 || ql == 2) ? 0xFF00u : 0u; ro.m2 = ql == 2 ? 0xFF00u : 0u; ro.sh = ql == 3 ? 0u : 9u * ql; ro.lane0 = ql == 0;
@@ -723,32 +766,41 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
                 if (go) { uint32_t dummy; bad = czc_parse_tables(dblk, dbsize, dsbody, dmodes, 1u << t, sl.stage, 256u, sl.probs, &binfo, rles, &dummy); }
             }
-            if (got) {
-                if (!bad) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
+            if (got && bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
+            CZC_PROF_ACC(10);
+            /* build the tables of the refilled slots, each by the whole wave, slot after slot: LL and ML first (the slot's OF
+               table, always rewritten for a new block, is their scratch), then OF (scratch: the description bytes, now read) */
+            {
+                __syncthreads();                                        /* descriptions read */
+                int tbad = 0;
+                for (unsigned long long need = __ballot(owner && got); need; need &= need - 1) {
+                    const int ol = cz_unii(__ffsll((long long)need) - 1);
+                    const uint32_t binf = cz_readlane(binfo, ol), mf = cz_readlane(o_mapflags, ol);
+                    const uint64_t hk = ((uint64_t)cz_readlane((uint32_t)(o_hdr >> 32), ol) << 32) | cz_readlane((uint32_t)o_hdr, ol);
+                    CzChainSlot& bs = cs.slot[(uint32_t)ol >> 2];
+                    cz_gptr maps = (cz_gptr)(a.chain_arena + hk + 4);
+                    int sbad = 0;
+#pragma unroll 1
+                    for (uint32_t o = 0; o < 3; o++) {
+                        const uint32_t bk = o == 0 ? 0u : (o == 1 ? 2u : 1u);   /* LL, ML, OF */
+                        const uint32_t info = (binf >> (10 * bk)) & 0x3FFu;
+                        if (!(info >> 6)) continue;
+                        uint16_t* table = bk == 0 ? bs.t_ll : (bk == 1 ? bs.t_of : bs.t_ml);
+                        uint8_t* symof = bk == 1 ? bs.stage : (uint8_t*)bs.t_of;
+                        cz_gptr map = !((mf >> bk) & 1u) ? (cz_gptr)nullptr : (bk == 0 ? maps : (bk == 2 ? maps + 512 : maps + 1024));   /* Repeat: the decode kernel keeps the earlier map */
+                        sbad |= czc_fse_build_wave(table, bs.probs[bk], (info & 63u) + 1u, info >> 6, symof, bs.counters_ml, cs.llml, bk, map);
+                        cz_wave_sync();
+                    }
+                    if (sbad && LANE == ol) tbad = 1;
+                }
+                __syncthreads();
+                if (got && tbad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
+                if (got) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
                     table[0] = CZC_E16(0u, 0u, t == 1 ? (uint32_t)rles[t] : (cs.llml[(t == 2 ? 40u : 0u) + (uint32_t)rles[t]] >> 24));
                     if ((o_mapflags >> t) & 1u) ((cz_gptr)(a.chain_arena + o_hdr + 4))[t == 0 ? 0 : (t == 2 ? 512 : 1024)] = (uint8_t)rles[t];
                 }
-                if (bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
-            }
-            CZC_PROF_ACC(10);
-            /* build the tables: the LL, ML and OF table of a slot on lanes 0, 1, 2 of its quad, side by side */
-            {
-                __syncthreads();                                        /* descriptions read: `stage` may become counters */
-                const uint32_t info = (czc_q0(got ? binfo : 0u) >> (10 * kind)) & 0x3FFu;
-                const uint64_t hk = czc_q0_64(o_hdr); const uint32_t mf = czc_q0(o_mapflags);
-                int tbad = 0;
-                if (has_slot && ql < 3 && (info >> 6)) {
-                    uint16_t* table = kind == 0 ? sl.t_ll : (kind == 1 ? sl.t_of : sl.t_ml);
-                    uint16_t* counters = kind == 0 ? (uint16_t*)sl.stage : (kind == 1 ? (uint16_t*)sl.stage + CZC_MAXSYM : sl.counters_ml);
-                    cz_gptr maps = (cz_gptr)(a.chain_arena + hk + 4);
-                    cz_gptr map = !((mf >> kind) & 1u) ? (cz_gptr)nullptr : (kind == 0 ? maps : (kind == 2 ? maps + 512 : maps + 1024));   /* Repeat: the decode kernel keeps the earlier map */
-                    tbad = czc_fse_build16(table, sl.probs[kind], (info & 63u) + 1u, info >> 6, counters, cs.llml, kind, map);
-                }
                 __syncthreads();
-                const int q0 = LANE & ~3;
-                const int anybad = __shfl(tbad, q0) | __shfl(tbad, q0 + 1) | __shfl(tbad, q0 + 2);
-                if (got && anybad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
             }
             CZC_PROF_ACC(11);
             /* the bit ring of the new blocks: the top 256 bytes of the stream; from here on every lane of a quad holds its slot's values */

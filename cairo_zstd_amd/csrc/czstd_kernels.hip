@@ -54,13 +54,16 @@ __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_un
 #define CZ_PROF_DECL unsigned long long cz_t_ = 0
 #define CZ_PROF_T0() do { if (LANE == 0) cz_t_ = __builtin_amdgcn_s_memtime(); } while (0)
 #define CZ_PROF_ACC(idx) do { if (LANE == 0) { unsigned long long n_ = __builtin_amdgcn_s_memtime(); sh.prof[idx] += n_ - cz_t_; cz_t_ = n_; } } while (0)
+#define CZ_PROF_CNT(idx) do { if (LANE == 0) sh.prof[idx] += 1; } while (0)
 #else
+#define CZ_PROF_CNT(idx) do { } while (0)
 #define CZ_PROF_DECL
 #define CZ_PROF_T0() do { } while (0)
 #define CZ_PROF_ACC(idx) do { } while (0)
 #endif
 enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER,
-       CZ_P_HUF_SPEC, CZ_P_HUF_SYNC, CZ_P_HUF_WRITE, CZ_P_COUNT };   /* the last three are sub-phases of CZ_P_HUFDEC (counted in both) */
+       CZ_P_HUF_SPEC, CZ_P_HUF_SYNC, CZ_P_HUF_WRITE,                  /* sub-phases of CZ_P_HUFDEC (counted in both) */
+       CZ_P_N_FAST, CZ_P_N_GENERAL, CZ_P_N_ROUNDS, CZ_P_N_BIG, CZ_P_COUNT };   /* counts: chunks on the LDS path / the general path, dependency rounds and wave-wide copies of the general path */
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
@@ -857,6 +860,52 @@ struct CzExecCtx {
     uint32_t lit_used;
 };
 
+/* ---- copies of the general path: every global load of a lane is issued before its first store, so a run costs one
+ * memory round trip instead of one per byte (a byte loop whose store may alias the next load cannot be pipelined). */
+/* the low m (<= 16) bytes of v to d, any alignment, in at most four stores */
+__device__ static inline void cz_store_upto16(cz_gptr d, uint4 v, uint32_t m) {
+    if (m >= 16) { __builtin_memcpy(d, &v, 16); return; }
+    if (m & 8u) { const uint64_t t = ((uint64_t)v.y << 32) | v.x; __builtin_memcpy(d, &t, 8); d += 8; v.x = v.z; v.y = v.w; }
+    if (m & 4u) { __builtin_memcpy(d, &v.x, 4); d += 4; v.x = v.y; }
+    if (m & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(d, &h, 2); d += 2; v.x >>= 16; }
+    if (m & 1u) *d = (uint8_t)v.x;
+}
+/* 16 bytes at s when the whole load lies inside the buffer (`whole`), else the first m bytes one by one */
+__device__ static inline uint4 cz_load_upto16(cz_gcptr s, uint32_t m, int whole) {
+    uint4 v;
+    if (whole) { __builtin_memcpy(&v, s, 16); return v; }
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t b = 0; b < 16; b++) if (b < m) w[b >> 2] |= (uint32_t)s[b] << (8 * (b & 3));
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+}
+/* n <= 32 bytes, one lane; wholeA / wholeB: the 16-byte loads at s / s + 16 stay inside the buffer and read nothing this
+   copy writes */
+__device__ static inline void cz_lane_copy32(cz_gptr d, cz_gcptr s, uint32_t n, int wholeA, int wholeB) {
+    const uint32_t nb = n > 16 ? n - 16 : 0;
+    const uint4 a = cz_load_upto16(s, n, wholeA);
+    uint4 b = uint4{0, 0, 0, 0};
+    if (nb) b = cz_load_upto16(s + 16, nb, wholeB);
+    cz_store_upto16(d, a, n);
+    if (nb) cz_store_upto16(d + 16, b, nb);
+}
+/* Up to four runs of at most CZ_QCOPY_MAX bytes at once, sixteen lanes x 16 bytes per step each: run g (source s, n bytes;
+   n == 0: none) belongs to lanes 16g..16g+15.  src_lim: no 16-byte load may reach beyond it (the tail is then read byte
+   by byte).  Source and destination of a run do not overlap. */
+#define CZ_QCOPY_MAX 1024u
+__device__ static inline void cz_quarter_copy(cz_gptr d, cz_gcptr s, uint32_t n, cz_gcptr src_lim) {
+    const uint32_t l16 = (uint32_t)LANE & 15u;
+#pragma unroll 1
+    for (uint32_t pos = 16u * l16; __ballot(pos < n); pos += 256u) {
+        if (pos < n) {
+            const uint32_t m = n - pos < 16u ? n - pos : 16u;
+            const uint4 v = cz_load_upto16(s + pos, m, s + pos + 16 <= src_lim);
+            cz_store_upto16(d + pos, v, m);
+        }
+    }
+}
+
 /* Execution of up to 64 decoded sequences, one per lane (ll, ml, off = resolved offset), in two
  * stages so that the record-driven path can plan one chunk ahead of the data movement:
  *   cz_chunk_plan  output/literal positions by wave scans + every check of
@@ -932,6 +981,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
      * round trip per phase instead of one per byte); matches that read the chunk's own output are
      * resolved by dependency rounds inside LDS. */
     if (sum_tot <= CZ_OBUF_BYTES && !__ballot(ll > CZ_OBUF_MAXLEN || ml > CZ_OBUF_MAXLEN)) {
+        CZ_PROF_CNT(CZ_P_N_FAST);
         uint8_t* ob = sh.a.t4.obuf;
         const uint32_t orel = incl_tot - tot, drel = orel + ll;
         uint8_t* const cout = x.out + x.produced;                       /* chunk output base */
@@ -942,7 +992,11 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         const int near = ml > 0 && !far;
         const int far_plain = far && off >= ml, far_period = far && off < ml;
         const uint8_t* ls = lit.p + lit_start;
+#ifdef CZ_EXP_NEARSRC   /* diagnostic only (wrong output): far match sources read next to the chunk instead of anywhere in the window */
+        const uint8_t* ms = x.produced >= 4096 ? cout - 8 - ((drel * 7u + off) & 1023u) : cout + (drel - (uint64_t)off);
+#else
         const uint8_t* ms = cout + (drel - (uint64_t)off);
+#endif
         /* first group of every lane: all loads, then all LDS writes; sized by the longest run of the chunk */
         const int lit_wide = !__ballot(ll > 0 && !lit.rle && (uint64_t)lit_start + 8 > lit.len);   /* 8-byte literal loads stay inside the buffer */
         const unsigned long long big = __ballot(ll > 4 || ml > 8), mid = __ballot(ll > 2 || ml > 4);
@@ -996,19 +1050,30 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         return 0;
     }
 
-    /* literals: short runs per lane, long runs cooperatively */
-    const int long_lit = ll > 32;
-    if (active && ll > 0 && !long_lit) {
-        uint8_t* d = x.out + out_start;
-        if (lit.rle) for (uint32_t k = 0; k < ll; k++) d[k] = lit.byte;
-        else { const uint8_t* s = lit.p + lit_start; for (uint32_t k = 0; k < ll; k++) d[k] = s[k]; }
-    }
-    unsigned long long lm = __ballot(long_lit);
-    while (lm) {
-        const int j = __ffsll((long long)lm) - 1; lm &= lm - 1;
-        const uint32_t n = cz_uni(__shfl(ll, j)), ls = cz_uni(__shfl(lit_start, j));
-        const uint64_t os = ((uint64_t)cz_uni(__shfl((uint32_t)(out_start >> 32), j)) << 32) | cz_uni(__shfl((uint32_t)out_start, j));
-        cz_lit_coop_copy(x.out + os, lit, ls, n);
+    /* literals: runs of up to 32 bytes per lane, up to CZ_QCOPY_MAX four at a time by quarter waves, longer ones by the wave */
+    CZ_PROF_CNT(CZ_P_N_GENERAL);
+    {
+        cz_gptr od = (cz_gptr)x.out + out_start; cz_gcptr lsrc = (cz_gcptr)lit.p + lit_start; cz_gcptr llim = (cz_gcptr)lit.p + lit.len;
+        if (lit.rle) {
+            if (active && ll > 0 && ll <= 32) { const uint32_t w = 0x01010101u * lit.byte; const uint4 v = uint4{w, w, w, w}; cz_store_upto16(od, v, ll); if (ll > 16) cz_store_upto16(od + 16, v, ll - 16); }
+        } else if (active && ll > 0 && ll <= 32) cz_lane_copy32(od, lsrc, ll, lsrc + 16 <= llim, lsrc + 32 <= llim);
+        unsigned long long qm = __ballot(ll > 32 && ll <= CZ_QCOPY_MAX && !lit.rle);
+        while (qm) {
+            int j = -1;                                                 /* the run of my quarter */
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const int f = qm ? __ffsll((long long)qm) - 1 : -1; if (f >= 0) qm &= qm - 1; if ((LANE >> 4) == g) j = f; }
+            const int jj = j < 0 ? 0 : j;
+            const uint32_t nj = __shfl(ll, jj), ls = __shfl(lit_start, jj), n = j < 0 ? 0u : nj;   /* every lane takes part in the shuffles */
+            const uint64_t os = ((uint64_t)__shfl((uint32_t)(out_start >> 32), jj) << 32) | __shfl((uint32_t)out_start, jj);
+            cz_quarter_copy((cz_gptr)x.out + os, (cz_gcptr)lit.p + ls, n, llim);
+        }
+        unsigned long long lm = __ballot(ll > CZ_QCOPY_MAX || (ll > 32 && lit.rle));
+        while (lm) {
+            const int j = __ffsll((long long)lm) - 1; lm &= lm - 1;
+            const uint32_t n = cz_uni(__shfl(ll, j)), ls = cz_uni(__shfl(lit_start, j));
+            const uint64_t os = ((uint64_t)cz_uni(__shfl((uint32_t)(out_start >> 32), j)) << 32) | cz_uni(__shfl((uint32_t)out_start, j));
+            cz_lit_coop_copy(x.out + os, lit, ls, n);
+        }
     }
     __syncthreads();
     CZ_PROF_ACC(CZ_P_LITCOPY);
@@ -1025,26 +1090,44 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         const int f = __ffsll((long long)pend) - 1;
         const uint64_t W = ((uint64_t)__shfl((uint32_t)(dst >> 32), f) << 32) | __shfl((uint32_t)dst, f);
         const int ready = !done && src_end <= W;
+        CZ_PROF_CNT(CZ_P_N_ROUNDS);
         if (ready && ml <= 32) {
-            uint8_t* d = x.out + dst; const uint8_t* s = x.out + src;
-            for (uint32_t k = 0; k < ml; k++) d[k] = s[k];              /* forward byte copy == decode_buffer.cairo:101-120 */
+            cz_gptr d = (cz_gptr)x.out + dst; cz_gcptr sp = (cz_gcptr)x.out + src;
+            /* both 16-byte loads precede the stores: they must not read what this copy writes, and stay below dst (<= cap) */
+            if (off >= 32 || (off >= 16 && ml <= 16)) cz_lane_copy32(d, sp, ml, 1, 1);
+            else for (uint32_t k = 0; k < ml; k++) d[k] = sp[k];       /* forward byte copy == decode_buffer.cairo:101-120 */
         }
-        unsigned long long big = __ballot(ready && ml > 32);
+        unsigned long long qm = __ballot(ready && ml > 32 && ml <= CZ_QCOPY_MAX && off >= ml);
+        while (qm) {
+            int j = -1;
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const int ff = qm ? __ffsll((long long)qm) - 1 : -1; if (ff >= 0) qm &= qm - 1; if ((LANE >> 4) == g) j = ff; }
+            const int jj = j < 0 ? 0 : j;
+            const uint32_t nj = __shfl(ml, jj), o = __shfl(off, jj), n = j < 0 ? 0u : nj;
+            const uint64_t dj = ((uint64_t)__shfl((uint32_t)(dst >> 32), jj) << 32) | __shfl((uint32_t)dst, jj);
+            cz_gptr d = (cz_gptr)x.out + dj;
+            cz_quarter_copy(d, d - o, n, d);                            /* loads stay below the run's own destination */
+        }
+        unsigned long long big = __ballot(ready && ml > 32 && !(ml <= CZ_QCOPY_MAX && off >= ml));
         while (big) {
             const int j = __ffsll((long long)big) - 1; big &= big - 1;
             const uint32_t n = cz_uni(__shfl(ml, j)), o = cz_uni(__shfl(off, j));
             const uint64_t dj = ((uint64_t)cz_uni(__shfl((uint32_t)(dst >> 32), j)) << 32) | cz_uni(__shfl((uint32_t)dst, j));
             uint8_t* d = x.out + dj; const uint8_t* s = d - o;
+            CZ_PROF_CNT(CZ_P_N_BIG);
             if (o >= n) cz_coop_copy(d, s, n);
-            else if (o >= 64) {
-                /* overlapping but far enough apart: copy `o`-byte generations, each fully
-                   written before the next one reads it */
-                for (uint32_t base = 0; base < n; base += o) {
-                    const uint32_t m = (n - base < o) ? n - base : o;
-                    for (uint32_t k = (uint32_t)LANE; k < m; k += 64) d[base + k] = s[base + k];
+            else {
+                /* overlapping (decode_buffer.cairo:101-120 copies `o` bytes at a time): the output is periodic with period o
+                   from s on, so any earlier multiple of o is as good a source — the copied length doubles every time
+                   (o, 2o, 4o, ...: log2(n / o) non-overlapping copies instead of n / o) */
+                uint32_t copied = 0, L = o;
+                while (copied < n) {
+                    const uint32_t len = n - copied < L ? n - copied : L;
+                    cz_coop_copy(d + copied, d + copied - L, len);
                     __syncthreads();
+                    copied += len; L += L;
                 }
-            } else for (uint32_t k = (uint32_t)LANE; k < n; k += 64) d[k] = s[k % o];   /* period-o pattern: source [s, s+o) is complete */
+            }
         }
         if (ready) done = 1;
         __syncthreads();

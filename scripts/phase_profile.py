@@ -49,7 +49,7 @@ def main():
         print(f"cz_chain_kernel wave-time shares (s_memtime ticks summed over waves; {ctx.last_chain_ms():.3f} ms of the launch):")
         for name, v in zip(["parse+tables", "ring fill+init", "top-up events", "chain groups", "finalize"], cv[:5]):
             print(f"  {name:15s} {100.0 * v / ct:5.1f} %")
-        print(f"  top-up events {cv[5]}  ({cv[2] / max(cv[5], 1):.0f} ticks each), groups {cv[6]} ({cv[3] / max(cv[6], 1):.1f} ticks each; 1 tick = 10 ns)")
+        print(f"  top-up events {cv[5]}  ({cv[2] / max(cv[5], 1):.0f} ticks each), groups {cv[6]} ({cv[3] / max(cv[6], 1):.1f} ticks each; ticks are shader clocks, ~0.5 ns)")
 
 
     rv = [buf[50 + i] for i in range(6)]

@@ -7,8 +7,9 @@ import json
 import sys
 
 
-def per_kernel(d, counter):
-    out = {}
+def per_dispatch(d, counter):
+    """[(dispatch id, kernel name, value summed over the XCD rows)] of the cz_ kernels, in dispatch order."""
+    by = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
@@ -16,18 +17,44 @@ def per_kernel(d, counter):
             k = row["Kernel_Name"].split("(")[0]
             if not k.startswith("cz_"):
                 continue
-            e = out.setdefault(k, {"sum": 0.0, "dispatches": set()})
-            e["sum"] += float(row["Counter_Value"])
-            e["dispatches"].add(row["Dispatch_Id"])
-    return {k: v["sum"] / max(len(v["dispatches"]), 1) for k, v in out.items()}
+            e = by.setdefault(int(row["Dispatch_Id"]), [k, 0.0])
+            e[1] += float(row["Counter_Value"])
+    return [(i, by[i][0], by[i][1]) for i in sorted(by)]
+
+
+def per_step(rows):
+    """Groups the dispatches into steps (a step starts at its first cz_scan_kernel, or at every dispatch when there is no
+    pre-pass) and returns the mean KB per step for each launch of the step, named by kernel and position."""
+    steps, cur = [], []
+    has_scan = any(k == "cz_scan_kernel" for _, k, _ in rows)
+    prev = None
+    for _, k, v in rows:
+        if (has_scan and k == "cz_scan_kernel" and prev != "cz_scan_kernel") or not has_scan:
+            if cur:
+                steps.append(cur)
+            cur = []
+        cur.append((k, v))
+        prev = k
+    if cur:
+        steps.append(cur)
+    shape = [k for k, _ in steps[-1]]
+    steps = [s for s in steps if [k for k, _ in s] == shape]
+    names, seen = [], {}
+    for k in shape:
+        seen[k] = seen.get(k, 0) + 1
+        names.append(k if shape.count(k) == 1 else f"{k}#{seen[k]}")
+    return {n: sum(s[i][1] for s in steps) / len(steps) for i, n in enumerate(names)}, len(steps)
 
 
 def main():
     fd, wd, bj, oj = sys.argv[1:5]
-    fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+    (fetch, nf), (write, nw) = per_step(per_dispatch(fd, "FETCH_SIZE")), per_step(per_dispatch(wd, "WRITE_SIZE"))
     line = json.load(open(bj))
     cfg = line["config"]
-    res = {"workload": cfg["workload"], "frames": cfg["frames_per_gpu"], "per_kernel": {},
+    res = {"workload": cfg["workload"], "frames": cfg["frames_per_gpu"], "steps_averaged": [nf, nw],
+           "launch_naming": "a kernel launched more than once per step is numbered in launch order: with the pre-pass, "
+                            "cz_decode_frames_kernel#1 is the literals pass and #2 the main pass",
+           "per_kernel": {},
            "algorithmic_read_bytes": cfg.get("compressed_bytes_rank0", cfg.get("compressed_bytes_per_gpu")),
            "algorithmic_write_bytes": cfg.get("decoded_bytes_rank0", cfg.get("decoded_bytes_per_gpu")),
            # bench.py quotes this file only for the kernel sources and launch options it was measured on
