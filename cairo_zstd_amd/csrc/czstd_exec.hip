@@ -191,14 +191,14 @@ __device__ static void czx_huf_stream_wave(cz_gcptr blk, cz_gptr target, uint32_
     const int32_t stop = (i + 1 == m) ? 0 : P0 - (int32_t)(i + 1) * C;
     CzGBits g; g.S = (uintptr_t)S; g.E = (uintptr_t)E; g.LB = (uintptr_t)blk; g.p = top_b;
     int32_t s = top_b, e = stop; uint32_t n = 0;
-    n = cz_gb_decode(g, mb, stop, live, nullptr, 0, nullptr);           /* 1. speculative pass */
+    n = cz_gb_decode(g, mb, stop, live, nullptr, 0, 0);           /* 1. speculative pass */
     if (live) e = g.p;
     for (int round = 0; round < 65; round++) {                          /* 2. fix the starts until nothing moves */
         const int32_t pe = __shfl_up(e, 1u);
         const int changed = live && i > 0 && pe != s;
         if (!__ballot(changed)) break;
         if (changed) { s = pe; g.p = s; }
-        const uint32_t nred = cz_gb_decode(g, mb, stop, changed, nullptr, 0, nullptr);
+        const uint32_t nred = cz_gb_decode(g, mb, stop, changed, nullptr, 0, 0);
         if (changed) { n = nred; e = g.p; }
     }
     const uint32_t incl = cz_wave_incl_scan(live ? n : 0u);             /* 3. output offsets, writing pass */
@@ -207,7 +207,7 @@ __device__ static void czx_huf_stream_wave(cz_gcptr blk, cz_gptr target, uint32_
     {
         g.p = s;
         const uint32_t room = off < cap ? cap - off : 0;
-        cz_gb_decode(g, mb, stop, live, target + off, room, nullptr);
+        cz_gb_decode(g, mb, stop, live, target + off, room, 0);
     }
     if (i == 0) {
         uint32_t fl = padbad ? 1u : 0u;

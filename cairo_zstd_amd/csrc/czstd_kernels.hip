@@ -450,6 +450,18 @@ __device__ static __attribute__((noinline)) void cz_huf_fill(uint32_t nsym) {
         for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.a.huf[base + k] = e;
     }
 }
+/* Entries of huf[] are symbol | length << 8; this adds, in bits 12..15, the length of the NEXT symbol when its whole
+ * code lies inside the index bits too (a prefix code that matches the known bits is determined by them; 0 otherwise), so
+ * that a pass that only counts can step two symbols at a time.  All lanes; huf[] complete. */
+__device__ static inline void cz_huf_fill_multi() {
+    const uint32_t mb = cz_uni(sh.huf_max_bits), size = 1u << mb, mask = size - 1;
+    /* only the length bits 8..11 of other entries are read, and those never change: no ordering between the lanes is needed */
+#pragma unroll 4
+    for (uint32_t idx = (uint32_t)LANE; idx < size; idx += 64) {
+        const uint32_t e = sh.a.huf[idx], l1 = (e >> 8) & 15u, l = (sh.a.huf[(idx << l1) & mask] >> 8) & 15u;
+        sh.a.huf[idx] = (uint16_t)((e & 0x0FFFu) | ((l1 + l <= mb ? l : 0u) << 12));
+    }
+}
 /* One huff0 stream, one lane (literals_section_decoder.cairo:183-243).  Writes at most `cap`
  * bytes to out but keeps counting.  flags: 1 ExtraPadding, 2 stream did not end exactly. */
 __device__ static __attribute__((noinline)) void cz_huf_stream(cz_gcptr src, uint32_t len, cz_gptr out, uint32_t cap,
@@ -463,7 +475,7 @@ __device__ static __attribute__((noinline)) void cz_huf_stream(cz_gcptr src, uin
     while (rb.remaining > 0) {
         cz_rb_refill(rb);
         const uint32_t e = sh.a.huf[(uint32_t)(rb.buf >> (64 - mb))];
-        const uint32_t nb = e >> 8;
+        const uint32_t nb = (e >> 8) & 15u;
         if (n < cap) out[n] = (uint8_t)e;
         n++;
         rb.buf <<= nb; rb.avail -= (int32_t)nb; rb.remaining -= (int32_t)nb;
@@ -586,6 +598,16 @@ __device__ static inline void cz_init_llml() {
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) sh.b.c.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
 }
 
+/* ---- copies of the general path: every global load of a lane is issued before its first store, so a run costs one
+ * memory round trip instead of one per byte (a byte loop whose store may alias the next load cannot be pipelined). */
+/* the low m (<= 16) bytes of v to d, any alignment, in at most four stores */
+__device__ static inline void cz_store_upto16(cz_gptr d, uint4 v, uint32_t m) {
+    if (m >= 16) { __builtin_memcpy(d, &v, 16); return; }
+    if (m & 8u) { const uint64_t t = ((uint64_t)v.y << 32) | v.x; __builtin_memcpy(d, &t, 8); d += 8; v.x = v.z; v.y = v.w; }
+    if (m & 4u) { __builtin_memcpy(d, &v.x, 4); d += 4; v.x = v.y; }
+    if (m & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(d, &h, 2); d += 2; v.x >>= 16; }
+    if (m & 1u) *d = (uint8_t)v.x;
+}
 /* ---- self-synchronising parallel huff0 decode ---------------------------------------------
  * A huff0 stream is a prefix code read in one direction, and prefix codes resynchronise: a
  * decoder started in the middle of a codeword falls back onto true codeword boundaries after a
@@ -634,8 +656,10 @@ __device__ static inline uint4 cz_gb_load(uintptr_t a, uintptr_t S, uintptr_t E,
 }
 /* One interval: reload the window at the current position, then decode up to CZ_GB_SYMS symbols
  * while p > stop.  `run` = this lane still has work.  Returns symbols decoded. */
-__device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_t stop, int run, uint8_t* out, uint32_t cap, uint32_t n0) {
+__device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_t stop, int run, cz_gptr out, uint32_t cap, uint32_t n0,
+                                               const int multi, int* full) {
     uint32_t n = 0;
+    *full = 0;
     if (run) {
         const int32_t p = g.p;
         const uintptr_t top = g.S + (uintptr_t)((p + 7) >> 3);          /* exclusive end of the byte holding bit p-1 */
@@ -654,36 +678,54 @@ __device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_
                    different symbols, so a per-symbol test makes the wave run the refill code at every symbol */
                 if ((j & 1u) == 0 && avail <= 32) { buf |= (uint64_t)q5 << (32 - avail); avail += 32; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = q0; q0 = 0; }
                 if (g.p > stop) {
-                    const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
-                    const uint32_t nb = e >> 8;
-                    word[grp] |= (e & 0xFFu) << (8 * j); n++;
-                    buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
+                    const uint32_t idx = (uint32_t)(buf >> (64 - mb));
+                    const uint32_t e = sh.a.huf[idx];
+                    if (multi) {
+                        /* counting only: two symbols when the index bits hold both, unless the second could begin at or below
+                           `stop` (then one, so that the range ends exactly where it would otherwise) */
+                        const uint32_t l1 = (e >> 8) & 15u, l2 = g.p - stop > (int32_t)mb ? e >> 12 : 0u;
+                        const uint32_t nb = l1 + l2;
+                        n += l2 ? 2u : 1u;
+                        buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
+                    } else {
+                        const uint32_t nb = (e >> 8) & 15u;
+                        word[grp] |= (e & 0xFFu) << (8 * j); n++;
+                        buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
+                    }
+                    if (grp == CZ_GB_SYMS / 4 - 1 && j == 3) *full = 1;   /* every step of the interval ran */
                 }
             }
         }
         if (out) {
-            if (n == CZ_GB_SYMS && n0 + CZ_GB_SYMS <= cap) {
-                uint4 v; v.x = word[0]; v.y = word[1]; v.z = word[2]; v.w = word[3];
-                __builtin_memcpy(out + n0, &v, 16); __builtin_memcpy(out + n0 + 16, &word[4], 4);
-            } else {
+            uint4 v; v.x = word[0]; v.y = word[1]; v.z = word[2]; v.w = word[3];
+            if (n == CZ_GB_SYMS && n0 + CZ_GB_SYMS <= cap) { __builtin_memcpy(out + n0, &v, 16); __builtin_memcpy(out + n0 + 16, &word[4], 4); }
+            else {
+                /* the last interval of a range (or a stream that runs over its capacity): exactly the bytes that are there,
+                   in at most seven stores (lanes end their ranges at different iterations, so this runs often) */
+                const uint32_t room = n0 < cap ? cap - n0 : 0u, m = n < room ? n : room;
+                cz_store_upto16(out + n0, v, m < 16u ? m : 16u);
 #pragma unroll
-                for (uint32_t t = 0; t < CZ_GB_SYMS; t++) if (t < n && n0 + t < cap) out[n0 + t] = (uint8_t)(word[t >> 2] >> (8 * (t & 3)));
+                for (uint32_t t = 16; t < CZ_GB_SYMS - 1; t++) if (t < m) out[n0 + t] = (uint8_t)(word[4] >> (8 * (t & 3)));
             }
         }
     }
     return n;
 }
 /* decode from position g.p while p > stop (all 64 lanes call this together; `live` lanes work) */
-__device__ static inline uint32_t cz_gb_decode(CzGBits& g, uint32_t mb, int32_t stop, int live, uint8_t* out, uint32_t cap,
-                                            int32_t* ck = nullptr) {
+__device__ static inline uint32_t cz_gb_decode(CzGBits& g, uint32_t mb, int32_t stop, int live, cz_gptr out, uint32_t cap, const int multi,
+                                            int32_t* ck = nullptr, uint32_t* ckn = nullptr) {
     uint32_t n = 0, it = 0;
     for (;;) {
         const int run = live && g.p > stop;
         if (!__ballot(run)) break;
-        const uint32_t got = cz_gb_interval(g, mb, stop, run, out, cap, n);
+        int full;
+        const uint32_t got = cz_gb_interval(g, mb, stop, run, out, cap, n, multi, &full);
         n += got; it++;
-        /* checkpoints of the speculative pass: position after 1, 2, 4 and 8 FULL intervals */
-        if (ck && run && got == CZ_GB_SYMS) { if (it == 1) ck[0] = g.p; else if (it == 2) ck[1] = g.p; else if (it == 4) ck[2] = g.p; else if (it == 8) ck[3] = g.p; }
+        /* checkpoints of the speculative pass: position and symbol count after 1, 2, 4 and 8 FULL intervals */
+        if (ck && run && full) {
+            if (it == 1) { ck[0] = g.p; ckn[0] = n; } else if (it == 2) { ck[1] = g.p; ckn[1] = n; }
+            else if (it == 4) { ck[2] = g.p; ckn[2] = n; } else if (it == 8) { ck[3] = g.p; ckn[3] = n; }
+        }
     }
     return n;
 }
@@ -712,7 +754,14 @@ __device__ static void cz_huf_streams_par(cz_gcptr blk, cz_gptr target, uint32_t
     CZ_PROF_DECL; CZ_PROF_T0();
     const int32_t CK_NONE = (int32_t)0x80000000;
     int32_t ck[4] = { CK_NONE, CK_NONE, CK_NONE, CK_NONE };            /* positions the speculative pass went through */
-    n = cz_gb_decode(g, mb, stop, live, nullptr, 0, ck);           /* 1. speculative pass */
+    uint32_t ckn[4] = { 0, 0, 0, 0 };                                   /* ... and the symbols it had counted there */
+    /* the passes that only count step two symbols at a time where the table says so (cz_huf_fill_multi) */
+#ifdef CZ_EXP_NO_MULTI
+#define CZ_MULTI 0
+#else
+#define CZ_MULTI 1
+#endif
+    n = cz_gb_decode(g, mb, stop, live, nullptr, 0, CZ_MULTI, ck, ckn);   /* 1. speculative pass */
     if (live) e = g.p;
     CZ_PROF_ACC(CZ_P_HUF_SPEC);
     /* 2. fix the starts until nothing moves */
@@ -722,18 +771,18 @@ __device__ static void cz_huf_streams_par(cz_gcptr blk, cz_gptr target, uint32_t
         if (!__ballot(changed)) break;
         /* A corrected lane rarely has to redo its whole range: as soon as it lands exactly on a
            position its speculative pass went through, the rest of that pass (end position, symbol
-           count) is already the truth.  Checkpoint j was taken after 20 << j symbols. */
+           count) is already the truth.  Checkpoint j was taken after 1 << j full intervals, ckn[j] symbols. */
         if (changed) { s = pe; g.p = s; }
         uint32_t nred = 0; int state = changed ? 0 : 2;                 /* 0 redoing, 1 merged into the old trajectory, 2 done */
         for (int j = 0; j < 4; j++) {
             const int try_ck = state == 0 && ck[j] != CK_NONE && ck[j] > stop;
-            nred += cz_gb_decode(g, mb, try_ck ? ck[j] : stop, try_ck, nullptr, 0);
+            nred += cz_gb_decode(g, mb, try_ck ? ck[j] : stop, try_ck, nullptr, 0, CZ_MULTI);
             if (try_ck) {
-                if (g.p == ck[j]) { n = nred + (n - (CZ_GB_SYMS << j)); state = 1; }   /* e stays */
+                if (g.p == ck[j]) { n = nred + (n - ckn[j]); state = 1; }   /* e stays */
                 else if (g.p <= stop) { n = nred; e = g.p; state = 2; ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE; }
             }
         }
-        nred += cz_gb_decode(g, mb, stop, state == 0, nullptr, 0);
+        nred += cz_gb_decode(g, mb, stop, state == 0, nullptr, 0, CZ_MULTI);
         if (state == 0) { n = nred; e = g.p; }
         if (changed) ck[0] = ck[1] = ck[2] = ck[3] = CK_NONE;           /* counts no longer line up with the checkpoints */
     }
@@ -746,7 +795,7 @@ __device__ static void cz_huf_streams_par(cz_gcptr blk, cz_gptr target, uint32_t
     {
         g.p = s;
         const uint32_t room = off < cap ? cap - off : 0;
-        cz_gb_decode(g, mb, stop, live, target + (uint64_t)k * seg + off, room);
+        cz_gb_decode(g, mb, stop, live, target + (uint64_t)k * seg + off, room, 0);
     }
     CZ_PROF_ACC(CZ_P_HUF_WRITE);
     if (mine && i == 0) {
@@ -860,16 +909,6 @@ struct CzExecCtx {
     uint32_t lit_used;
 };
 
-/* ---- copies of the general path: every global load of a lane is issued before its first store, so a run costs one
- * memory round trip instead of one per byte (a byte loop whose store may alias the next load cannot be pipelined). */
-/* the low m (<= 16) bytes of v to d, any alignment, in at most four stores */
-__device__ static inline void cz_store_upto16(cz_gptr d, uint4 v, uint32_t m) {
-    if (m >= 16) { __builtin_memcpy(d, &v, 16); return; }
-    if (m & 8u) { const uint64_t t = ((uint64_t)v.y << 32) | v.x; __builtin_memcpy(d, &t, 8); d += 8; v.x = v.z; v.y = v.w; }
-    if (m & 4u) { __builtin_memcpy(d, &v.x, 4); d += 4; v.x = v.y; }
-    if (m & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(d, &h, 2); d += 2; v.x >>= 16; }
-    if (m & 1u) *d = (uint8_t)v.x;
-}
 /* 16 bytes at s when the whole load lies inside the buffer (`whole`), else the first m bytes one by one */
 __device__ static inline uint4 cz_load_upto16(cz_gcptr s, uint32_t m, int whole) {
     uint4 v;
@@ -1523,6 +1562,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
     if (bc.huf_fill) {
         cz_huf_fill(bc.huf_nsym); __syncthreads();
+        if (cz_uni(bc.regen) >= 2048u || !last_block) { cz_huf_fill_multi(); __syncthreads(); }   /* pays from a few symbols per lane on; a carried table always has it */
         if (!last_block) {                                              /* carried for later Treeless blocks */
             for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)huf_global)[i] = ((const uint32_t*)sh.a.huf)[i];
         }
@@ -1829,6 +1869,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_decode_frames_
         if (fi >= a.n) break;
         const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;   /* the pre-pass sorted the frames: longest first */
         if (a.literals_only) {
+            /* a frame the scan kernel found no sequences section in (or did not list) gains nothing from literal nodes:
+               the main pass decodes its literals straight to where they are used */
+            if (a.chain_arena && cz_uni64(a.frame_first[f]) == 0) { if (LANE == 0) a.lit_first[f] = 0; continue; }
             cz_state_reset();
             __syncthreads();
             const uint64_t first = cz_run_frame_literals(a, (cz_gcptr)(a.in_base + a.in_off[f]), a.in_len[f], lit_scratch);
