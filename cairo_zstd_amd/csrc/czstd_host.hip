@@ -75,7 +75,7 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     if (!strstr(prop.gcnArchName, "gfx950")) { delete c; return CZ_E_NO_DEVICE; }   /* kernels are built for gfx950 only */
     c->num_cu = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, CZ_FSE_LDS_BYTES) != hipSuccess || occ <= 0) occ = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, CZ_MAIN_DYN_LDS) != hipSuccess || occ <= 0) occ = 4;
     c->occupancy = occ; c->grid_max = c->num_cu * occ;
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = nullptr; delete c; return CZ_E_HIP; } c->own_stream = true; }
@@ -168,7 +168,7 @@ CZ_EXPORT int cz_context_last_chain_ms(cz_context* c, float* ms) {
 }
 
 /* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context and
- * sizes its record arena: 8 bytes per sequence + 1056 per block with sequences; frames that do not fit fall back
+ * sizes its record arena: 8 bytes per sequence + 1312 per block with sequences; frames that do not fit fall back
  * to in-kernel chains, so any size is safe. */
 CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (!c) return CZ_E_INVALID_ARG;
@@ -360,7 +360,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
-    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, a);
+    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_MAIN_DYN_LDS, c->stream, a);
     CZ_HIP(c, hipGetLastError());
     CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));
     c->timed = true; c->last_grid = grid;

@@ -6,6 +6,12 @@
 #include "cairo_zstd_amd.h"
 
 #define CZ_FSE_LDS_BYTES ((512 + 512 + 256) * 4)
+#ifndef CZ_MAIN_DYN_LDS              /* experiment builds only: a smaller dynamic LDS for batches whose every frame is pre-passed */
+#define CZ_MAIN_DYN_LDS CZ_FSE_LDS_BYTES
+#endif
+#ifndef CZ_MAIN_WAVES                /* waves per SIMD the decode kernel is compiled for (launch bounds) */
+#define CZ_MAIN_WAVES 4
+#endif
 /* dynamic LDS declaration (the CPU emulation harness of tests/emu supplies a static stand-in) */
 #ifndef CZ_DYNAMIC_LDS
 #define CZ_DYNAMIC_LDS(name) extern __shared__ uint32_t name[]

@@ -93,12 +93,13 @@ int cz_decode_batch_host(cz_context* ctx,
                          void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,
                          cz_frame_result* results);
 
-/* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context
- * and sizes its record arena (8 bytes per sequence + 1056 per block with sequences; ~6x the
- * compressed bytes covers BASELINE config 4a).  With the pre-pass a batch decode is two launches:
- * cz_chain_kernel (twelve frames per wave, one FSE state-machine chain per lane) writes
- * per-sequence records, cz_decode_frames_kernel consumes them.  Frames the arena cannot hold, that are
- * irregular in any way, or whose chains are short, are decoded entirely by cz_decode_frames_kernel. */
+/* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context and sizes its record
+ * arena (8 bytes per sequence + 1312 per block with sequences; 8x the compressed bytes + 64 MiB covers every BASELINE
+ * config).  With the pre-pass a batch decode is: cz_scan_kernel twice (lists the blocks of all frames, sorted by
+ * sequence count, and allocates their arena space) -> cz_chain_kernel (ten blocks per wave, the three FSE state
+ * machines of a block on three lanes; writes one record per sequence) -> cz_decode_frames_kernel, which consumes the
+ * records.  Frames the arena cannot hold, or that are irregular in any way, are decoded entirely by
+ * cz_decode_frames_kernel: errors are only ever reported by it. */
 int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
 /* Enables (bytes > 0) or disables (0) the literals pass that goes with the pre-pass: the Huffman-coded literals of the
  * frames the pre-pass takes are decoded (tree description, table, streams: literals_section_decoder.cairo:58-243) by a
