@@ -291,19 +291,17 @@ __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL 
     "v_and_or_b32 v101, %[E], %[XM], %[K64]\n" \
     "v_sub_u32 v102, v101, v100\n" \
     "v_lshrrev_b32 v103, 22, %[E]\n" \
-    "v_max_u32 %[SLOW], %[SLOW], v108\n"          /* extra bits of the PREVIOUS step (0 before the first) */ \
+    "v_and_b32 %[PH], 31, %[U]\n"                 /* phase of the cursor (and the second instruction between v102 and its DPP readers) */ \
     "v_add_u32_dpp v105, v102, v102 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
     "v_and_b32_dpp v106, v102, %[M1] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n" \
     "v_and_b32_dpp v107, v102, %[M2] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" \
     "v_add_u32_dpp v105, v102, v105 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
     "v_add3_u32 v109, v106, v107, v102\n" \
-    "v_bfe_u32 v108, v105, 16, 8\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_cmp_ge_u32 vcc, %[PH], v108\n" \
-    "v_sub_u32 v110, %[PH], v108\n" \
+    "v_sub_co_u32_sdwa v110, vcc, %[PH], v105 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"   /* phase - extra bits of the quad (byte 2 of the sum); vcc = they reach below the cursor word */ \
     "v_alignbit_b32 " WIN ", %[W2], v125, %[PH]\n" \
-    "v_cndmask_b32 v111, v125, %[W2], vcc\n" \
-    "v_cndmask_b32 v112, v124, v125, vcc\n" \
+    "v_cndmask_b32 v111, %[W2], v125, vcc\n" \
+    "v_cndmask_b32 v112, v125, v124, vcc\n" \
     "v_alignbit_b32 v113, v111, v112, v110\n" \
     "v_bfe_u32 v116, v113, v109, v100\n" \
     "v_lshl_or_b32 %[S], v103, v100, v116\n" \
@@ -333,11 +331,10 @@ __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL 
     STORE \
     "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n" \
     "v_dot4c_i32_i8_e32 %[U], 0x01ff0001, v105\n" \
-    "v_and_b32 v119, 31, v108\n"                  /* spacer: v118 -> DPP two instructions, v_dot4c -> reader three, 16-byte store -> write of its data one */ \
+    "v_max_u32_sdwa %[SLOW], %[SLOW], v105 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n"   /* most extra bits of any step so far; also the spacer: v118 -> DPP two instructions, v_dot4c -> reader three, 16-byte store -> write of its data one */ \
     "v_add_u32_dpp " NEXTH ", v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
     "v_add_u32_dpp " NEXTH ", v118, " NEXTH " quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
     "v_bfe_u32 v114, %[U], 5, 7\n" \
-    "v_and_b32 %[PH], 31, %[U]\n" \
     "v_lshl_add_u32 v115, v114, 2, %[RB]\n" \
     CZC_ASM_RING01 \
     "ds_read_b32 %[W2], v115 offset:8\n"
@@ -370,7 +367,7 @@ __device__ static inline void czc_group_asm(CzcLane& c, const CzcRole& ro, CZ_GL
         CZC_ASM_PAIR(0) CZC_ASM_PAIR(16) CZC_ASM_PAIR(32) CZC_ASM_PAIR(48) CZC_ASM_PAIR(64) CZC_ASM_PAIR(80) CZC_ASM_PAIR(96) CZC_ASM_PAIR(112)
         CZC_ASM_PAIR(128) CZC_ASM_PAIR(144) CZC_ASM_PAIR(160) CZC_ASM_PAIR(176) CZC_ASM_PAIR(192) CZC_ASM_PAIR(208) CZC_ASM_PAIR(224) CZC_ASM_PAIR(240)
         "s_waitcnt lgkmcnt(0)\n"
-        "v_max_u32 %[SLOW], %[SLOW], v108\n"
+        "v_and_b32 %[PH], 31, %[U]\n"
         "v_mov_b32 %[W0], v124\n"
         "v_mov_b32 %[W1], v125\n"
         : [E] "+v"(c.E), [S] "+v"(c.S), [U] "+v"(c.u), [PH] "+v"(c.ph), [W0] "+v"(c.w0), [W1] "+v"(c.w1), [W2] "+v"(c.w2), [SLOW] "+v"(c.slow)

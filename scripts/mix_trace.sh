@@ -1,0 +1,15 @@
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+mkdir -p gpurun_out/r2; rm -rf gpurun_out/r2/kt_mix
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r2/kt_mix -- python3 scripts/kernel_times.py --child mix 12500 > gpurun_out/r2/kt_mix.log 2>&1
+python3 - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/r2/kt_mix/**/*kernel_trace.csv',recursive=True)[0]
+rows=[r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('cz_')]
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+t0=None
+for r in rows[-6:]:
+    s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
+    if t0 is None: t0=s
+    print(f"{r['Kernel_Name'][:28]:28s} start {(s-t0)/1e6:8.3f} ms  dur {(e-s)/1e6:8.3f} ms")
+PY
+mkdir -p gpurun_out/r2; rm -rf gpurun_out/r2/kt_mix
