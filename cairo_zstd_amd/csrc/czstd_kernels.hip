@@ -674,26 +674,32 @@ __device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_
         for (uint32_t grp = 0; grp < CZ_GB_SYMS / 4; grp++) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                /* refill once per PAIR of symbols (a pair takes at most 22 of the >= 33 bits): lanes refill at
-                   different symbols, so a per-symbol test makes the wave run the refill code at every symbol */
-                if ((j & 1u) == 0 && avail <= 32) { buf |= (uint64_t)q5 << (32 - avail); avail += 32; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = q0; q0 = 0; }
-                if (g.p > stop) {
-                    const uint32_t idx = (uint32_t)(buf >> (64 - mb));
-                    const uint32_t e = sh.a.huf[idx];
-                    if (multi) {
-                        /* counting only: two symbols when the index bits hold both, unless the second could begin at or below
-                           `stop` (then one, so that the range ends exactly where it would otherwise) */
-                        const uint32_t l1 = (e >> 8) & 15u, l2 = g.p - stop > (int32_t)mb ? e >> 12 : 0u;
-                        const uint32_t nb = l1 + l2;
-                        n += l2 ? 2u : 1u;
-                        buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
-                    } else {
-                        const uint32_t nb = (e >> 8) & 15u;
-                        word[grp] |= (e & 0xFFu) << (8 * j); n++;
-                        buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
-                    }
-                    if (grp == CZ_GB_SYMS / 4 - 1 && j == 3) *full = 1;   /* every step of the interval ran */
+                /* Branch-free: every lane runs every step and a lane that is past its range consumes zero bits.  (Predicated
+                   steps made the compiler carry word[] through a chain of v_mov copies and an exec save/restore per symbol.)
+                   Refill once per PAIR of symbols (a pair takes at most 22 of the >= 33 bits). */
+                if ((j & 1u) == 0) {
+                    const int rf = avail <= 32;
+                    const uint32_t sh_ = rf ? (uint32_t)(32 - avail) : 0u;
+                    buf |= (uint64_t)(rf ? q5 : 0u) << sh_;
+                    avail += rf ? 32 : 0;
+                    q5 = rf ? q4 : q5; q4 = rf ? q3 : q4; q3 = rf ? q2 : q3; q2 = rf ? q1 : q2; q1 = rf ? q0 : q1; q0 = rf ? 0u : q0;
                 }
+                const int live = g.p > stop;
+                const uint32_t e = sh.a.huf[(uint32_t)(buf >> (64 - mb))];
+                uint32_t nb;
+                if (multi) {
+                    /* counting only: two symbols when the index bits hold both, unless the second could begin at or below
+                       `stop` (then one, so that the range ends exactly where it would otherwise) */
+                    const uint32_t l2 = g.p - stop > (int32_t)mb ? e >> 12 : 0u;
+                    nb = live ? ((e >> 8) & 15u) + l2 : 0u;
+                    n += live ? (l2 ? 2u : 1u) : 0u;
+                } else {
+                    nb = live ? (e >> 8) & 15u : 0u;
+                    word[grp] |= (live ? e & 0xFFu : 0u) << (8 * j);
+                    n += live ? 1u : 0u;
+                }
+                buf <<= nb; avail -= (int32_t)nb; g.p -= (int32_t)nb;
+                if (grp == CZ_GB_SYMS / 4 - 1 && j == 3) *full = live;  /* the cursor only moves down: every step of the interval ran */
             }
         }
         if (out) {
