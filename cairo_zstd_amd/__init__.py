@@ -280,6 +280,75 @@ class DecoderScratch:
     def hash_digest(self) -> int:
         return int(lib().cz_decoder_scratch_hash_digest(self._h))
 
+    def init_from_dict(self, dictionary: "Dictionary") -> int:
+        """DecoderScratchTrait::init_from_dict (src/decoding/scratch.cairo:60-65)."""
+        self._dict = dictionary                                        # keep it alive while the workspace uses it
+        return lib().cz_decoder_scratch_init_from_dict(self._h, dictionary._h)
+
+
+class Dictionary:
+    """Dictionary / DictionaryTrait::decode_dict (src/decoding/dictionary.cairo:11-91), parsed on and resident in the device."""
+
+    def __init__(self, ctx: "Context", raw):
+        a = _as_u8(raw)
+        self._ctx, self._h = ctx, C.c_void_p()
+        detail = (C.c_uint64 * 2)()
+        st = lib().cz_dictionary_decode(ctx._h, a.ctypes.data if a.size else None, a.size, C.byref(self._h), detail)
+        if st:
+            self._h = None
+            raise CzError(st, f"cz_dictionary_decode (detail {int(detail[0]):#x})")
+        ctx._decoders.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().cz_dictionary_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    @property
+    def id(self) -> int:
+        return int(lib().cz_dictionary_id(self._h))
+
+    @property
+    def content_len(self) -> int:
+        return int(lib().cz_dictionary_content_len(self._h))
+
+    @property
+    def offset_hist(self):
+        v = (C.c_uint32 * 3)()
+        lib().cz_dictionary_offset_hist(self._h, v)
+        return tuple(int(x) for x in v)
+
+
+def decode_frame_with_dict(src, dictionary: Dictionary, ctx: "Context") -> bytes:
+    """One frame, block by block, on a workspace seeded from `dictionary`: read_frame_header -> DecoderScratch::new ->
+    init_from_dict -> {read_block_header, decode_block_content} until the last block -> drain.  (The reference's
+    FrameDecoder never calls init_from_dict, so neither does cz_frame_decoder_*.)  Raises CzError."""
+    a = _as_u8(src)
+    st, fh, _ = read_frame_header(a)
+    if st:
+        raise CzError(st, "read_frame_header")
+    ws = DecoderScratch(ctx, int(fh.window_size))
+    try:
+        st = ws.init_from_dict(dictionary)
+        if st:
+            raise CzError(st, "init_from_dict")
+        bd, pos = BlockDecoder(), int(fh.header_len)
+        while True:
+            st, bh, used = bd.read_block_header(a[pos:])
+            if st:
+                raise CzError(st, f"read_block_header at byte {pos}")
+            pos += used
+            st, used = bd.decode_block_content(bh, ws, a[pos:])
+            if st:
+                raise CzError(st, f"decode_block_content at byte {pos}")
+            pos += used
+            if bh.last_block:
+                return ws.drain(max(ws.buffer_len(), 1))
+    finally:
+        ws.close()
+
 
 class BlockDecoder:
     """BlockDecoder (src/decoding/block_decoder.cairo:20-30, :69-137, :237-278)."""

@@ -157,6 +157,18 @@ def lib() -> C.CDLL:
         L.cz_block_decoder_read_block_header.argtypes = [vp, vp, sz, C.POINTER(BlockHeader), C.POINTER(C.c_uint8)]
         L.cz_block_decoder_decode_block_content.restype = C.c_int
         L.cz_block_decoder_decode_block_content.argtypes = [vp, C.POINTER(BlockHeader), vp, vp, sz, u64p]
+        if hasattr(L, "cz_dictionary_decode"):
+            L.cz_dictionary_decode.restype = C.c_int
+            L.cz_dictionary_decode.argtypes = [vp, vp, sz, C.POINTER(vp), u64p]
+            L.cz_dictionary_destroy.argtypes = [vp]
+            L.cz_dictionary_id.restype = C.c_uint32
+            L.cz_dictionary_id.argtypes = [vp]
+            L.cz_dictionary_content_len.restype = sz
+            L.cz_dictionary_content_len.argtypes = [vp]
+            L.cz_dictionary_offset_hist.restype = C.c_int
+            L.cz_dictionary_offset_hist.argtypes = [vp, C.POINTER(C.c_uint32)]
+            L.cz_decoder_scratch_init_from_dict.restype = C.c_int
+            L.cz_decoder_scratch_init_from_dict.argtypes = [vp, vp]
         L.cz_frame_decoder_scratch.restype = vp
         L.cz_frame_decoder_scratch.argtypes = [vp]
     _lib = L

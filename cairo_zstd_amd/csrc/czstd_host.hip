@@ -568,6 +568,14 @@ struct Xxh64 {
  * decoded frame stays in HBM; `drained` marks how much the host already collected (buffer.len() == produced - drained)
  * and `base_off` how many leading frame bytes were dropped from the resident buffer (only drained bytes are ever
  * dropped, and a match can only reach bytes that are still in the buffer, decode_buffer.cairo:65). */
+/* Dictionary (src/decoding/dictionary.cairo:11-18): the raw bytes and the carried-state image decode_dict makes of them, both
+ * in HBM.  The tables are built by cz_dict_setup_kernel with the decoder's own builders. */
+struct cz_dictionary {
+    cz_context* ctx = nullptr;
+    uint8_t* d_raw = nullptr; size_t len = 0; size_t content_off = 0;
+    cz_device_frame_state* d_state = nullptr;
+    uint32_t id = 0; uint32_t hist[3] = {0, 0, 0};
+};
 struct cz_decoder_scratch {
     cz_context* ctx = nullptr;
     uint64_t window_size = 0;
@@ -575,6 +583,7 @@ struct cz_decoder_scratch {
     Xxh64 hash;
     uint8_t* d_src = nullptr; size_t d_src_cap = 0;
     uint8_t* d_ctl = nullptr;   /* [state | state backup | task | result] */
+    const struct cz_dictionary* dict = nullptr;   /* DecodeBuffer.dict_content comes from it (init_from_dict); cleared by reset */
 };
 static const size_t CTL_STATE = 0, CTL_BACKUP = (sizeof(cz_device_frame_state) + 255) & ~(size_t)255,
                     CTL_TASK = 2 * CTL_BACKUP, CTL_RES = CTL_TASK + 256, CTL_BYTES = CTL_RES + 256;
@@ -587,6 +596,7 @@ static int scratch_reset_state(cz_decoder_scratch* s, uint64_t window_size) {   
     CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_STATE, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     s->window_size = window_size; s->produced = 0; s->drained = 0; s->base_off = 0; s->hash.reset();
+    s->dict = nullptr;                                                  /* decode_buffer.cairo:38 */
     return CZ_OK;
 }
 CZ_EXPORT int cz_decoder_scratch_create(cz_context* ctx, uint64_t window_size, cz_decoder_scratch** out) {
@@ -612,6 +622,62 @@ CZ_EXPORT void cz_decoder_scratch_destroy(cz_decoder_scratch* s) {
 }
 CZ_EXPORT size_t cz_decoder_scratch_buffer_len(const cz_decoder_scratch* s) { return s ? (size_t)(s->produced - s->drained) : 0; }   /* buffer.len() */
 CZ_EXPORT uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s) { return s ? s->produced : 0; }              /* total_output_counter */
+
+/* DictionaryTrait::decode_dict (dictionary.cairo:35-91) */
+CZ_EXPORT int cz_dictionary_decode(cz_context* c, const uint8_t* raw, size_t len, cz_dictionary** out, uint64_t* detail) {
+    if (!c || !out || (!raw && len)) return CZ_E_INVALID_ARG;
+    *out = nullptr;
+    if (detail) { detail[0] = 0; detail[1] = 0; }
+    CZ_HIP(c, hipSetDevice(c->device));
+    cz_dictionary* d = new (std::nothrow) cz_dictionary();
+    if (!d) return CZ_E_INVALID_ARG;
+    d->ctx = c; d->len = len;
+    uint64_t* d_res = nullptr;
+    auto fail = [&](int st) { if (d->d_raw) (void)hipFree(d->d_raw); if (d->d_state) (void)hipFree(d->d_state); if (d_res) (void)hipFree(d_res); delete d; return st; };
+    if (hipMalloc((void**)&d->d_raw, len + 16) != hipSuccess || hipMalloc((void**)&d->d_state, sizeof(cz_device_frame_state)) != hipSuccess ||
+        hipMalloc((void**)&d_res, 64) != hipSuccess) return fail(CZ_E_HIP);
+    if (len && hipMemcpyAsync(d->d_raw, raw, len, hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(CZ_E_HIP);
+    hipLaunchKernelGGL(cz_dict_setup_kernel, dim3(1), dim3(CZ_WG_THREADS), CZ_FSE_LDS_BYTES, c->stream, (const uint8_t*)d->d_raw, (uint64_t)len, d->d_state, d_res);
+    uint64_t res[4] = {0, 0, 0, 0};
+    cz_device_frame_state* hs = new (std::nothrow) cz_device_frame_state();
+    if (!hs || hipGetLastError() != hipSuccess || hipMemcpyAsync(res, d_res, sizeof res, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { delete hs; return fail(CZ_E_HIP); }
+    if (detail) detail[0] = res[3];                                     /* the magic number read (BadMagicNum) */
+    if (res[0]) { delete hs; return fail((int)res[0]); }
+    if (hipMemcpy(hs, d->d_state, sizeof *hs, hipMemcpyDeviceToHost) != hipSuccess) { delete hs; return fail(CZ_E_HIP); }
+    d->content_off = (size_t)res[1]; d->id = (uint32_t)res[2];
+    for (int k = 0; k < 3; k++) d->hist[k] = hs->hist[k];
+    delete hs;
+    (void)hipFree(d_res);
+    *out = d;
+    return CZ_OK;
+}
+CZ_EXPORT void cz_dictionary_destroy(cz_dictionary* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->d_raw) (void)hipFree(d->d_raw);
+    if (d->d_state) (void)hipFree(d->d_state);
+    delete d;
+}
+CZ_EXPORT uint32_t cz_dictionary_id(const cz_dictionary* d) { return d ? d->id : 0; }
+CZ_EXPORT size_t cz_dictionary_content_len(const cz_dictionary* d) { return d ? d->len - d->content_off : 0; }
+CZ_EXPORT int cz_dictionary_offset_hist(const cz_dictionary* d, uint32_t out[3]) {
+    if (!d || !out) return CZ_E_INVALID_ARG;
+    for (int k = 0; k < 3; k++) out[k] = d->hist[k];
+    return CZ_OK;
+}
+/* DecoderScratchTrait::init_from_dict (scratch.cairo:60-65): tables, repeat offsets and dict_content of the workspace
+   become the dictionary's.  The dictionary must outlive the workspace's use of it. */
+CZ_EXPORT int cz_decoder_scratch_init_from_dict(cz_decoder_scratch* s, const cz_dictionary* d) {
+    if (!s || !d || s->ctx != d->ctx) return CZ_E_INVALID_ARG;
+    cz_context* c = s->ctx;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_STATE, d->d_state, sizeof(cz_device_frame_state), hipMemcpyDeviceToDevice, c->stream));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    s->dict = d;
+    return CZ_OK;
+}
 
 /* Makes room for `need` resident bytes behind base_off, keeping what a match or a drain can still reach:
  * first drops the drained prefix (compaction), then grows. */
@@ -665,6 +731,7 @@ static int scratch_run(cz_decoder_scratch* s, const uint8_t* src, size_t len, ui
         t.dst_cap = s->base_off + s->d_out_cap; t.produced = s->produced; t.drained = s->drained;
         t.window_size = s->window_size; t.strategy = strategy; t.strategy_n = n; t.has_checksum = has_checksum; t.streaming = streaming;
         t.state = (cz_device_frame_state*)(s->d_ctl + CTL_STATE);
+        if (s->dict) { t.dict = s->dict->d_raw + s->dict->content_off; t.dict_len = s->dict->len - s->dict->content_off; }
         CZ_HIP(c, hipMemcpyAsync(s->d_ctl + CTL_TASK, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
         cz_batch_args a; memset(&a, 0, sizeof a);
         a.tasks = (const cz_device_task*)(s->d_ctl + CTL_TASK); a.results = (cz_frame_result*)(s->d_ctl + CTL_RES);

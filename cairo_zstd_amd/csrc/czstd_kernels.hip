@@ -116,6 +116,7 @@ struct CzShared {
     } b;
     CzBroadcast bc;
     uint32_t frame_idx;
+    uint32_t dict_lag[2];               /* cz_device_frame_state.dict_lag of the frame in flight (lo, hi) */
 #ifdef CZ_PROFILE
     unsigned long long prof[CZ_P_COUNT];
 #endif
@@ -913,6 +914,8 @@ struct CzExecCtx {
     uint64_t drained;        /* bytes drained by the host (buffer.len = produced - drained) */
     uint64_t window;
     uint32_t lit_used;
+    cz_gcptr dict; uint64_t dict_len;   /* DecodeBuffer.dict_content: logically just before the first resident byte (position `drained`) */
+    uint64_t lag;            /* see cz_device_frame_state.dict_lag */
 };
 
 /* 16 bytes at s when the whole load lies inside the buffer (`whole`), else the first m bytes one by one */
@@ -978,12 +981,27 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
     if (active) {
         if (ll > 0 && (uint64_t)lit_used + p.lrel + ll > lit.len) e = CZ_E_EXEC_NOT_ENOUGH_LITERALS;   /* :28-36 */
         else if (off == 0) e = CZ_E_EXEC_ZERO_OFFSET;                                               /* :47 */
-        else if (ml > 0 && (uint64_t)off > dst - x.drained)                                         /* decode_buffer.cairo:65 */
-            e = (dst <= x.window) ? CZ_E_EXEC_NOT_ENOUGH_DICT : CZ_E_EXEC_OFFSET_TOO_BIG;           /* :66-75 / :92 */
-        else if (dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
     }
+    /* matches that begin before the first resident byte: dictionary content, if the frame has one and the reference's
+       total_output_counter (which skips matches copied wholly from the dictionary: lag) is still inside the window
+       (decode_buffer.cairo:65-93) */
+    const int reach = active && !e && ml > 0 && (uint64_t)off > dst - x.drained;
+    int dictm = 0;
+    if (__ballot(reach)) {
+        const uint64_t bfd = reach ? (uint64_t)off - (dst - x.drained) : 0;                         /* bytes_from_dict :67 */
+        const int cand = reach && bfd <= x.dict_len;
+        const uint32_t lag_lane = cand && bfd >= ml ? ml : 0u;                                      /* :85-90 */
+        const uint64_t lag_before = x.lag + (cz_wave_incl_scan(lag_lane) - lag_lane);
+        if (reach) {
+            if (dst - lag_before > x.window) e = CZ_E_EXEC_OFFSET_TOO_BIG;                          /* :92 */
+            else if (!cand) e = CZ_E_EXEC_NOT_ENOUGH_DICT;                                          /* :69-75 */
+            else dictm = 1;
+        }
+    }
+    if (active && !e && dst + ml > x.cap) e = CZ_E_OUTPUT_TOO_SMALL;
     const unsigned long long emask = __ballot(e != 0);
     if (emask) { const int first = __ffsll((long long)emask) - 1; p.err = cz_unii(__shfl(e, first)); }
+    else if (__ballot(dictm)) p.err = -1;                               /* not an error: cz_chunk_copy takes the dictionary path */
     return p;
 }
 /* First NL literal bytes and first NMB match bytes (plain far matches) of every lane into the chunk
@@ -1025,7 +1043,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
      * fetched from global memory with every load of a lane issued before its first use (one memory
      * round trip per phase instead of one per byte); matches that read the chunk's own output are
      * resolved by dependency rounds inside LDS. */
-    if (sum_tot <= CZ_OBUF_BYTES && !__ballot(ll > CZ_OBUF_MAXLEN || ml > CZ_OBUF_MAXLEN)) {
+    if (p.err == 0 && sum_tot <= CZ_OBUF_BYTES && !__ballot(ll > CZ_OBUF_MAXLEN || ml > CZ_OBUF_MAXLEN)) {
         CZ_PROF_CNT(CZ_P_N_FAST);
         uint8_t* ob = sh.a.t4.obuf;
         const uint32_t orel = incl_tot - tot, drel = orel + ll;
@@ -1127,6 +1145,15 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
        destination of the first undone sequence; a sequence may go once its source range
        (clipped to its own destination for self-overlap) lies below W. */
     int done = !(active && ml > 0);
+    /* dictionary matches (p.err < 0: the plan found some, and no error): a lane whose match begins before the first
+       resident byte copies bytes_from_dict bytes from the end of the dictionary content and goes on from the START of the
+       resident buffer (decode_buffer.cairo:77-90) — when every earlier sequence is done, one byte at a time */
+    const int dictm = p.err < 0 && active && ml > 0 && (uint64_t)off > dst - x.drained;
+    if (p.err < 0) {
+        const uint64_t bfd = dictm ? (uint64_t)off - (dst - x.drained) : 0;
+        const uint32_t lag_lane = dictm && bfd >= ml ? ml : 0u;
+        x.lag += cz_readlane(cz_wave_incl_scan(lag_lane), 63);
+    }
     const uint64_t src = dst - off;
     const uint64_t src_end = (src + ml < dst) ? src + ml : dst;
     for (;;) {
@@ -1134,7 +1161,13 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         if (!pend) break;
         const int f = __ffsll((long long)pend) - 1;
         const uint64_t W = ((uint64_t)__shfl((uint32_t)(dst >> 32), f) << 32) | __shfl((uint32_t)dst, f);
-        const int ready = !done && src_end <= W;
+        if (dictm && !done && LANE == f) {
+            const uint64_t bfd = (uint64_t)off - (dst - x.drained);
+            cz_gptr d = (cz_gptr)x.out + dst; cz_gcptr dc = x.dict + (x.dict_len - bfd); cz_gcptr head = (cz_gcptr)x.out + x.drained;
+            for (uint32_t k = 0; k < ml; k++) d[k] = k < bfd ? dc[k] : head[k - bfd];
+            done = 1;
+        }
+        const int ready = !done && !dictm && src_end <= W;
         CZ_PROF_CNT(CZ_P_N_ROUNDS);
         if (ready && ml <= 32) {
             cz_gptr d = (cz_gptr)x.out + dst; cz_gcptr sp = (cz_gcptr)x.out + src;
@@ -1184,7 +1217,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
 
 __device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t cnt, uint32_t ll, uint32_t ml, uint32_t off) {
     const CzPlan p = cz_chunk_plan(x, x.produced, x.lit_used, lit, cnt, ll, ml, off);
-    if (p.err) return p.err;
+    if (p.err > 0) return p.err;
     return cz_chunk_copy(x, lit, p);
 }
 
@@ -1516,7 +1549,7 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
     for (uint32_t done = 0; done < nseq; done += 64) {
         const CzPlan cur = plan(r1, done, x.produced, x.lit_used);
         r1 = r2; r2 = r3; r3 = load_rec(done + 192);
-        if (cur.err) return cur.err;
+        if (cur.err > 0) return cur.err;
         CZ_PROF_ACC(CZ_P_EXTRACT);
         exec_err = cz_chunk_copy(x, lit, cur);
         CZ_PROF_T0();
@@ -1542,8 +1575,9 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref
     CzExecCtx x = xref;
     x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
     x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
+    x.dict = (cz_gcptr)cz_uni64((uint64_t)x.dict); x.dict_len = cz_uni64(x.dict_len); x.lag = cz_uni64(x.lag);
     const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags, bits);
-    xref.produced = x.produced; xref.lit_used = x.lit_used;
+    xref.produced = x.produced; xref.lit_used = x.lit_used; xref.lag = x.lag;
     return e;
 }
 
@@ -1727,6 +1761,7 @@ struct CzFrameIO {
     uint64_t produced, drained, window;
     uint32_t parse_header, has_checksum, strategy, streaming; uint64_t strategy_n;
     uint32_t verify;          /* compute XXH64 of the decoded frame and compare with the frame's checksum */
+    cz_gcptr dict; uint64_t dict_len;   /* dictionary content of the frame's DecodeBuffer (resumable path only) */
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
@@ -1743,6 +1778,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         __syncthreads();
     }
     CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
+    x.dict = io.dict; x.dict_len = io.dict_len; x.lag = ((uint64_t)cz_uni(sh.dict_lag[1]) << 32) | cz_uni(sh.dict_lag[0]);
     const uint64_t produced0 = io.produced;
     while (!err) {
         /* block header (block_decoder.cairo:237-321) */
@@ -1812,6 +1848,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         res->checksum_from_data = cksum; res->flags = flags; res->calculated_checksum = calc; res->reserved = 0;
         res->detail[0] = io.parse_header && (err == CZ_E_FH_SKIP_FRAME || err == CZ_E_FH_BAD_MAGIC) ? bc.d0 : blocks;
         res->detail[1] = io.parse_header && err == CZ_E_FH_SKIP_FRAME ? bc.d1 : pos;
+        sh.dict_lag[0] = (uint32_t)x.lag; sh.dict_lag[1] = (uint32_t)(x.lag >> 32);
     }
     __syncthreads();
 }
@@ -1829,7 +1866,7 @@ __device__ static uint64_t cz_run_frame_literals(const cz_batch_args& a, cz_gcpt
     uint64_t pos = cz_uni(bc.hdr_len);
     __syncthreads();
     if (err) return 0;
-    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0;
+    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0; x.dict = nullptr; x.dict_len = 0; x.lag = 0;
     CzLitPass lp; lp.arena = nullptr; lp.cursor = 0; lp.first = 0; lp.last_nseq = 0;
     uint64_t no_chain = 0; int seen_seq = 0;
     for (;;) {
@@ -1857,7 +1894,73 @@ __device__ static void cz_state_reset() {                   /* scratch.cairo:23-
         sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
         sh.fse_rle[0] = sh.fse_rle[1] = sh.fse_rle[2] = -1;
         sh.fse_log[0] = sh.fse_log[1] = sh.fse_log[2] = 0; sh.huf_max_bits = 0;
+        sh.dict_lag[0] = sh.dict_lag[1] = 0;
     }
+}
+
+/* DictionaryTrait::decode_dict (dictionary.cairo:35-91) on the device, with the decoder's own table builders, so that the
+ * tables come out in the layout the kernels use: Huffman table, then the OF, ML and LL tables (max logs 8, 9, 9), three
+ * repeat offsets, and the rest is content.  One workgroup, CZ_FSE_LDS_BYTES of dynamic LDS.
+ * result: [status, offset of the content, dictionary id, magic number read]. */
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel(const uint8_t* raw_, uint64_t len, cz_device_frame_state* st_, uint64_t* result_) {
+    cz_gcptr raw = (cz_gcptr)raw_; CZ_GLOBAL cz_device_frame_state* st = (CZ_GLOBAL cz_device_frame_state*)st_;
+    CZ_GLOBAL uint64_t* result = (CZ_GLOBAL uint64_t*)result_;
+    CzBroadcast& bc = sh.bc;
+    cz_init_llml(); cz_state_reset();
+    __syncthreads();
+    int err = 0; uint64_t off = 8; uint32_t magic = 0, id = 0;
+    if (len < 8) err = CZ_E_DICT_TRUNCATED;                             /* (panic) :45,:50 */
+    else {
+        magic = (uint32_t)raw[0] | ((uint32_t)raw[1] << 8) | ((uint32_t)raw[2] << 16) | ((uint32_t)raw[3] << 24);
+        id = (uint32_t)raw[4] | ((uint32_t)raw[5] << 8) | ((uint32_t)raw[6] << 16) | ((uint32_t)raw[7] << 24);
+        if (magic != 0xEC30A437u) err = CZ_E_DICT_BAD_MAGIC;            /* :46-48 */
+    }
+    if (!err) {                                                         /* :55-62 HuffmanTable::build_decoder */
+        const uint32_t left = len - off > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(len - off);
+        if (LANE == 0) { uint32_t used = 0, nsym = 0; bc.err = cz_huf_read_and_rank(raw, left, 0, 0, 8, &used, &nsym); bc.huf_nsym = nsym; bc.d0 = used; }
+        __syncthreads();
+        err = cz_unii(bc.err);
+        const uint32_t used = cz_uni((uint32_t)bc.d0), nsym = cz_uni(bc.huf_nsym);
+        __syncthreads();
+        if (!err && used > left) err = CZ_E_DICT_TRUNCATED;             /* (panic) slice :62 */
+        if (!err) {
+            cz_huf_fill(nsym); __syncthreads();
+            cz_huf_fill_multi(); __syncthreads();
+            for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)st->huf)[i] = ((const uint32_t*)sh.a.huf)[i];
+            off += used;
+        }
+        __syncthreads();                                                /* region `a` becomes the T3 scratch of the table builds */
+    }
+    for (int o = 0; o < 3 && !err; o++) {                               /* :64-80: offsets, match lengths, literal lengths */
+        const int t = o == 0 ? 1 : (o == 1 ? 2 : 0);
+        const uint32_t left = len - off > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(len - off);
+        if (LANE == 0) {
+            CzFBits br; br.g = raw + off; br.len = left; br.idx = 0; br.stage = sh.a.t3.stage; br.stage_lo = 0; br.stage_hi = 0;
+            uint32_t np = 0, lg = 0, used = 0;
+            int e = cz_fse_read_probs(br, t == 1 ? 8u : 9u, sh.a.t3.probs[t], &np, &lg, &used, 100);
+            if (!e && used > left) e = CZ_E_DICT_TRUNCATED;
+            if (!e) { cz_fse_build(cz_fse_table(t), sh.a.t3.probs[t], np, lg, sh.a.t3.counters[t], sh.b.c.llml, (uint32_t)t); sh.fse_log[t] = (uint8_t)lg; }
+            bc.err = e; bc.d0 = used;
+        }
+        __syncthreads();
+        err = cz_unii(bc.err); off += cz_uni((uint32_t)bc.d0);
+        __syncthreads();
+    }
+    if (!err && len - off < 12) err = CZ_E_DICT_TRUNCATED;              /* (panic) :81-83 */
+    if (!err) {
+        for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { st->fse[0][i] = CZ_FSE_LL[i]; st->fse[2][i] = CZ_FSE_ML[i]; }
+        for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) st->fse[1][i] = CZ_FSE_OF[i];
+        if (LANE == 0) {
+            for (int k = 0; k < 3; k++) {
+                cz_gcptr q = raw + off + 4 * k;
+                st->hist[k] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);   /* :81-85 */
+                st->fse_rle[k] = -1; st->fse_log[k] = sh.fse_log[k];
+            }
+            st->huf_max_bits = sh.huf_max_bits; st->dict_lag = 0;
+        }
+        off += 12;
+    }
+    if (LANE == 0) { result[0] = (uint64_t)(uint32_t)err; result[1] = off; result[2] = id; result[3] = magic; }
 }
 
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
@@ -1891,6 +1994,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
             io.src = (cz_gcptr)t.src; io.src_len = t.src_len; io.dst = (cz_gptr)t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
             io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
             io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming; io.verify = 0;
+            io.dict = (cz_gcptr)t.dict; io.dict_len = t.dict_len;
             /* restore carried state (the Huffman table stays in t.state->huf until a Treeless block asks for it) */
             cz_device_frame_state* gs = t.state;
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { CZ_FSE_LL[i] = gs->fse[0][i]; CZ_FSE_ML[i] = gs->fse[2][i]; }
@@ -1898,6 +2002,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
             if (LANE == 0) {
                 for (int k = 0; k < 3; k++) { sh.hist[k] = gs->hist[k]; sh.fse_rle[k] = gs->fse_rle[k]; sh.fse_log[k] = gs->fse_log[k]; }
                 sh.huf_max_bits = gs->huf_max_bits;
+                sh.dict_lag[0] = (uint32_t)gs->dict_lag; sh.dict_lag[1] = (uint32_t)(gs->dict_lag >> 32);
             }
             __syncthreads();
             CzLitPass nolit; nolit.arena = nullptr; nolit.cursor = 0; nolit.first = 0; nolit.last_nseq = 0;
@@ -1907,11 +2012,12 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
             if (LANE == 0) {
                 for (int k = 0; k < 3; k++) { gs->hist[k] = sh.hist[k]; gs->fse_rle[k] = sh.fse_rle[k]; gs->fse_log[k] = sh.fse_log[k]; }
                 gs->huf_max_bits = sh.huf_max_bits;
+                gs->dict_lag = ((uint64_t)sh.dict_lag[1] << 32) | sh.dict_lag[0];
             }
         } else {
             io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
-            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum;
+            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum; io.dict = nullptr; io.dict_len = 0;
             cz_state_reset();
             __syncthreads();
             CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0;

@@ -30,6 +30,8 @@ typedef struct cz_device_frame_state {
     int32_t  fse_rle[3];
     uint8_t  fse_log[3];
     uint8_t  huf_max_bits;
+    uint64_t dict_lag;        /* bytes copied by matches that lay wholly in the dictionary: the reference's total_output_counter
+                                 does not count them (decode_buffer.cairo:85-90), and its window test uses that counter */
 } cz_device_frame_state;
 
 /* One unit of work for the resumable path (cz_frame_decoder_*): decode blocks of ONE frame
@@ -43,6 +45,7 @@ typedef struct cz_device_task {
     uint32_t strategy; uint32_t _pad; uint64_t strategy_n;
     uint32_t has_checksum; uint32_t streaming;/* streaming=1: decode_from_to semantics (stop quietly when short) */
     cz_device_frame_state* state;             /* in/out */
+    const uint8_t* dict; uint64_t dict_len;   /* DecodeBuffer.dict_content (decode_buffer.cairo:13): device pointer, 0 = none */
 } cz_device_task;
 
 /* One compressed block that has sequences, as cz_scan_kernel lists it for cz_chain_kernel. */

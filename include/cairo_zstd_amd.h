@@ -202,6 +202,24 @@ int  cz_decoder_scratch_drain(cz_decoder_scratch* s, uint8_t* dst, size_t cap, s
 int  cz_decoder_scratch_drain_to_window_size(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written);
 uint64_t cz_decoder_scratch_hash_digest(const cz_decoder_scratch* s);                              /* buffer.hash.digest(): XXH64 of what was drained */
 
+/* ------------------------------------------------- dictionaries */
+/* Dictionary (src/decoding/dictionary.cairo:11-18).  The reference parses dictionaries and can seed a DecoderScratch from one,
+ * but none of its decoders ever does (frame_decoder.cairo never calls init_from_dict): the same two calls are offered here,
+ * on the block level, and a workspace seeded from a dictionary decodes frames that were compressed with it — Repeat-mode /
+ * Treeless first blocks use the dictionary's tables, repeat offsets start from its three, matches may reach into its content
+ * (decode_buffer.cairo:65-93).  The parsed tables and the content live in HBM. */
+typedef struct cz_dictionary cz_dictionary;
+/* DictionaryTrait::decode_dict (dictionary.cairo:35-91).  Errors: CZ_E_DICT_BAD_MAGIC (detail[0] = the magic read),
+ * CZ_E_DICT_TRUNCATED, or the HuffmanTableError / FSETableError leaf. */
+int  cz_dictionary_decode(cz_context* ctx, const uint8_t* raw, size_t len, cz_dictionary** out, uint64_t* detail);
+void cz_dictionary_destroy(cz_dictionary* d);
+uint32_t cz_dictionary_id(const cz_dictionary* d);                                                 /* Dictionary.id */
+size_t cz_dictionary_content_len(const cz_dictionary* d);                                          /* dict_content.len() */
+int  cz_dictionary_offset_hist(const cz_dictionary* d, uint32_t out[3]);                           /* Dictionary.offset_hist */
+/* DecoderScratchTrait::init_from_dict (scratch.cairo:60-65); call it on a fresh or reset workspace.  reset clears it again
+ * (decode_buffer.cairo:38).  The dictionary must stay alive while the workspace uses it. */
+int  cz_decoder_scratch_init_from_dict(cz_decoder_scratch* workspace, const cz_dictionary* d);
+
 /* BlockDecoder (src/decoding/block_decoder.cairo:20-30): a plain value like the reference's struct. */
 typedef struct cz_block_decoder {
     uint8_t internal_state;       /* DecoderState, block_decoder.cairo:26-30 */

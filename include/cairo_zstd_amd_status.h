@@ -107,6 +107,11 @@ typedef enum cz_status {
     CZ_E_EXEC_NOT_ENOUGH_DICT = 92,     /* NotEnoughBytesInDictionary decode_buffer.cairo:70 */
     CZ_E_EXEC_OFFSET_TOO_BIG = 93,      /* OffsetTooBig               decode_buffer.cairo:92 */
 
+    /* ---- DictionaryDecodeError (src/decoding/dictionary.cairo:20-25); its FSETableError / HuffmanTableError
+            arms report the leaf codes above ---- */
+    CZ_E_DICT_BAD_MAGIC = 95,           /* BadMagicNum                dictionary.cairo:46-48 */
+    CZ_E_DICT_TRUNCATED = 96,           /* (panic) word_u32_le(..).expect at :45,:50,:81-83: shorter than its fixed fields */
+
     /* ---- no reference analogue: batch / device boundary ---- */
     CZ_E_OUTPUT_TOO_SMALL = 900,   /* caller-provided output region cannot hold the frame */
     CZ_E_INVALID_ARG = 901,

@@ -74,6 +74,12 @@ def lib() -> C.CDLL:
         L.czo_fd_decode_from_to.restype = C.c_int
         L.czo_fd_decode_from_to.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.czo_dict_decode.restype = C.c_int
+        L.czo_dict_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), u64p]
+        L.czo_dict_destroy.argtypes = [C.c_void_p]
+        L.czo_dict_info.argtypes = [C.c_void_p, u64p]
+        L.czo_fd_init_from_dict.restype = C.c_int
+        L.czo_fd_init_from_dict.argtypes = [C.c_void_p, C.c_void_p]
         L.czo_kat_reverse_reads.restype = C.c_int
         L.czo_kat_reverse_reads.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, u64p, C.POINTER(C.c_int64)]
         L.czo_kat_forward_reads.restype = C.c_int
@@ -221,3 +227,43 @@ class FrameDecoder:
         st = lib().czo_fd_decode_from_to(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap,
                                          C.byref(r), C.byref(w))
         return st, r.value, out[: w.value].tobytes()
+
+
+class Dictionary:
+    """DictionaryTrait::decode_dict (src/decoding/dictionary.cairo:35-91).  `status` != 0: the parse failed."""
+
+    INFO = ("id", "content_off", "content_len", "hist0", "hist1", "hist2", "huf_max_bits", "ll_log", "ml_log", "of_log")
+
+    def __init__(self, raw):
+        self._raw = _buf(raw)
+        self._h = C.c_void_p()
+        detail = (C.c_uint64 * 2)()
+        self.status = lib().czo_dict_decode(self._raw.ctypes.data, self._raw.size, C.byref(self._h), detail)
+        self.detail = int(detail[0])
+        self.info = {}
+        if self.status == 0:
+            v = (C.c_uint64 * 10)()
+            lib().czo_dict_info(self._h, v)
+            self.info = dict(zip(self.INFO, (int(x) for x in v)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().czo_dict_destroy(self._h)
+            self._h = None
+
+
+def decode_frame_with_dict(src, dictionary: Dictionary, cap: int = 1 << 24):
+    """new -> init_from_dict (scratch.cairo:60-65, the call the reference never makes) -> decode_blocks(All) -> collect.
+    Returns (status, bytes)."""
+    fd = FrameDecoder()
+    st, used, _ = fd.new(src)
+    if st:
+        return st, b""
+    st = lib().czo_fd_init_from_dict(fd._h, dictionary._h)
+    if st:
+        return st, b""
+    a = _buf(src)
+    st, _, _ = fd.decode_blocks(a[used:])
+    if st:
+        return st, b""
+    return 0, fd.collect(cap)

@@ -455,6 +455,7 @@ typedef struct {
     /* DecodeBuffer: bytes [buf_head, buf_len) of `buf` are the live ring content */
     uint8_t* buf; size_t buf_cap; size_t buf_len; size_t buf_head; int buf_owned;
     uint64_t total_output_counter; size_t window_size;
+    const uint8_t* dict_content; size_t dict_len;            /* decode_buffer.cairo:13 (borrowed from the dictionary) */
     xxh64_state hash;
     /* literals + sequences of the current block */
     uint8_t* lit; size_t lit_cap; size_t lit_len;
@@ -471,6 +472,7 @@ static void scratch_reset(scratch* s, size_t window_size) {
     s->offset_hist[0] = 1; s->offset_hist[1] = 4; s->offset_hist[2] = 8;
     s->lit_len = 0; s->nseq = 0;
     s->buf_len = 0; s->buf_head = 0; s->total_output_counter = 0; s->window_size = window_size;
+    s->dict_content = NULL; s->dict_len = 0;                /* decode_buffer.cairo:38 (reset clears dict_content) */
     xxh64_reset(&s->hash, 0);                               /* decode_buffer.cairo:31,41 */
     fse_reset(&s->ll); fse_reset(&s->ml); fse_reset(&s->of);
     s->ll_rle = s->ml_rle = s->of_rle = -1;
@@ -495,10 +497,24 @@ static int buffer_fill(scratch* s, uint8_t byte, size_t n) {            /* block
     int e = buffer_reserve(s, n); if (e) return e;
     memset(s->buf + s->buf_len, byte, n); s->buf_len += n; s->total_output_counter += n; return 0;
 }
-/* decode_buffer.cairo:62-133 (dictionary is always empty: SURVEY.md §2 row 13) */
+/* decode_buffer.cairo:62-133.  The dictionary is empty unless czo_*_with_dict initialised the scratch from one
+   (scratch.cairo:60-65 init_from_dict — present in the reference, called by nothing there). */
 static int buffer_repeat(scratch* s, size_t offset, size_t match_length) {
     if (offset > buffer_len(s)) {                           /* :65 */
-        if (s->total_output_counter <= (uint64_t)s->window_size) return CZ_E_EXEC_NOT_ENOUGH_DICT; /* :66-75: bytes_from_dict>0 > dict len 0 */
+        if (s->total_output_counter <= (uint64_t)s->window_size) {      /* :66 */
+            const size_t bytes_from_dict = offset - buffer_len(s);      /* :67 */
+            if (bytes_from_dict > s->dict_len) return CZ_E_EXEC_NOT_ENOUGH_DICT;     /* :69-75 */
+            if (bytes_from_dict < match_length) {                       /* :77-84 */
+                int e = buffer_reserve(s, bytes_from_dict); if (e) return e;
+                memcpy(s->buf + s->buf_len, s->dict_content + s->dict_len - bytes_from_dict, bytes_from_dict);
+                s->buf_len += bytes_from_dict; s->total_output_counter += bytes_from_dict;
+                return buffer_repeat(s, buffer_len(s), match_length - bytes_from_dict);   /* :84: goes on from the start of the buffer */
+            }
+            int e = buffer_reserve(s, match_length); if (e) return e;   /* :85-90; total_output_counter is NOT advanced here (as written) */
+            memcpy(s->buf + s->buf_len, s->dict_content + s->dict_len - bytes_from_dict, match_length);
+            s->buf_len += match_length;
+            return 0;
+        }
         return CZ_E_EXEC_OFFSET_TOO_BIG;                    /* :92 */
     }
     int e = buffer_reserve(s, match_length); if (e) return e;
@@ -834,6 +850,74 @@ static int fd_init_common(czo_frame_decoder* d, const uint8_t* src, size_t len, 
 }
 CZO_API int czo_fd_new(czo_frame_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init_common(d, src, len, consumed, detail, 0); }
 CZO_API int czo_fd_reset(czo_frame_decoder* d, const uint8_t* src, size_t len, size_t* consumed, uint64_t* detail) { return fd_init_common(d, src, len, consumed, detail, 1); }
+
+/* ------------------------------------------------------------------ dictionaries */
+/* src/decoding/dictionary.cairo:11-18.  The reference parses dictionaries (decode_dict) and can seed a DecoderScratch
+   from one (scratch.cairo:60-65 init_from_dict), but nothing in it calls init_from_dict: czo_fd_init_from_dict is that
+   missing call, made right after new / reset. */
+typedef struct czo_dictionary {
+    uint32_t id; huf_table huf; fse_table ll, ml, of; uint32_t offset_hist[3];
+    uint8_t* raw; size_t raw_len; size_t content_off;
+} czo_dictionary;
+static int fse_copy(fse_table* d, const fse_table* s) {                 /* fse_decoder.cairo:117-123 reinit_from */
+    const size_t n = s->accuracy_log ? (size_t)1 << s->accuracy_log : 0;
+    if (n && fse_reserve(d, n)) return 1;
+    if (n) memcpy(d->decode, s->decode, n * sizeof(fse_entry));
+    d->accuracy_log = s->accuracy_log; memcpy(d->probs, s->probs, sizeof d->probs); d->nprobs = s->nprobs;
+    return 0;
+}
+CZO_API void czo_dict_destroy(czo_dictionary* d) {
+    if (!d) return;
+    fse_free(&d->huf.fse); fse_free(&d->ll); fse_free(&d->ml); fse_free(&d->of); free(d->raw); free(d);
+}
+/* DictionaryTrait::decode_dict (dictionary.cairo:35-91).  detail[0] = the magic number read (BadMagicNum). */
+CZO_API int czo_dict_decode(const uint8_t* raw, size_t len, czo_dictionary** out, uint64_t* detail) {
+    *out = NULL;
+    if (len < 8) return CZ_E_DICT_TRUNCATED;                            /* (panic) :45,:50 */
+    const uint32_t magic = (uint32_t)raw[0] | ((uint32_t)raw[1] << 8) | ((uint32_t)raw[2] << 16) | ((uint32_t)raw[3] << 24);
+    if (detail) detail[0] = magic;
+    if (magic != 0xEC30A437u) return CZ_E_DICT_BAD_MAGIC;               /* :46-48 */
+    czo_dictionary* d = (czo_dictionary*)calloc(1, sizeof *d);
+    if (!d) return CZ_E_INVALID_ARG;
+    d->id = (uint32_t)raw[4] | ((uint32_t)raw[5] << 8) | ((uint32_t)raw[6] << 16) | ((uint32_t)raw[7] << 24);   /* :50-51 */
+    d->offset_hist[0] = 2; d->offset_hist[1] = 4; d->offset_hist[2] = 8;                                       /* :41 */
+    size_t off = 8; int e; uint32_t hb = 0; size_t used = 0;
+    if ((e = huf_build_decoder(&d->huf, raw + off, len - off, &hb))) { czo_dict_destroy(d); return e; }         /* :55-61 */
+    if (hb > len - off) { czo_dict_destroy(d); return CZ_E_DICT_TRUNCATED; }                                    /* (panic) slice :62 */
+    off += hb;
+    if ((e = fse_build_decoder(&d->of, raw + off, len - off, 8, &used)) || used > len - off) { czo_dict_destroy(d); return e ? e : CZ_E_DICT_TRUNCATED; }   /* :64-68 */
+    off += used;
+    if ((e = fse_build_decoder(&d->ml, raw + off, len - off, 9, &used)) || used > len - off) { czo_dict_destroy(d); return e ? e : CZ_E_DICT_TRUNCATED; }   /* :70-74 */
+    off += used;
+    if ((e = fse_build_decoder(&d->ll, raw + off, len - off, 9, &used)) || used > len - off) { czo_dict_destroy(d); return e ? e : CZ_E_DICT_TRUNCATED; }   /* :76-80 */
+    off += used;
+    if (len - off < 12) { czo_dict_destroy(d); return CZ_E_DICT_TRUNCATED; }                                    /* (panic) :81-83 */
+    for (int k = 0; k < 3; k++) { const uint8_t* q = raw + off + 4 * k; d->offset_hist[k] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); }   /* :81-85 */
+    off += 12;
+    d->raw = (uint8_t*)malloc(len ? len : 1);
+    if (!d->raw) { czo_dict_destroy(d); return CZ_E_INVALID_ARG; }
+    memcpy(d->raw, raw, len); d->raw_len = len; d->content_off = off;                                           /* :87-88 */
+    *out = d; return 0;
+}
+/* info: id, content offset, content length, offset_hist[0..2], Huffman max bits, LL / ML / OF accuracy logs */
+CZO_API void czo_dict_info(const czo_dictionary* d, uint64_t info[10]) {
+    info[0] = d->id; info[1] = d->content_off; info[2] = d->raw_len - d->content_off;
+    info[3] = d->offset_hist[0]; info[4] = d->offset_hist[1]; info[5] = d->offset_hist[2];
+    info[6] = d->huf.max_num_bits; info[7] = d->ll.accuracy_log; info[8] = d->ml.accuracy_log; info[9] = d->of.accuracy_log;
+}
+/* DecoderScratchTrait::init_from_dict (scratch.cairo:60-65) */
+static int scratch_init_from_dict(scratch* s, const czo_dictionary* d) {
+    if (fse_copy(&s->ll, &d->ll) || fse_copy(&s->ml, &d->ml) || fse_copy(&s->of, &d->of)) return CZ_E_INVALID_ARG;
+    s->ll_rle = s->ml_rle = s->of_rle = -1;                             /* scratch.cairo:104-106: the dictionary's are None */
+    memcpy(s->huf.decode, d->huf.decode, sizeof s->huf.decode);        /* huff0_decoder.cairo:129-137 reinit_from */
+    memcpy(s->huf.weights, d->huf.weights, sizeof s->huf.weights); s->huf.nweights = d->huf.nweights;
+    s->huf.max_num_bits = d->huf.max_num_bits;
+    if (fse_copy(&s->huf.fse, &d->huf.fse)) return CZ_E_INVALID_ARG;
+    memcpy(s->offset_hist, d->offset_hist, sizeof s->offset_hist);
+    s->dict_content = d->raw + d->content_off; s->dict_len = d->raw_len - d->content_off;
+    return 0;
+}
+CZO_API int czo_fd_init_from_dict(czo_frame_decoder* d, const czo_dictionary* dict) { return scratch_init_from_dict(&d->sc, dict); }
 
 CZO_API uint64_t czo_fd_content_size(const czo_frame_decoder* d) { return d->fh.frame_content_size; }          /* :125 */
 CZO_API int czo_fd_checksum_from_data(const czo_frame_decoder* d, uint32_t* v) { if (d->has_check_sum) *v = d->check_sum; return d->has_check_sum; } /* :129 */

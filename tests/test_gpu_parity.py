@@ -593,3 +593,72 @@ def test_bench_two_ranks_spawned_by_gpus_flag(cz):
     assert line["n_gpus"] == 2 and line["bit_exact"] is True and line["config"]["frames_total"] == 600
     assert "dealt by algorithmic bytes" in line["config"]["parallelism"]
     assert line["with_gather_to_rank0"]["ms_per_step"] >= line["ms_per_step"] * 0.5 and line["with_gather_to_rank0"]["gathered_bytes_per_step"] > 0
+
+
+# ---------------------------------------------------------------- dictionaries
+def _dict_fixture():
+    import glob
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+    raw = open(os.path.join(d, "dict.bin"), "rb").read()
+    frames = [(os.path.basename(z), open(z, "rb").read(), open(z[:-4] + ".orig", "rb").read()) for z in sorted(glob.glob(os.path.join(d, "frame_*.zst")))]
+    return raw, frames
+
+
+def test_dictionary_decode_dict_matches_oracle(cz, ctx):
+    """DictionaryTrait::decode_dict (src/decoding/dictionary.cairo:35-91) on the device against the oracle: fields of the
+    trained dictionary, and the same status for every way of cutting or corrupting it."""
+    raw, _ = _dict_fixture()
+    od = oracle.Dictionary(raw)
+    assert od.status == 0
+    gd = cz.Dictionary(ctx, raw)
+    assert gd.id == od.info["id"] and gd.content_len == od.info["content_len"]
+    assert gd.offset_hist == (od.info["hist0"], od.info["hist1"], od.info["hist2"])
+    gd.close()
+    rng = np.random.default_rng(7)
+    muts = [raw[:n] for n in (0, 3, 7, 8, 9, 20, 40, 60, 90, od.info["content_off"] - 13, od.info["content_off"] - 1, od.info["content_off"])]
+    for _ in range(40):
+        a = bytearray(raw)
+        a[int(rng.integers(0, od.info["content_off"]))] ^= 1 << int(rng.integers(0, 8))
+        muts.append(bytes(a))
+    for m in muts:
+        want = oracle.Dictionary(m).status
+        try:
+            g = cz.Dictionary(ctx, m)
+            got = 0
+            g.close()
+        except cz.CzError as e:
+            got = e.code
+        if got == cz.status.CZ_E_UNSUPPORTED:                            # D2: Huffman-weight FSE log above 9
+            continue
+        assert got == want, f"len {len(m)}: device {cz.status.name(got)} oracle {cz.status.name(want)}"
+
+
+def test_frames_compressed_with_a_dictionary(cz, ctx):
+    """A workspace seeded with init_from_dict (src/decoding/scratch.cairo:60-65) decodes frames made by
+    ZSTD_compress_usingDict block by block: the first block repeats the dictionary's tables, repeat offsets start from its
+    three, matches reach into its content (src/decoding/decode_buffer.cairo:65-93).  Bit-exact with the originals (which
+    libzstd's ZSTD_decompress_usingDict reproduced when the fixtures were made) and with the oracle; corrupted frames give
+    the oracle's status."""
+    raw, frames = _dict_fixture()
+    od, gd = oracle.Dictionary(raw), cz.Dictionary(ctx, raw)
+    for name, z, orig in frames:
+        assert cz.decode_frame_with_dict(z, gd, ctx) == orig, name
+    rng = np.random.default_rng(11)
+    checked = 0
+    for name, z, orig in frames[:6]:
+        for _ in range(12):
+            a = bytearray(z)
+            a[int(rng.integers(6, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            want, wout = oracle.decode_frame_with_dict(bytes(a), od, cap=len(orig) * 4 + 4096)
+            try:
+                gout, got = cz.decode_frame_with_dict(bytes(a), gd, ctx), 0
+            except cz.CzError as e:
+                gout, got = None, e.code
+            if got in (cz.status.CZ_E_UNSUPPORTED, cz.status.CZ_E_OUTPUT_TOO_SMALL) or want == cz.status.CZ_E_OUTPUT_TOO_SMALL:
+                continue
+            assert got == want, f"{name}: device {cz.status.name(got)} oracle {cz.status.name(want)}"
+            if got == 0:
+                assert gout == wout, name
+            checked += 1
+    assert checked > 40
+    gd.close()

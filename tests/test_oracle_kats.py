@@ -16,6 +16,7 @@ import pytest
 
 import oracle
 from conftest import GOLDEN, REFERENCE_CORPUS
+from cairo_zstd_amd import status
 
 CONST16 = bytes.fromhex("C141080000ECC8964279D4BCF72CD548")  # ba.append_word(0xC141..., 16): big-endian bytes
 
@@ -238,3 +239,49 @@ def test_oracle_accepts_huffman_weight_fse_log_10():
     z, want = open(os.path.join(d, "d2_weight_log10.zst"), "rb").read(), open(os.path.join(d, "d2_weight_log10"), "rb").read()
     st, out, _ = oracle.decode_frame(z, cap=64)
     assert st == 0 and out == want
+
+
+# ---------------------------------------------------------------- dictionaries
+DICT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+
+
+def _dict_cases():
+    import glob
+    raw = open(os.path.join(DICT_DIR, "dict.bin"), "rb").read()
+    frames = []
+    for z in sorted(glob.glob(os.path.join(DICT_DIR, "frame_*.zst"))):
+        frames.append((os.path.basename(z), open(z, "rb").read(), open(z[:-4] + ".orig", "rb").read()))
+    return raw, frames
+
+
+def test_oracle_dictionary_decode_dict_fields():
+    """DictionaryTrait::decode_dict (src/decoding/dictionary.cairo:35-91) on the committed trained dictionary
+    (scripts/gen_dict_vectors.py): magic, id, four tables, three repeat offsets, content."""
+    raw, _ = _dict_cases()
+    d = oracle.Dictionary(raw)
+    assert d.status == 0
+    assert d.info["id"] == int.from_bytes(raw[4:8], "little")
+    assert d.info["content_off"] + d.info["content_len"] == len(raw) and d.info["content_len"] > 0
+    assert (d.info["hist0"], d.info["hist1"], d.info["hist2"]) == tuple(
+        int.from_bytes(raw[d.info["content_off"] - 12 + 4 * k: d.info["content_off"] - 8 + 4 * k], "little") for k in range(3))
+    assert 1 <= d.info["huf_max_bits"] <= 11 and d.info["ll_log"] <= 9 and d.info["ml_log"] <= 9 and d.info["of_log"] <= 8
+    bad = bytearray(raw); bad[0] ^= 1
+    e = oracle.Dictionary(bytes(bad))
+    assert e.status == status.CZ_E_DICT_BAD_MAGIC and e.detail == int.from_bytes(bad[0:4], "little")
+    assert oracle.Dictionary(raw[:7]).status == status.CZ_E_DICT_TRUNCATED
+    assert oracle.Dictionary(raw[: d.info["content_off"] - 5]).status == status.CZ_E_DICT_TRUNCATED
+    assert oracle.Dictionary(raw[:40]).status != 0                       # inside the tables: a table error or a truncation
+
+
+def test_oracle_decodes_frames_compressed_with_a_dictionary():
+    """init_from_dict (src/decoding/scratch.cairo:60-65) + the dictionary arm of DecodeBuffer::repeat
+    (src/decoding/decode_buffer.cairo:65-93): frames made by libzstd's ZSTD_compress_usingDict decode to their originals;
+    without the dictionary the same frames fail the way the reference does."""
+    raw, frames = _dict_cases()
+    d = oracle.Dictionary(raw)
+    assert d.status == 0
+    for name, z, orig in frames:
+        st, out = oracle.decode_frame_with_dict(z, d, cap=len(orig) + 64)
+        assert st == 0 and out == orig, name
+        st2 = oracle.decode_frame(z, cap=len(orig) + 64)[0]
+        assert st2 != 0, f"{name} decodes without its dictionary"
