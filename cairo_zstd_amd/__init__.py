@@ -74,6 +74,13 @@ class Context:
         """Compute and compare the XXH64 content checksum of every checksummed frame on the device."""
         lib().cz_context_set_verify_checksum(self._h, 1 if on else 0)
 
+    def set_dictionary(self, dictionary: "Dictionary | None"):
+        """Batch decodes start every frame from `dictionary` (None: from nothing): init_from_dict, src/decoding/scratch.cairo:60-65."""
+        self._dict = dictionary
+        st = lib().cz_context_set_dictionary(self._h, dictionary._h if dictionary is not None else None)
+        if st:
+            raise CzError(st, "cz_context_set_dictionary")
+
     def last_chain_ms(self) -> float:
         """Milliseconds of the last launch spent in the FSE-chain pre-pass kernel (0 when it is off)."""
         ms = C.c_float(0)

@@ -167,6 +167,8 @@ def lib() -> C.CDLL:
             L.cz_dictionary_content_len.argtypes = [vp]
             L.cz_dictionary_offset_hist.restype = C.c_int
             L.cz_dictionary_offset_hist.argtypes = [vp, C.POINTER(C.c_uint32)]
+            L.cz_context_set_dictionary.restype = C.c_int
+            L.cz_context_set_dictionary.argtypes = [vp, vp]
             L.cz_decoder_scratch_init_from_dict.restype = C.c_int
             L.cz_decoder_scratch_init_from_dict.argtypes = [vp, vp]
         L.cz_frame_decoder_scratch.restype = vp

@@ -28,11 +28,20 @@
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
 
 /* ------------------------------------------------------------------ context */
+/* Dictionary (src/decoding/dictionary.cairo:11-18): the raw bytes and the carried-state image decode_dict makes of them, both
+ * in HBM.  The tables are built by cz_dict_setup_kernel with the decoder's own builders. */
+struct cz_dictionary {
+    struct cz_context* ctx = nullptr;
+    uint8_t* d_raw = nullptr; size_t len = 0; size_t content_off = 0;
+    cz_device_frame_state* d_state = nullptr;
+    uint32_t id = 0; uint32_t hist[3] = {0, 0, 0};
+};
 struct cz_context {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     int num_cu = 0, occupancy = 0, grid_max = 0;
     uint8_t* lit_scratch = nullptr; int lit_slots = 0; uint32_t* work_counter = nullptr;
+    const struct cz_dictionary* batch_dict = nullptr;                   /* cz_context_set_dictionary */
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
     bool exec_kernel = false;              /* frames with chain records run on cz_exec_frames_kernel (one workgroup per CU); off by default:
                                               measured slower than the one-wave record path, DESIGN.md §5 */
@@ -283,6 +292,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
     a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum;
+    if (!a.tasks && c->batch_dict) { a.dict_state = c->batch_dict->d_state; a.dict = c->batch_dict->d_raw + c->batch_dict->content_off; a.dict_len = c->batch_dict->len - c->batch_dict->content_off; }
     int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
 #ifdef CZ_EXPERIMENT
     if (const char* e = getenv("CZ_GRID_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < grid) grid = g; }
@@ -568,14 +578,6 @@ struct Xxh64 {
  * decoded frame stays in HBM; `drained` marks how much the host already collected (buffer.len() == produced - drained)
  * and `base_off` how many leading frame bytes were dropped from the resident buffer (only drained bytes are ever
  * dropped, and a match can only reach bytes that are still in the buffer, decode_buffer.cairo:65). */
-/* Dictionary (src/decoding/dictionary.cairo:11-18): the raw bytes and the carried-state image decode_dict makes of them, both
- * in HBM.  The tables are built by cz_dict_setup_kernel with the decoder's own builders. */
-struct cz_dictionary {
-    cz_context* ctx = nullptr;
-    uint8_t* d_raw = nullptr; size_t len = 0; size_t content_off = 0;
-    cz_device_frame_state* d_state = nullptr;
-    uint32_t id = 0; uint32_t hist[3] = {0, 0, 0};
-};
 struct cz_decoder_scratch {
     cz_context* ctx = nullptr;
     uint64_t window_size = 0;
@@ -659,6 +661,14 @@ CZ_EXPORT void cz_dictionary_destroy(cz_dictionary* d) {
     if (d->d_raw) (void)hipFree(d->d_raw);
     if (d->d_state) (void)hipFree(d->d_state);
     delete d;
+}
+/* Batch decodes of this context start every frame from `d` (NULL: from nothing, the default). */
+CZ_EXPORT int cz_context_set_dictionary(cz_context* c, const cz_dictionary* d) {
+    if (!c || (d && d->ctx != c)) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->batch_dict = d;
+    return CZ_OK;
 }
 CZ_EXPORT uint32_t cz_dictionary_id(const cz_dictionary* d) { return d ? d->id : 0; }
 CZ_EXPORT size_t cz_dictionary_content_len(const cz_dictionary* d) { return d ? d->len - d->content_off : 0; }

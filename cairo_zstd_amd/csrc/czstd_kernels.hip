@@ -2017,8 +2017,21 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
         } else {
             io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
-            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum; io.dict = nullptr; io.dict_len = 0;
+            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum; io.dict = (cz_gcptr)a.dict; io.dict_len = a.dict_len;
             cz_state_reset();
+            if (a.dict_state) {
+                /* every frame of the batch starts as DecoderScratch::init_from_dict leaves a workspace (scratch.cairo:60-65):
+                   the dictionary's tables and repeat offsets; its Huffman table goes to this workgroup's carried-table slot */
+                CZ_GLOBAL const cz_device_frame_state* ds = (CZ_GLOBAL const cz_device_frame_state*)a.dict_state;
+                __syncthreads();
+                for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { CZ_FSE_LL[i] = ds->fse[0][i]; CZ_FSE_ML[i] = ds->fse[2][i]; }
+                for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) CZ_FSE_OF[i] = ds->fse[1][i];
+                for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)(lit_scratch + CZ_LIT_SCRATCH_BYTES))[i] = ((CZ_GLOBAL const uint32_t*)ds->huf)[i];
+                if (LANE == 0) {
+                    for (int k = 0; k < 3; k++) { sh.hist[k] = ds->hist[k]; sh.fse_rle[k] = ds->fse_rle[k]; sh.fse_log[k] = ds->fse_log[k]; }
+                    sh.huf_max_bits = ds->huf_max_bits;
+                }
+            }
             __syncthreads();
             CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0;
             lp.cursor = a.lit_arena ? cz_uni64(a.lit_first[f]) : 0;

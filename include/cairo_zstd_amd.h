@@ -219,6 +219,11 @@ int  cz_dictionary_offset_hist(const cz_dictionary* d, uint32_t out[3]);        
 /* DecoderScratchTrait::init_from_dict (scratch.cairo:60-65); call it on a fresh or reset workspace.  reset clears it again
  * (decode_buffer.cairo:38).  The dictionary must stay alive while the workspace uses it. */
 int  cz_decoder_scratch_init_from_dict(cz_decoder_scratch* workspace, const cz_dictionary* d);
+/* The batch form of the same call: every frame cz_decode_batch_* decodes on this context starts as init_from_dict leaves a
+ * workspace (NULL: back to the default, no dictionary).  This is the many-small-records case dictionaries exist for; frames
+ * whose first block leans on the dictionary's tables are decoded by cz_decode_frames_kernel alone (the pre-pass lists only
+ * frames that define their own tables), the others take the pre-pass as usual.  The dictionary must outlive the launches. */
+int  cz_context_set_dictionary(cz_context* ctx, const cz_dictionary* d);
 
 /* BlockDecoder (src/decoding/block_decoder.cairo:20-30): a plain value like the reference's struct. */
 typedef struct cz_block_decoder {

@@ -662,3 +662,29 @@ def test_frames_compressed_with_a_dictionary(cz, ctx):
             checked += 1
     assert checked > 40
     gd.close()
+
+
+@pytest.mark.parametrize("prepass", [False, True])
+def test_batch_decode_with_a_context_dictionary(cz, ctx, prepass):
+    """cz_context_set_dictionary: one launch decodes many frames that share a dictionary (each starts as init_from_dict
+    leaves a workspace), with and without the pre-pass; afterwards the context decodes ordinary frames again."""
+    raw, frames = _dict_fixture()
+    gd = cz.Dictionary(ctx, raw)
+    zs = [z for _, z, _ in frames] * 5
+    origs = [o for _, _, o in frames] * 5
+    ctx.set_chain_arena((sum(len(z) for z in zs) * 8 + (8 << 20)) if prepass else 0)
+    ctx.set_literal_arena((sum(len(o) for o in origs) + (4 << 20)) if prepass else 0)
+    ctx.set_dictionary(gd)
+    try:
+        got = cz.decode_batch_host(zs, [len(o) + 32 for o in origs], ctx)
+        for i, ((r, out), orig) in enumerate(zip(got, origs)):
+            assert int(r["status"]) == 0, f"frame {i}: {cz.status.name(r['status'])}"
+            assert out == orig, f"frame {i}"
+    finally:
+        ctx.set_dictionary(None)
+        ctx.set_chain_arena(0)
+        ctx.set_literal_arena(0)
+    pairs = corpus_pairs()[:8]
+    for (name, z, orig), (r, out) in zip(pairs, cz.decode_batch_host([z for _, z, _ in pairs], [len(o) + 32 for _, _, o in pairs], ctx)):
+        assert int(r["status"]) == 0 and out == orig, name
+    gd.close()
