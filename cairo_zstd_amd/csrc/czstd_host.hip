@@ -350,15 +350,6 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             const int lgrid = (int)(n < lmax ? n : lmax);
             hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(lgrid), dim3(CZ_WG_THREADS), 0, c->stream2, l);
             CZ_HIP(c, hipGetLastError());
-            /* ... and, behind the chain kernel on the main stream, more workgroups for the same work list: on batches
-               whose literals take longer than their chains the first launch (sized to leave the chain kernel its LDS)
-               would otherwise finish alone; when it is already done they find the list empty and exit */
-            const int hgrid = c->lit_slots - lgrid < (int)n ? c->lit_slots - lgrid : (int)n;
-            if (hgrid > 0) {
-                cz_batch_args h = l; h.lit_slot_base = (uint32_t)lgrid;
-                hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(hgrid), dim3(CZ_WG_THREADS), 0, c->stream, h);
-                CZ_HIP(c, hipGetLastError());
-            }
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
             CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* chain kernel done AND literals pass done */

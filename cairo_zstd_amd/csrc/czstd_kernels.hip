@@ -1966,7 +1966,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_decode_frames_kernel(cz_batch_args a) {
     cz_init_llml();
-    cz_gptr lit_scratch = (cz_gptr)(a.lit_scratch + (uint64_t)(a.lit_slot_base + blockIdx.x) * a.lit_scratch_stride);
+    cz_gptr lit_scratch = (cz_gptr)(a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride);
 #ifdef CZ_PROFILE
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
 #endif

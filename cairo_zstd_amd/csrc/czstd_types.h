@@ -72,7 +72,6 @@ typedef struct cz_batch_args {
     uint32_t* work_counter;                   /* zeroed before every launch */
     uint8_t* lit_scratch; uint64_t lit_scratch_stride;   /* one region per resident workgroup */
     const cz_device_frame_state* dict_state; const uint8_t* dict; uint64_t dict_len;   /* batch frames start from this dictionary (cz_context_set_dictionary) */
-    uint32_t lit_slot_base;                              /* region of workgroup b = lit_slot_base + b (two launches that run side by side) */
     unsigned long long* prof;                 /* diagnostic build only: per-phase cycle sums (NULL otherwise) */
     /* optional FSE-chain pre-pass (cz_chain_kernel): NULL / 0 = disabled.  arena[] is in 8-byte units:
        per block {status|nseq<<32, bitstream_off, next header index, 0} then nseq records
