@@ -7,7 +7,8 @@ f=glob.glob('gpurun_out/r2/kt_mix/**/*kernel_trace.csv',recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f)) if r['Kernel_Name'].startswith('cz_')]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 t0=None
-for r in rows[-6:]:
+last_scan = max(i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("cz_scan_kernel") and (i == 0 or not rows[i - 1]["Kernel_Name"].startswith("cz_scan_kernel")))
+for r in rows[last_scan:]:
     s,e=int(r['Start_Timestamp']),int(r['End_Timestamp'])
     if t0 is None: t0=s
     print(f"{r['Kernel_Name'][:28]:28s} start {(s-t0)/1e6:8.3f} ms  dur {(e-s)/1e6:8.3f} ms")
