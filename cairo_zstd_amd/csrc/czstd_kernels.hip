@@ -117,6 +117,8 @@ struct CzShared {
     CzBroadcast bc;
     uint32_t frame_idx;
     uint32_t dict_lag[2];               /* cz_device_frame_state.dict_lag of the frame in flight (lo, hi) */
+    uint32_t dict_ptr[2], dict_len[2];  /* DecodeBuffer.dict_content of the frame in flight: kept here, not in registers — only the rare
+                                           dictionary arm of the match copy reads them */
 #ifdef CZ_PROFILE
     unsigned long long prof[CZ_P_COUNT];
 #endif
@@ -914,9 +916,12 @@ struct CzExecCtx {
     uint64_t drained;        /* bytes drained by the host (buffer.len = produced - drained) */
     uint64_t window;
     uint32_t lit_used;
-    cz_gcptr dict; uint64_t dict_len;   /* DecodeBuffer.dict_content: logically just before the first resident byte (position `drained`) */
-    uint64_t lag;            /* see cz_device_frame_state.dict_lag */
 };
+/* DecodeBuffer.dict_content (logically just before the first resident byte, position `drained`) and the lag of the reference's
+   total_output_counter (cz_device_frame_state.dict_lag) live in LDS */
+__device__ static inline uint64_t cz_dict_len() { return ((uint64_t)sh.dict_len[1] << 32) | sh.dict_len[0]; }
+__device__ static inline cz_gcptr cz_dict_ptr() { return (cz_gcptr)(uintptr_t)(((uint64_t)sh.dict_ptr[1] << 32) | sh.dict_ptr[0]); }
+__device__ static inline uint64_t cz_dict_lag() { return ((uint64_t)sh.dict_lag[1] << 32) | sh.dict_lag[0]; }
 
 /* 16 bytes at s when the whole load lies inside the buffer (`whole`), else the first m bytes one by one */
 __device__ static inline uint4 cz_load_upto16(cz_gcptr s, uint32_t m, int whole) {
@@ -989,9 +994,9 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
     int dictm = 0;
     if (__ballot(reach)) {
         const uint64_t bfd = reach ? (uint64_t)off - (dst - x.drained) : 0;                         /* bytes_from_dict :67 */
-        const int cand = reach && bfd <= x.dict_len;
+        const int cand = reach && bfd <= cz_dict_len();
         const uint32_t lag_lane = cand && bfd >= ml ? ml : 0u;                                      /* :85-90 */
-        const uint64_t lag_before = x.lag + (cz_wave_incl_scan(lag_lane) - lag_lane);
+        const uint64_t lag_before = cz_dict_lag() + (cz_wave_incl_scan(lag_lane) - lag_lane);
         if (reach) {
             if (dst - lag_before > x.window) e = CZ_E_EXEC_OFFSET_TOO_BIG;                          /* :92 */
             else if (!cand) e = CZ_E_EXEC_NOT_ENOUGH_DICT;                                          /* :69-75 */
@@ -1152,7 +1157,10 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
     if (p.err < 0) {
         const uint64_t bfd = dictm ? (uint64_t)off - (dst - x.drained) : 0;
         const uint32_t lag_lane = dictm && bfd >= ml ? ml : 0u;
-        x.lag += cz_readlane(cz_wave_incl_scan(lag_lane), 63);
+        const uint64_t lag = cz_dict_lag() + cz_readlane(cz_wave_incl_scan(lag_lane), 63);
+        cz_wave_sync();
+        if (LANE == 0) { sh.dict_lag[0] = (uint32_t)lag; sh.dict_lag[1] = (uint32_t)(lag >> 32); }
+        cz_wave_sync();
     }
     const uint64_t src = dst - off;
     const uint64_t src_end = (src + ml < dst) ? src + ml : dst;
@@ -1163,7 +1171,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         const uint64_t W = ((uint64_t)__shfl((uint32_t)(dst >> 32), f) << 32) | __shfl((uint32_t)dst, f);
         if (dictm && !done && LANE == f) {
             const uint64_t bfd = (uint64_t)off - (dst - x.drained);
-            cz_gptr d = (cz_gptr)x.out + dst; cz_gcptr dc = x.dict + (x.dict_len - bfd); cz_gcptr head = (cz_gcptr)x.out + x.drained;
+            cz_gptr d = (cz_gptr)x.out + dst; cz_gcptr dc = cz_dict_ptr() + (cz_dict_len() - bfd); cz_gcptr head = (cz_gcptr)x.out + x.drained;
             for (uint32_t k = 0; k < ml; k++) d[k] = k < bfd ? dc[k] : head[k - bfd];
             done = 1;
         }
@@ -1575,9 +1583,8 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref
     CzExecCtx x = xref;
     x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
     x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
-    x.dict = (cz_gcptr)cz_uni64((uint64_t)x.dict); x.dict_len = cz_uni64(x.dict_len); x.lag = cz_uni64(x.lag);
     const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags, bits);
-    xref.produced = x.produced; xref.lit_used = x.lit_used; xref.lag = x.lag;
+    xref.produced = x.produced; xref.lit_used = x.lit_used;
     return e;
 }
 
@@ -1778,7 +1785,8 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         __syncthreads();
     }
     CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
-    x.dict = io.dict; x.dict_len = io.dict_len; x.lag = ((uint64_t)cz_uni(sh.dict_lag[1]) << 32) | cz_uni(sh.dict_lag[0]);
+    if (LANE == 0) { sh.dict_ptr[0] = (uint32_t)(uintptr_t)io.dict; sh.dict_ptr[1] = (uint32_t)((uint64_t)(uintptr_t)io.dict >> 32); sh.dict_len[0] = (uint32_t)io.dict_len; sh.dict_len[1] = (uint32_t)(io.dict_len >> 32); }
+    __syncthreads();
     const uint64_t produced0 = io.produced;
     while (!err) {
         /* block header (block_decoder.cairo:237-321) */
@@ -1848,7 +1856,6 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         res->checksum_from_data = cksum; res->flags = flags; res->calculated_checksum = calc; res->reserved = 0;
         res->detail[0] = io.parse_header && (err == CZ_E_FH_SKIP_FRAME || err == CZ_E_FH_BAD_MAGIC) ? bc.d0 : blocks;
         res->detail[1] = io.parse_header && err == CZ_E_FH_SKIP_FRAME ? bc.d1 : pos;
-        sh.dict_lag[0] = (uint32_t)x.lag; sh.dict_lag[1] = (uint32_t)(x.lag >> 32);
     }
     __syncthreads();
 }
@@ -1866,7 +1873,7 @@ __device__ static uint64_t cz_run_frame_literals(const cz_batch_args& a, cz_gcpt
     uint64_t pos = cz_uni(bc.hdr_len);
     __syncthreads();
     if (err) return 0;
-    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0; x.dict = nullptr; x.dict_len = 0; x.lag = 0;
+    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0;
     CzLitPass lp; lp.arena = nullptr; lp.cursor = 0; lp.first = 0; lp.last_nseq = 0;
     uint64_t no_chain = 0; int seen_seq = 0;
     for (;;) {
