@@ -1262,12 +1262,9 @@ __device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) {
 /* Repeat-offset history (sequence_execution.cairo:85-129) for up to 64 sequences, one per lane, by a
  * DPP wave scan.  Every transform either permutes the three history slots or pushes an offset in
  * front, so after any prefix of sequences a slot holds either what one of the three slots held at
- * the start of the chunk or the offset pushed by some lane.  A transform is two packed words:
- *   T byte k = 0,1,2   slot k holds what slot T_k held before
- *            = 4 + k   slot k holds the offset pushed by lane (V byte k)
- * Composing "P, then Q" is then two byte permutes with Q's T as the selector (v_perm_b32: selector
- * 0..3 picks a byte of P, 4..7 a byte of Q), plus moving a "pushed" marker that came from P's slot j
- * to its new slot k.  The one transform that is not of this kind, offset_value 3 with no literals,
+ * the start of the chunk or the offset pushed by some lane.  A transform is one packed word (see below);
+ * composing "P, then Q" is a byte permute with Q's word as the selector.
+ * The one transform that is not of this kind, offset_value 3 with no literals,
  * pushes h0 - 1: it scans as a push, and the few such values of a chunk are filled in afterwards in
  * lane order (each needs only slot 0 before its lane).  Advances the uniform history (h0,h1,h2) and
  * returns the lane's actual offset = slot 0 after its own transform. */
@@ -1276,17 +1273,21 @@ __device__ static inline uint32_t cz_pick3(uint32_t k, uint32_t a0, uint32_t a1,
 __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t ov, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     const int active = (uint32_t)LANE < cnt;
     const int dec = active && ov == 3 && ll == 0;
-    uint32_t T, V;
+    /* A transform is ONE packed word T (byte k = slot k): 0,1,2 = the slot holds what slot T_k held before, 0x80 | lane = it
+       holds the offset pushed by that lane; M = 0xFF in the bytes of T that are "pushed".  "P, then Q": v_perm_b32 with Q's T
+       as the selector picks P's byte for 0..2 and yields the constant 0xFF for a selector byte >= 13 — which is exactly the
+       new M for Q's own pushes, and in T those bytes are put back from Q with one v_bfi.  Five instructions per scan step. */
+    uint32_t T, M;
     {
         /* 0 keep, 1 swap h0/h1, 2 rotate h2 to the front, 3 push — selected on single bits (no branches) */
         const uint32_t kind = !active ? 0u : (ov > 3 ? 3u : ov - (ll > 0 ? 1u : 0u));
-        const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? 0x00010004u : 0x00010002u;
+        const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? (0x00010080u | (uint32_t)LANE) : 0x00010002u;
         T = (kind & 2u) ? t23 : t01;
-        V = (uint32_t)LANE;                                             /* only read where T says "pushed" */
+        M = kind == 3u ? 0xFFu : 0u;
     }
-#define CZ_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pV = cz_dpp<CTRL, RM>(0u, V); \
-        const uint32_t R = __builtin_amdgcn_perm(T, pT, T); V = __builtin_amdgcn_perm(V, pV, T); \
-        const uint32_t m = ((R >> 2) & 0x00010101u) * 0xFFu; T = (0x00060504u & m) | (R & ~m); } while (0)
+#define CZ_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pM = cz_dpp<CTRL, RM>(0u, M); \
+        const uint32_t R = __builtin_amdgcn_perm(T, pT, T); const uint32_t Mn = __builtin_amdgcn_perm(M, pM, T); \
+        T = (T & M) | (R & ~M); M = Mn; } while (0)
     CZ_HT_STEP(CZ_DPP_SHR1, 0xF); CZ_HT_STEP(CZ_DPP_SHR2, 0xF); CZ_HT_STEP(CZ_DPP_SHR4, 0xF); CZ_HT_STEP(CZ_DPP_SHR8, 0xF);
     CZ_HT_STEP(CZ_DPP_BCAST15, 0xA); CZ_HT_STEP(CZ_DPP_BCAST31, 0xC);
 #undef CZ_HT_STEP
@@ -1294,24 +1295,24 @@ __device__ static inline uint32_t cz_history(uint32_t cnt, uint32_t ll, uint32_t
     uint32_t pv = ov - 3;
     const unsigned long long dm = __ballot(dec);
     if (dm) {
-        const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T), eV = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0u, V);   /* transform of everything before the lane */
+        const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T);      /* transform of everything before the lane */
         for (unsigned long long m = dm; m; m &= m - 1) {
             const int j = cz_unii(__ffsll((long long)m) - 1);
-            const uint32_t bT = cz_readlane(eT, j) & 0xFFu, bV = cz_readlane(eV, j) & 63u;
-            const uint32_t r = (bT & 4u) ? cz_readlane(pv, cz_unii((int)bV)) : cz_pick3(bT, h0, h1, h2);
+            const uint32_t bT = cz_readlane(eT, j) & 0xFFu;
+            const uint32_t r = (bT & 0x80u) ? cz_readlane(pv, cz_unii((int)(bT & 63u))) : cz_pick3(bT & 3u, h0, h1, h2);
             if (LANE == j) pv = r - 1;
         }
     }
-    const uint32_t pushed = __shfl(pv, (int)(V & 63u));                 /* every lane takes part */
-    const uint32_t actual = (T & 4u) ? pushed : cz_pick3(T & 3u, h0, h1, h2);
+    const uint32_t pushed = __shfl(pv, (int)(T & 63u));                 /* every lane takes part */
+    const uint32_t actual = (T & 0x80u) ? pushed : cz_pick3(T & 3u, h0, h1, h2);
     const int lastl = cz_unii((int)cnt - 1);
-    const uint32_t fT = cz_readlane(T, lastl), fV = cz_readlane(V, lastl);
+    const uint32_t fT = cz_readlane(T, lastl);
     uint32_t n[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const uint32_t tk = (fT >> (8 * k)) & 0xFFu, vk = (fV >> (8 * k)) & 63u;
-        const uint32_t pk = cz_readlane(pv, cz_unii((int)vk));
-        n[k] = (tk & 4u) ? pk : cz_pick3(tk & 3u, h0, h1, h2);
+        const uint32_t tk = (fT >> (8 * k)) & 0xFFu;
+        const uint32_t pk = cz_readlane(pv, cz_unii((int)(tk & 63u)));
+        n[k] = (tk & 0x80u) ? pk : cz_pick3(tk & 3u, h0, h1, h2);
     }
     h0 = cz_uni(n[0]); h1 = cz_uni(n[1]); h2 = cz_uni(n[2]);
     return actual;
@@ -1547,7 +1548,11 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
                 ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
             }
         }
+#ifdef CZ_EXP_NOHIST   /* diagnostic only (wrong output): instruction count of the chunk loop without the repeat-offset scan */
+        const uint32_t actual = ov > 3 ? ov - 3 : h0 + ov;
+#else
         const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
+#endif
         return cz_chunk_plan(x, produced, lit_used, lit, cnt, ll, ml, actual);
     };
     /* Records are loaded three chunks ahead; each chunk is planned (codes -> values, repeat offsets,
@@ -1559,7 +1564,11 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
         r1 = r2; r2 = r3; r3 = load_rec(done + 192);
         if (cur.err > 0) return cur.err;
         CZ_PROF_ACC(CZ_P_EXTRACT);
+#ifdef CZ_EXP_NOCOPY   /* diagnostic only (wrong output): ... without the copy stage */
+        x.produced += cur.sum_tot; x.lit_used += cur.sum_ll; exec_err = 0;
+#else
         exec_err = cz_chunk_copy(x, lit, cur);
+#endif
         CZ_PROF_T0();
         if (exec_err) return exec_err;
         cz_wave_sync();

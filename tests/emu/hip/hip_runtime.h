@@ -90,7 +90,9 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t 
     for (int i = 0; i < 4; i++) {
         const uint32_t c = (sel >> (8 * i)) & 0xFF;
         uint32_t b;
-        if (c <= 7) b = (uint32_t)(both >> (8 * c)) & 0xFF; else if (c == 0x0C) b = 0; else __builtin_trap();
+        if (c <= 7) b = (uint32_t)(both >> (8 * c)) & 0xFF;
+        else if (c <= 11) __builtin_trap();                                  /* sign replication: not used by the kernels */
+        else if (c == 0x0C) b = 0; else b = 0xFF;                           /* 12: 0x00, >= 13: 0xFF */
         r |= b << (8 * i);
     }
     return r;
