@@ -1,14 +1,16 @@
 /*
- * czstd_chain.hip — cz_chain_kernel: the FSE-chain pre-pass.
+ * czstd_chain.hip — cz_scan_kernel + cz_chain_kernel: the block-parallel FSE-chain pre-pass.
  *
  * The interleaved LL/OF/ML FSE state machines of a sequences section are ONE serial dependency
- * chain per block (sequence_section_decoder.cairo:223-286).  With every frame of a batch in flight
+ * chain per block (sequence_section_decoder.cairo:223-286).  With every block of a batch in flight
  * at once the pass lasts (sequences per block) x (latency of one chain step), so the step is
- * written for latency, one wave per SIMD:
+ * written for latency, one wave per SIMD; the unit of work is a BLOCK (cz_scan_kernel lists the blocks of
+ * all frames, a slot takes the next one when its block is done):
  *   - a chain is spread over a QUAD of lanes: lane 0 runs the LL state, lane 1 the ML state, lane 2
  *     the OF state (update order LL, ML, OF, :258-277), lane 3 idles on a dummy table.  Each lane does
  *     ONE table lookup, one v_ffbh and one v_bfe per step; the bit offsets of the three fields and
- *     the total come from four quad_perm DPP operations; the cursor advances with one v_dot4c.
+ *     the total come from four quad_perm DPP operations; the cursor advances with one v_dot4c;
+ *     tables of a refilled slot are built by the whole wave (czc_fse_build_wave).
  *   - CZC_SLOTS (10) quads per wave, four waves per CU: 40 chains per CU (LDS: 16-bit
  *     decoding tables 2.5 KB + a 512-byte bit ring per chain; 48 would fit, 40 leave 25 KB per CU to the literals pass that
  *     runs next to this kernel).
@@ -23,8 +25,8 @@
  * bits, resolve offsets and execute the sequences without tables, bitstream or chain.
  *
  * This pass is a pure accelerator for well-formed frames: on ANY irregularity (malformed header,
- * table error, invalid code, overrun, left-over bits, arena overflow, > 64 symbols in a table description) — and for frames whose first sequences
- * section is short (chain_min_nseq), where it would not pay — it marks the whole frame "no chain info"
+ * table error, invalid code, overrun, left-over bits, arena overflow, > 64 symbols in a table description) — and for frames
+ * whose first sequences section is shorter than chain_min_nseq (0 by default) — it marks the whole frame "no chain info"
  * (frame_first[f] = 0) and the main kernel decodes that frame entirely by itself, producing the
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
@@ -40,8 +42,8 @@ static_assert(((CZC_STEPS * 58u + 7u) / 8u + 12u) + 12u <= 256u + 12u, "a top-up
 #define CZC_NEED ((CZC_STEPS * 58u + 7u) / 8u + 12u)   /* CZC_STEPS steps x 58 bits (32 extra bits + 26 state bits at most) + the 8 bytes a step reads below its cursor;
                                                           also covers CZC_WIDE_STEPS (16) steps of czc_step at 89 bits (63 extra bits) each */
 #define CZC_MAP_WORDS CZ_CHAIN_MAP_WORDS  /* per block in the arena: state -> code maps, 512 B LL + 512 B ML + 256 B OF */
-/* args.chain_min_nseq (default 2048): frames whose first sequences section is smaller are left to the
-   main kernel — the pre-pass only pays for long chains (measured on the corpus-like mix). */
+/* args.chain_min_nseq (default 0): frames whose first sequences section is smaller are left to the main kernel (with
+   blocks as the unit of work short chains cost little; the knob stays for experiments). */
 
 /* Chain-time decoding tables are 16 bits per state so that more chains fit in a CU's LDS.  An entry
  * holds only what the serial core needs:
@@ -316,17 +318,8 @@ __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL 
 #else
 #define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF "\n"
 #endif
-#ifdef CZC_BISECT_C
-#undef CZC_ASM_STORE
-#define CZC_ASM_STORE(OFF) "global_store_dwordx2 %[RP], v[120:121], off offset:" #OFF "\n" "global_store_dwordx2 %[RP], v[122:123], off offset:" #OFF "+8\n"
-#endif
-#ifdef CZC_BISECT_B
-#define CZC_ASM_RING01 "ds_read_b32 v124, v115\n" "ds_read_b32 v125, v115 offset:4\n"
-#define CZC_ASM_LGKM_E "s_waitcnt lgkmcnt(3)\n"
-#else
 #define CZC_ASM_RING01 "ds_read2_b32 v[124:125], v115 offset1:1\n"
 #define CZC_ASM_LGKM_E "s_waitcnt lgkmcnt(2)\n"
-#endif
 #define CZC_ASM_TAIL(STORE, NEXTH) \
     STORE \
     "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n" \

@@ -307,7 +307,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
     if (c->chain_arena && !a.tasks) {
-        /* pass A: CZC_SLOTS frames per wave, one FSE chain per lane -> records in the arena */
+        /* the pre-pass: block list (cz_scan_kernel), then the FSE chains of all blocks (cz_chain_kernel) -> records in the arena */
         if (c->frame_first_cap < n) {
             if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
             CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8)); c->frame_first_cap = n;

@@ -1,21 +1,26 @@
 /*
  * czstd_kernels.hip — CDNA4 (gfx950) kernels of the zstd frame/block decoder.
  *
- * Mapping: ONE 64-lane wavefront (= one workgroup) per frame, a
+ * cz_decode_frames_kernel: ONE 64-lane wavefront (= one workgroup) per frame, a
  * persistent grid that pulls frames from an atomic work counter.  Blocks of one frame are
  * chained (Treeless literals, Repeat FSE modes, offset history, window reach-back:
  * src/decoding/scratch.cairo:11-19), so the frame is the unit of parallelism and all carried
- * state lives in the workgroup's LDS: Huffman table (4 KiB), LL/OF/ML FSE tables (6 KiB),
+ * state lives in the workgroup's LDS: Huffman table (4 KiB), LL/OF/ML FSE tables (5 KiB),
  * offset history.  Per block:
  *     lane 0      parses headers / table descriptions from an LDS-staged copy of the bytes
- *     lanes 0..2  build the three FSE decoding tables side by side
+ *     lanes 0..2  build the three FSE decoding tables side by side (only for blocks the pre-pass did not take)
  *     all lanes   fill the Huffman table; copy / fill Raw and RLE payloads (16 B per lane)
- *     lanes 0..3  decode the four huff0 streams (one backward bit reader per lane)
- *     lane 0      runs the interleaved LL/OF/ML FSE state machines, 64 sequences at a time,
- *                 then all 64 lanes execute those sequences: wave prefix sums give every
- *                 sequence its literal and output offsets, literals are scattered in
- *                 parallel, matches are resolved in dependency rounds (ballot + first-undone
- *                 watermark), long copies are done cooperatively.
+ *     all lanes   decode the huff0 streams: each stream cut into up to 16 bit ranges, one lane per range
+ *                 (self-synchronising: counting pass, start fix-up, writing pass)
+ *     lane 0      runs the interleaved LL/OF/ML FSE state machines, 64 sequences at a time — unless
+ *                 cz_chain_kernel left per-sequence records (czstd_chain.hip) — then all 64 lanes
+ *                 execute those sequences: a DPP scan resolves repeat offsets, wave prefix sums give
+ *                 every sequence its literal and output offsets, short chunks are assembled in LDS,
+ *                 matches are resolved in dependency rounds (ballot + first-undone watermark), long
+ *                 copies are done cooperatively.
+ * The same kernel launched with literals_only = 1 is the literals pass (Huffman literals of every
+ * pre-passed frame into the literal arena, beside cz_chain_kernel).  cz_dict_setup_kernel parses a
+ * dictionary with the same table builders.
  *
  * Semantics follow the reference (NethermindEth/cairo_zstd) line by line where it matters;
  * each device function cites the reference file:line it restates.  Error codes mirror the

@@ -16,17 +16,19 @@ from cairo_zstd_amd import synth
 
 def main():
     total_bad = 0
-    for kind, n, first in (("mix", 6000, 100000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000)):
+    for kind, n, first in (("mix", 6000, 100000), ("mix", 6000, 300000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000)):
         b = synth.generate(kind, n, first_index=first, nthreads=16)
         frames = [b.frame(i) for i in range(n)]
         caps = [int(r) + 8 for r in b.regen]
         o_off, o_cap, o_total = b.out_layout(64)
         _, olen, ost = oracle.decode_batch(b.base, b.off, b.length, o_off, o_cap, int(o_total) + 256, nthreads=32)
         ref_out = _
-        for prepass in (0, 1):
+        for prepass in (0, 1, 2):                                        # 2: pre-pass + literals pass
             c = cz.Context(0)
             if prepass:
                 c.set_chain_arena(int(b.length.sum()) * 8 + (64 << 20), min_sequences=0)
+            if prepass == 2:
+                c.set_literal_arena(int(b.regen.sum()) + (16 << 20))
             t = time.time()
             got = cz.decode_batch_host(frames, caps, c)
             bad = 0
