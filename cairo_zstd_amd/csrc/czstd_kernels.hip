@@ -1148,7 +1148,10 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
             cz_lit_coop_copy(x.out + os, lit, ls, n);
         }
     }
-    __syncthreads();
+    /* No wait for the stores: a wave's vector-memory instructions reach the memory pipeline in program order, so the loads
+       below see them (the LDS path above relies on the same; s_waitcnt vmcnt(0) here and after every round was a third
+       of this path's time) */
+    cz_wave_sync();
     CZ_PROF_ACC(CZ_P_LITCOPY);
 
     /* matches: dependency rounds.  W = first byte not yet guaranteed written = match
@@ -1215,13 +1218,13 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
                 while (copied < n) {
                     const uint32_t len = n - copied < L ? n - copied : L;
                     cz_coop_copy(d + copied, d + copied - L, len);
-                    __syncthreads();
+                    cz_wave_sync();
                     copied += len; L += L;
                 }
             }
         }
         if (ready) done = 1;
-        __syncthreads();
+        cz_wave_sync();
     }
     CZ_PROF_ACC(CZ_P_MATCH);
     x.produced += sum_tot; x.lit_used += sum_ll;
