@@ -33,7 +33,7 @@ class BlockHeader(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the library in-tree with hipcc for gfx950 (csrc/Makefile)."""
-    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_types.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_exec.hip", "czstd_types.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("cairo_zstd_amd.h", "cairo_zstd_amd_status.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
