@@ -42,12 +42,13 @@ static void* emu_watchdog(void*) {
 #include "czstd_chain.hip"
 #include "czstd_exec.hip"
 
-struct lane_arg { cz_batch_args a; unsigned lane, block; int which; };
+struct lane_arg { cz_batch_args a; unsigned lane, block; int which; const uint8_t* dict_raw; uint64_t dict_len; cz_device_frame_state* dict_state; uint64_t* dict_res; };
 static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
     if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a);
+    else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
     else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
     else cz_decode_frames_kernel(la->a);                                /* 1 decode, 3 literals pass */
     emu_lane_done[la->lane] = 1;
@@ -105,6 +106,29 @@ int main(int argc, char** argv) {
         blk_desc.resize(a.chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
         a.blk_desc = blk_desc.data(); a.blk_capacity = (uint32_t)blk_desc.size(); a.scan_ctl = scan_ctl.data();
         frame_order.resize(n ? n : 1); a.frame_order = frame_order.data();
+    }
+    /* EMU_DICT=<file>: parse the dictionary with cz_dict_setup_kernel (one workgroup) and start every frame from it, as
+       cz_context_set_dictionary does; a dictionary that does not parse ends the run with exit code 3 and its status on stderr */
+    std::vector<uint8_t> dict_raw; cz_device_frame_state* dict_state = nullptr; uint64_t dict_res[4] = {0, 0, 0, 0};
+    if (const char* de = getenv("EMU_DICT")) {
+        FILE* df = fopen(de, "rb"); if (!df) return 2;
+        fseek(df, 0, SEEK_END); long dl = ftell(df); fseek(df, 0, SEEK_SET);
+        dict_raw.resize((size_t)dl); if (dl && fread(dict_raw.data(), 1, (size_t)dl, df) != (size_t)dl) return 2;
+        fclose(df);
+        uint8_t* dict_exact = (uint8_t*)malloc(dict_raw.size() ? dict_raw.size() : 1); memcpy(dict_exact, dict_raw.data(), dict_raw.size());
+        dict_state = (cz_device_frame_state*)calloc(1, sizeof(cz_device_frame_state));
+        emu_nthreads = 64; pthread_barrier_init(&emu_barrier, nullptr, 64u);
+        std::vector<pthread_t> th(64); std::vector<lane_arg> la(64);
+        for (int l = 0; l < 64; l++) {
+            la[l].a = a; la[l].lane = (unsigned)l; la[l].block = 0; la[l].which = 6;
+            la[l].dict_raw = dict_exact; la[l].dict_len = dict_raw.size(); la[l].dict_state = dict_state; la[l].dict_res = dict_res;
+            pthread_create(&th[l], nullptr, lane_main, &la[l]);
+        }
+        for (int l = 0; l < 64; l++) pthread_join(th[l], nullptr);
+        pthread_barrier_destroy(&emu_barrier);
+        fprintf(stderr, "EMU_DICT: status %llu content offset %llu id %llu\n", (unsigned long long)dict_res[0], (unsigned long long)dict_res[1], (unsigned long long)dict_res[2]);
+        if (dict_res[0]) return 3;
+        a.dict_state = dict_state; a.dict = dict_exact + dict_res[1]; a.dict_len = dict_raw.size() - dict_res[1];
     }
     /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int order[6] = {4, 5, 0, 3, 2, 1};

@@ -2,6 +2,8 @@
 emulator under AddressSanitizer + UBSan (tests/emu) and checks it against the oracle.
 GPU sanitizers are not available on the pool, so this is where out-of-bounds accesses, hangs
 and barrier races in the kernels get caught before they reach a device.  CPU-only, small."""
+import os
+
 import numpy as np
 import pytest
 
@@ -124,3 +126,17 @@ def test_emu_d2_weight_log_10_unsupported():
     for chain in (0, 1 << 20):
         res = emu_runner.run([z], [64], chain_bytes=chain)
         assert int(res[0][0]["status"]) == status.CZ_E_UNSUPPORTED
+
+
+def test_emu_dictionary_frames():
+    """cz_dict_setup_kernel and the dictionary arm of the match copy under ASan/UBSan: the committed dictionary frames, every
+    frame of the batch started from the dictionary (what cz_context_set_dictionary does), with and without the pre-pass."""
+    import glob
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+    pairs = [(open(z, "rb").read(), open(z[:-4] + ".orig", "rb").read()) for z in sorted(glob.glob(os.path.join(d, "frame_*.zst")))[:5]]
+    for chain_bytes in (0, 8 << 20):
+        got = emu_runner.run([z for z, _ in pairs], [len(o) + 16 for _, o in pairs], dict_path=os.path.join(d, "dict.bin"),
+                             chain_bytes=chain_bytes, lit_bytes=(4 << 20) if chain_bytes else 0)
+        for i, ((r, out), (_, orig)) in enumerate(zip(got, pairs)):
+            assert int(r["status"]) == 0, (i, int(r["status"]))
+            assert out == orig, i
