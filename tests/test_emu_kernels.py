@@ -74,11 +74,11 @@ def test_emu_chain_prepass():
     leave them to the decoder, which reports the reference's status), an arena that is far too small, and the
     literals pass (a literals-only launch of the decode kernel) feeding the decode kernel, with room and without."""
     frames, caps = [], []
-    for name, z, orig in corpus_pairs(max_orig=6000):
+    for name, z, orig in corpus_pairs(max_orig=4000):
         frames.append(z)
         caps.append(len(orig) + 16)
     b = synth.generate("mix", 24, first_index=4242, nthreads=2)
-    keep = [i for i in range(b.n) if b.regen[i] < 30000][:6]
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:4]
     frames += [b.frame(i) for i in keep]
     caps += [int(b.regen[i]) + 8 for i in keep]
     for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=700)):
@@ -92,7 +92,7 @@ def test_emu_chain_prepass():
         caps.append(len(orig) * 2 + 4096)
     _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20)
     assert "frames have literal nodes" in emu_runner.run.last_stderr
-    _run_and_compare(frames[::3], caps[::3], chain_bytes=8 << 20)
+    _run_and_compare(frames[::4], caps[::4], chain_bytes=8 << 20)
     _run_and_compare(frames[:12], caps[:12], chain_bytes=4096, lit_bytes=6000)
 
 
@@ -101,11 +101,11 @@ def test_emu_exec_kernel():
     order behind done flags) under ASan/UBSan, 4 waves per workgroup: corpus frames, synthetic frames, malformed
     frames (it must leave them to cz_decode_frames_kernel)."""
     frames, caps = [], []
-    for name, z, orig in corpus_pairs(max_orig=5000):
+    for name, z, orig in corpus_pairs(max_orig=3500):
         frames.append(z)
         caps.append(len(orig) + 16)
     b = synth.generate("mix", 24, first_index=4242, nthreads=2)
-    keep = [i for i in range(b.n) if b.regen[i] < 30000][:5]
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:4]
     frames += [b.frame(i) for i in keep]
     caps += [int(b.regen[i]) + 8 for i in keep]
     for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=600)):
