@@ -302,7 +302,7 @@ def main():
         torch.cuda.synchronize()
         copy_ceiling = 2.0 * a.numel() * 5 / (time.perf_counter() - t1) / 1e9
         del a, b2
-        for wl in ("raw_rle", "huf_literals", "full_4a", "mix"):
+        for wl in ("raw_rle", "huf_literals", "full_4a", "full_4b", "mix"):
             if wl == args.workload:
                 continue
             nf = 12500 if wl == "mix" else 10000
