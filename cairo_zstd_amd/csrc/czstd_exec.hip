@@ -435,6 +435,8 @@ __device__ static int czx_run_frame(const cz_batch_args& a, uint32_t f, cz_gptr 
             __syncthreads();
             CZX_PROF(0);
             if (huf_fill) {                                             /* huff0_decoder.cairo:451-463, a symbol per wave at a time */
+                if (WAVE == 0) cz_huf_rank_wave(huf_nsym);
+                __syncthreads();
                 const uint32_t max_bits = sh.huf_max_bits;
                 for (uint32_t s = (uint32_t)WAVE; s < huf_nsym; s += CZX_WAVES) {
                     const uint32_t b = sh.b.c.hbits[s];

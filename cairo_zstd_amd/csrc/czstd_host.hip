@@ -111,7 +111,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
     (void)hipMemset(c->d_prof, 0, sizeof tmp);
     int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
     for (int i = 0; i < n; i++) out[i] = tmp[i];
-    for (int i = 32; i < 58 && i < cap; i++) out[i] = tmp[i];        /* cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
+    for (int i = 20; i < 58 && i < cap; i++) out[i] = tmp[i];        /* literals pass: 20..30; cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
     return n;
 }
 

@@ -86,7 +86,7 @@ struct CzBroadcast {
     /* literals section */
     uint32_t lit_type, regen, nstreams, lit_total;      /* lit_total = header + body bytes */
     uint32_t stream_off[4], stream_len[4];              /* relative to the block start */
-    uint32_t huf_fill, huf_nsym;
+    uint32_t huf_fill, huf_nsym, huf_last_w;   /* huf_last_w: the implied weight of the last symbol (huff0_decoder.cairo:359-372) */
     uint32_t st_count[4], st_flags[4];
     /* sequences section */
     int32_t  seq_hdr_err; uint32_t nseq, seq_modes, seq_body_off;
@@ -117,7 +117,7 @@ struct CzShared {
                  __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64]; } t4;   /* + one dump byte per lane */   /* mirror[8..15] == ring[2040..2047] */
     } a;
     struct {
-        struct { uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
+        struct { __attribute__((aligned(4))) uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
     } b;
     CzBroadcast bc;
     uint32_t frame_idx;
@@ -419,11 +419,19 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
         *bytes_used = 1 + need;
     }
     /* build_table_from_weights :321-431 */
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < nw; i++) {
-        if (w[i] > 11) return CZ_E_HUF_WEIGHT_TOO_BIG;                  /* :335 */
-        sum += w[i] ? (1u << (w[i] - 1)) : 0u;
+    uint32_t sum = 0, too_big = 0;
+    {
+        /* four weights per LDS read, no exit inside the loop (one dependent LDS round trip per weight made this loop as
+           long as the weight decode itself); bytes beyond nw are masked */
+        const uint32_t* w4 = (const uint32_t*)w;                        /* hbits is 4-byte aligned, 264 bytes long */
+        for (uint32_t i = 0; i < nw; i += 4) {
+            uint32_t v = w4[i >> 2];
+            if (nw - i < 4) v &= 0xFFFFFFFFu >> (8 * (4 - (nw - i)));
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) { const uint32_t x = (v >> (8 * j)) & 0xFFu; too_big |= x > 11u; sum += x ? (1u << ((x - 1) & 31u)) : 0u; }
+        }
     }
+    if (too_big) return CZ_E_HUF_WEIGHT_TOO_BIG;                        /* :335 (the first failing check of the reference; nothing else is tested before it) */
     if (sum == 0) return CZ_E_HUF_MISSING_WEIGHTS;                      /* :351 */
     const uint32_t max_bits = cz_hbs(sum), left = (1u << max_bits) - sum;
     if (left == 0 || (left & (left - 1))) return CZ_E_HUF_LEFTOVER_NOT_POW2;            /* :359 */
@@ -431,23 +439,50 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
     sh.huf_max_bits = (uint8_t)max_bits;                             /* :383 */
     if (max_bits > 11) { sh.huf_max_bits = 0; return CZ_E_HUF_MAX_BITS_TOO_HIGH; }   /* :385; the reference leaves the too-large value in its (now unusable)
                                                                            table; here a resumed decoder must not index a 2^11-entry table with it */
-    /* in LDS: arrays indexed by a run-time value would otherwise live in scratch memory, one HBM-backed
-       round trip per access of this serial loop */
-    uint32_t* rank_cnt = sh.a.t1.rank_cnt; uint32_t* rank_idx = sh.a.t1.rank_idx;
-    for (int b = 0; b < 13; b++) { rank_cnt[b] = 0; rank_idx[b] = 0; }
-    for (uint32_t s = 0; s <= nw; s++) {
-        uint32_t wt = s < nw ? w[s] : last_w, bits = wt ? max_bits + 1 - wt : 0;
-        w[s] = (uint8_t)bits; rank_cnt[bits]++;
-    }
-    for (uint32_t b = max_bits; b > 0; b--) rank_idx[b - 1] = rank_idx[b] + rank_cnt[b] * (1u << (max_bits - b)); /* :414-429 */
-    for (uint32_t s = 0; s <= nw; s++) {                                /* :433-450 */
-        uint32_t b = w[s];
-        if (b) { sh.b.c.sym_base[s] = (uint16_t)rank_idx[b]; rank_idx[b] += 1u << (max_bits - b); }
-    }
+    /* bit lengths, ranks and the first table index of every symbol: cz_huf_rank_wave, by all lanes, before cz_huf_fill */
+    sh.bc.huf_last_w = last_w;
     *nsym_out = nw + 1;
     return 0;
 }
 /* all lanes: the cell-filling half (huff0_decoder.cairo:451-463).  entry = symbol | bits<<8 */
+/* The rest of build_table_from_weights (huff0_decoder.cairo:374-450) by the whole wave — weights -> bit lengths, symbols per
+ * length, and for every symbol the first index of its run in the decoding table (runs ordered by length, longest first,
+ * symbols of one length in symbol order).  One lane did this in three dependent LDS loops over up to 256 symbols; here
+ * lane = symbol, 64 at a time: lanes of equal length are matched with four ballots (the rank of a symbol among its length
+ * within the chunk), earlier chunks are in cnt[].  hbits[] holds the weights on entry and the bit lengths on exit.
+ * Scratch: sh.a.t1.rank_cnt / rank_idx (region `a` is the parse scratch until cz_huf_fill turns it into the table). */
+__device__ static inline void cz_huf_rank_wave(uint32_t nsym) {
+    const uint32_t max_bits = cz_uni(sh.huf_max_bits), last_w = cz_uni(sh.bc.huf_last_w), lane = (uint32_t)LANE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* cnt = sh.a.t1.rank_cnt; uint32_t* idx = sh.a.t1.rank_idx;
+    if (lane < 16) { cnt[lane] = 0; idx[lane] = 0; }
+    cz_wave_sync();
+    uint32_t bits[4], k[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t s = 64u * c + lane;
+        const int in = s < nsym;
+        const uint32_t wt = !in ? 0u : (s + 1 < nsym ? sh.b.c.hbits[s] : last_w);
+        const uint32_t b = wt ? max_bits + 1 - wt : 0u;
+        unsigned long long same = __ballot(b != 0);
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) { const int bit = (int)((b >> t) & 1u); const unsigned long long m = __ballot(bit); same &= bit ? m : ~m; }
+        const uint32_t before = b ? cnt[b] : 0u;
+        cz_wave_sync();                                                 /* every lane has read cnt[] */
+        if (b && (same >> lane) == 1ull) cnt[b] = before + (uint32_t)__popcll(same);   /* the highest lane of the group */
+        cz_wave_sync();
+        bits[c] = b; k[c] = before + (uint32_t)__popcll(same & lt);
+        if (in) sh.b.c.hbits[s] = (uint8_t)b;
+    }
+    if (lane == 0) for (uint32_t b = max_bits; b > 0; b--) idx[b - 1] = idx[b] + cnt[b] * (1u << (max_bits - b));   /* :414-429 */
+    cz_wave_sync();
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {                                  /* :433-450 */
+        const uint32_t s = 64u * c + lane;
+        if (s < nsym && bits[c]) sh.b.c.sym_base[s] = (uint16_t)(idx[bits[c]] + (k[c] << (max_bits - bits[c])));
+    }
+    cz_wave_sync();
+}
 __device__ static __attribute__((noinline)) void cz_huf_fill(uint32_t nsym) {
     const uint32_t max_bits = sh.huf_max_bits;
     for (uint32_t s = 0; s < nsym; s++) {
@@ -1625,6 +1660,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
     CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
     if (bc.huf_fill) {
+        cz_huf_rank_wave(cz_uni(bc.huf_nsym)); __syncthreads();
         cz_huf_fill(bc.huf_nsym); __syncthreads();
         if (cz_uni(bc.regen) >= 2048u || !last_block) { cz_huf_fill_multi(); __syncthreads(); }   /* pays from a few symbols per lane on; a carried table always has it */
         if (!last_block) {                                              /* carried for later Treeless blocks */
@@ -1948,6 +1984,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
         __syncthreads();
         if (!err && used > left) err = CZ_E_DICT_TRUNCATED;             /* (panic) slice :62 */
         if (!err) {
+            cz_huf_rank_wave(nsym); __syncthreads();
             cz_huf_fill(nsym); __syncthreads();
             cz_huf_fill_multi(); __syncthreads();
             for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((CZ_GLOBAL uint32_t*)st->huf)[i] = ((const uint32_t*)sh.a.huf)[i];
@@ -2009,6 +2046,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
             __syncthreads();
             const uint64_t first = cz_run_frame_literals(a, (cz_gcptr)(a.in_base + a.in_off[f]), a.in_len[f], lit_scratch);
             if (LANE == 0) a.lit_first[f] = first;
+#ifdef CZ_PROFILE
+            if (LANE == 0 && a.prof) for (int i = 0; i < 11; i++) { atomicAdd(&a.prof[20 + i], sh.prof[i]); sh.prof[i] = 0; }   /* the literals pass has phase slots of its own */
+#endif
             continue;
         }
         if (!a.tasks && a.chain_arena && cz_uni64(a.frame_first[f]) == 0xFFFFFFFFFFFFFFFFull) continue;   /* finished by cz_exec_frames_kernel */

@@ -38,5 +38,8 @@ for rank in [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]:
     tot = sum(vals) or 1
     print(f"frame rank {rank}: {int(rg[0])} B decoded, {int(ln[0])} B compressed, {int(res['blocks_decoded'][0])} blocks, total {ctx.last_kernel_ms():.3f} ms chain {ctx.last_chain_ms():.3f} ms status {int(res['status'][0])}")
     print("   " + "  ".join(f"{nm} {100.0 * v / tot:.1f}%" for nm, v in zip(PHASES, vals) if v))
+    lv = [buf[20 + i] for i in range(11)]
+    if sum(lv):
+        print("   literals pass: " + "  ".join(f"{nm} {100.0 * v / sum(lv):.1f}%" for nm, v in zip(PHASES, lv) if v) + f"  ({sum(lv) / 2.1e6:.2f} ms of wave time at 2.1 GHz)")
     print(f"   chunks: {buf[14]} on the LDS path, {buf[15]} general with {buf[16]} dependency rounds and {buf[17]} wave-wide match copies")
 ctx.close()
