@@ -428,6 +428,12 @@ __device__ static int czx_run_frame(const cz_batch_args& a, uint32_t f, cz_gptr 
             __syncthreads();
             if (threadIdx.x == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi);
             __syncthreads();
+            if (cz_unii(bc.err) == CZ_PARSE_NEED_WTAB) {
+                if (WAVE == 0) cz_huf_weight_table();
+                __syncthreads();
+                if (threadIdx.x == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, 0, 1);
+                __syncthreads();
+            }
             if (cz_unii(bc.err)) return 1;
             const uint32_t huf_fill = cz_uni(bc.huf_fill), lt = cz_uni(bc.lit_type), regen = cz_uni(bc.regen), lit_total = cz_uni(bc.lit_total);
             const uint32_t nseq = cz_uni(bc.nseq), nstreams = cz_uni(bc.nstreams), huf_nsym = cz_uni(bc.huf_nsym);

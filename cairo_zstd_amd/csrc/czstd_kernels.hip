@@ -86,6 +86,7 @@ struct CzBroadcast {
     /* literals section */
     uint32_t lit_type, regen, nstreams, lit_total;      /* lit_total = header + body bytes */
     uint32_t stream_off[4], stream_len[4];              /* relative to the block start */
+    uint32_t wt_nprobs, wt_log, wt_fse_bytes;   /* description of the Huffman-weight FSE table between the two phases of the tree parse */
     uint32_t huf_fill, huf_nsym, huf_last_w;   /* huf_last_w: the implied weight of the last symbol (huff0_decoder.cairo:359-372) */
     uint32_t st_count[4], st_flags[4];
     /* sequences section */
@@ -370,8 +371,86 @@ __device__ static __attribute__((noinline)) void cz_fse_build(uint32_t* table, c
  * (huff0_decoder.cairo:159-319, :321-431).  Lane 0.  Leaves per-symbol code lengths in
  * sh.b.c.hbits[0..nsym) and first-cell indices in sh.b.c.sym_base[]; the table itself is filled by
  * all lanes afterwards (cz_huf_fill).  *bytes_used per :313-318. */
+/* cz_fse_build by the whole wave (all 64 lanes; at most 64 symbols, table of at most 256 cells): the same three steps as
+ * czc_fse_build_wave in czstd_chain.hip — lane = symbol for the "less than one" cells and the first rank of every symbol,
+ * lane = step of the spreading walk, lane = cell for the entries, equal symbols of a chunk matched with six ballots —
+ * with this kernel's 32-bit entries.  symof: `size` bytes of scratch, counters: 64 halfwords. */
+#define CZ_PARSE_NEED_WTAB (-2)   /* cz_parse_sections / cz_huf_read_and_rank, phase 0: the weights' FSE table is described in bc.wt_*; build it and call phase 1 */
+__device__ static inline void cz_fse_build_wave(uint32_t* table, const int16_t* probs, uint32_t nprobs, uint32_t log, uint8_t* symof, uint16_t* counters,
+                                                 const uint32_t* llml, uint32_t kind) {
+    const uint32_t size = 1u << log, mask = size - 1, lane = (uint32_t)LANE;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int32_t p = lane < nprobs ? (int32_t)probs[lane] : 0;
+    const unsigned long long lowm = __ballot(p == -1);
+    const uint32_t neg = size - (uint32_t)__popcll(lowm);
+    if (p == -1) table[size - 1u - (uint32_t)__popcll(lowm & lt)] = CZ_FSE_PACK(lane, log, 0) | cz_fse_code_bits(llml, kind, lane);   /* :169-188 */
+    counters[lane] = 0;
+    const uint32_t cnt = p > 0 ? (uint32_t)p : 0u;
+    const uint32_t cum = cz_wave_incl_scan(cnt) - cnt;
+    for (uint32_t i = 4u * lane; i < size; i += 256u) *(uint32_t*)(symof + i) = 0u;
+    cz_wave_sync();
+    if (cnt && cum < size) symof[cum] = (uint8_t)lane;
+    cz_wave_sync();
+    {
+        const uint32_t per = size >= 64u ? size >> 6 : 1u, b0 = lane * per;
+        const int act = b0 < size;
+        uint32_t run = 0, vals[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) { if (act && j < per) { const uint32_t v = symof[b0 + j]; run = v > run ? v : run; } vals[j] = run; }
+        uint32_t inc = act ? run : 0u;
+#define CZ_MAX_STEP(CTRL, RM) do { const uint32_t o_ = cz_dpp<CTRL, RM>(0u, inc); inc = o_ > inc ? o_ : inc; } while (0)
+        CZ_MAX_STEP(CZ_DPP_SHR1, 0xF); CZ_MAX_STEP(CZ_DPP_SHR2, 0xF); CZ_MAX_STEP(CZ_DPP_SHR4, 0xF); CZ_MAX_STEP(CZ_DPP_SHR8, 0xF);
+        CZ_MAX_STEP(CZ_DPP_BCAST15, 0xA); CZ_MAX_STEP(CZ_DPP_BCAST31, 0xC);
+#undef CZ_MAX_STEP
+        const uint32_t exc = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(0u, inc);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) if (act && j < per) symof[b0 + j] = (uint8_t)(vals[j] > exc ? vals[j] : exc);
+    }
+    cz_wave_sync();
+    {
+        const uint32_t step = (size >> 1) + (size >> 3) + 3u;          /* :190-226 */
+        uint32_t running = 0;
+        for (uint32_t j0 = 0; j0 < size; j0 += 64u) {
+            const uint32_t j = j0 + lane, pos = (j * step) & mask;
+            const int valid = j < size && pos < neg;
+            const unsigned long long vm = __ballot(valid);
+            if (valid) table[pos] = symof[running + (uint32_t)__popcll(vm & lt)];
+            running += (uint32_t)__popcll(vm);
+        }
+    }
+    cz_wave_sync();
+    for (uint32_t i0 = 0; i0 < neg; i0 += 64u) {                        /* :231-255, :377-400 */
+        const uint32_t i = i0 + lane;
+        const int cell = i < neg;
+        const uint32_t s = cell ? table[i] : 0u;
+        unsigned long long same = __ballot(cell);
+#pragma unroll
+        for (uint32_t b = 0; b < 6; b++) { const int bit = (int)((s >> b) & 1u); const unsigned long long m = __ballot(bit); same &= bit ? m : ~m; }
+        const uint32_t n = cell ? (uint32_t)probs[s] : 1u;
+        const uint32_t k = (cell ? (uint32_t)counters[s] : 0u) + (uint32_t)__popcll(same & lt);
+        cz_wave_sync();                                                 /* every lane has read counters[] */
+        if (cell && (same >> lane) == 1ull) counters[s] = (uint16_t)(k + 1u);
+        if (cell) {
+            const uint32_t m = 1u << (cz_hbs(n) - 1), slices = (m == n) ? n : m * 2;
+            const uint32_t dbl = slices - n, single = n - dbl, width = size >> (cz_hbs(slices) - 1);
+            uint32_t nb = cz_hbs(width) - 1, bl;
+            if (k < dbl) { bl = single * width + k * width * 2; nb += 1; }
+            else bl = (k - dbl) * width;
+            table[i] = CZ_FSE_PACK(s, nb, bl) | cz_fse_code_bits(llml, kind, s);
+        }
+        cz_wave_sync();
+    }
+}
+/* the weights' FSE table between the phases of the tree parse: by the wave when it fits that builder, else by lane 0 as before */
+__device__ static inline void cz_huf_weight_table() {
+    const uint32_t np = cz_uni(sh.bc.wt_nprobs), lg = cz_uni(sh.bc.wt_log);
+    if (np <= 64u && lg <= 8u) cz_fse_build_wave(sh.a.t1.wtab, sh.a.t1.probs0, np, lg, (uint8_t*)(sh.a.t1.wtab + 256), sh.a.t1.counters0, sh.b.c.llml, 3);
+    else if (LANE == 0) cz_fse_build(sh.a.t1.wtab, sh.a.t1.probs0, np, lg, sh.a.t1.counters0, sh.b.c.llml, 3);
+}
+/* phase 0 stops (CZ_PARSE_NEED_WTAB) once an FSE-compressed description's probabilities are read; the caller has the table
+   built (cz_huf_weight_table, all lanes) and calls phase 1, which goes on from there */
 __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g, uint32_t len, uint32_t stage_lo, uint32_t stage_hi,
-                                           uint32_t goff, uint32_t* bytes_used, uint32_t* nsym_out) {
+                                           uint32_t goff, uint32_t* bytes_used, uint32_t* nsym_out, int phase) {
     /* g = block start, the tree description begins at block offset goff, len bytes available */
     if (len == 0) return CZ_E_HUF_SOURCE_EMPTY;                         /* :162 */
     CzFBits fb; fb.g = g; fb.stage = sh.a.t1.stage; fb.stage_lo = stage_lo; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = 0;
@@ -385,10 +464,14 @@ __device__ static __attribute__((noinline)) int cz_huf_read_and_rank(cz_gcptr g,
         br.stage_lo = 0; br.stage_hi = 0;
         if (goff + 1 >= stage_lo && goff + 1 < stage_hi) { br.stage = sh.a.t1.stage + (goff + 1 - stage_lo); br.stage_lo = 0; br.stage_hi = stage_hi - (goff + 1); }
         uint32_t nprobs, log, fse_bytes;
-        int e = cz_fse_read_probs(br, 100, sh.a.t1.probs0, &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
-        if (e) return e;
-        if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
-        cz_fse_build(sh.a.t1.wtab, sh.a.t1.probs0, nprobs, log, sh.a.t1.counters0, sh.b.c.llml, 3);
+        if (phase == 0) {
+            int e = cz_fse_read_probs(br, 100, sh.a.t1.probs0, &nprobs, &log, &fse_bytes, 9);   /* :176 max_log 100; device cap 9 (D2) */
+            if (e) return e;
+            if (fse_bytes > header) return CZ_E_HUF_FSE_USED_TOO_MANY_BYTES; /* :181 */
+            sh.bc.wt_nprobs = nprobs; sh.bc.wt_log = log; sh.bc.wt_fse_bytes = fse_bytes;
+            return CZ_PARSE_NEED_WTAB;
+        }
+        nprobs = sh.bc.wt_nprobs; log = sh.bc.wt_log; fse_bytes = sh.bc.wt_fse_bytes; (void)nprobs;
         /* the weight bitstream (<= 127 bytes) is read from the LDS stage when it lies inside it: one dependent global
            load per refill otherwise */
         const uint32_t wlo = goff + 1 + fse_bytes, whi = goff + 1 + header;
@@ -484,13 +567,19 @@ __device__ static inline void cz_huf_rank_wave(uint32_t nsym) {
     cz_wave_sync();
 }
 __device__ static __attribute__((noinline)) void cz_huf_fill(uint32_t nsym) {
-    const uint32_t max_bits = sh.huf_max_bits;
-    for (uint32_t s = 0; s < nsym; s++) {
-        const uint32_t b = sh.b.c.hbits[s];
-        if (!b) continue;
-        const uint32_t base = sh.b.c.sym_base[s], len = 1u << (max_bits - b);
-        const uint16_t e = (uint16_t)(s | (b << 8));
-        for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.a.huf[base + k] = e;
+    const uint32_t max_bits = cz_uni(sh.huf_max_bits);
+    /* 64 symbols at a time: every lane fetches the length and the first index of one symbol (one LDS round trip for the
+       chunk instead of one per symbol), then the coded symbols of the chunk are taken in turn from registers and the lanes
+       write the symbol's run together */
+    for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)LANE;
+        const uint32_t bl = s < nsym ? sh.b.c.hbits[s] : 0u, bs = s < nsym ? sh.b.c.sym_base[s] : 0u;
+        for (unsigned long long m = __ballot(bl != 0); m; m &= m - 1) {
+            const int j = cz_unii(__ffsll((long long)m) - 1);
+            const uint32_t b = cz_readlane(bl, j), base = cz_readlane(bs, j), len = 1u << (max_bits - b);
+            const uint16_t e = (uint16_t)((s0 + (uint32_t)j) | (b << 8));
+            for (uint32_t k = (uint32_t)LANE; k < len; k += 64) sh.a.huf[base + k] = e;
+        }
     }
 }
 /* Entries of huf[] are symbol | length << 8; this adds, in bits 12..15, the length of the NEXT symbol when its whole
@@ -573,7 +662,7 @@ __device__ static inline void cz_lit_coop_copy(uint8_t* dst, const CzLit& lit, u
 /* LiteralsSection::parse_from_header (literals_section.cairo:81-175) + the serial parts of
  * decompress_literals (literals_section_decoder.cairo:58-117) + SequencesHeader::parse_from_header
  * (sequence_section.cairo:77-114).  Lane 0; results in sh.bc. */
-__device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, uint32_t bsize, uint32_t stage_hi, int have_literals = 0) {
+__device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, uint32_t bsize, uint32_t stage_hi, int have_literals = 0, int phase = 0) {
     CzBroadcast& bc = sh.bc;
     CzFBits fb; fb.g = blk; fb.stage = sh.a.t1.stage; fb.stage_lo = 0; fb.stage_hi = stage_hi; fb.idx = 0; fb.len = bsize;
     if (bsize == 0) return CZ_E_LS_GETBITS;                             /* :84-90 */
@@ -599,7 +688,7 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, 
         uint32_t off = need, left = comp;
         if (type == 2) {
             uint32_t used, nsym;
-            int e = cz_huf_read_and_rank(blk, left, 0, stage_hi, off, &used, &nsym);
+            int e = cz_huf_read_and_rank(blk, left, 0, stage_hi, off, &used, &nsym, phase);
             if (e) return e;
             bc.huf_fill = 1; bc.huf_nsym = nsym;
             if (used > left) return CZ_E_BLOCK_TRUNCATED;               /* (panic) slice(bytes_read, len) :89 */
@@ -1657,6 +1746,12 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     const int have_literals = !lit_out && lp.cursor != 0;
     if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals);
     __syncthreads();
+    if (cz_unii(bc.err) == CZ_PARSE_NEED_WTAB) {                        /* an FSE-compressed tree description: its table by the wave, then the rest of the parse */
+        cz_huf_weight_table();
+        __syncthreads();
+        if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals, 1);
+        __syncthreads();
+    }
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
     CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
     if (bc.huf_fill) {
@@ -1977,8 +2072,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
     }
     if (!err) {                                                         /* :55-62 HuffmanTable::build_decoder */
         const uint32_t left = len - off > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(len - off);
-        if (LANE == 0) { uint32_t used = 0, nsym = 0; bc.err = cz_huf_read_and_rank(raw, left, 0, 0, 8, &used, &nsym); bc.huf_nsym = nsym; bc.d0 = used; }
+        if (LANE == 0) { uint32_t used = 0, nsym = 0; bc.err = cz_huf_read_and_rank(raw, left, 0, 0, 8, &used, &nsym, 0); bc.huf_nsym = nsym; bc.d0 = used; }
         __syncthreads();
+        if (cz_unii(bc.err) == CZ_PARSE_NEED_WTAB) {
+            cz_huf_weight_table();
+            __syncthreads();
+            if (LANE == 0) { uint32_t used = 0, nsym = 0; bc.err = cz_huf_read_and_rank(raw, left, 0, 0, 8, &used, &nsym, 1); bc.huf_nsym = nsym; bc.d0 = used; }
+            __syncthreads();
+        }
         err = cz_unii(bc.err);
         const uint32_t used = cz_uni((uint32_t)bc.d0), nsym = cz_uni(bc.huf_nsym);
         __syncthreads();
