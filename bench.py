@@ -80,7 +80,7 @@ def _kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cairo_zstd_amd", "csrc")
-    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_exec.hip", "czstd_host.hip", "czstd_types.h"):
+    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_host.hip", "czstd_types.h"):
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--no-verify-all", action="store_true", help="check only a sample of the frames against the oracle (default: every frame, by XXH64)")
     ap.add_argument("--no-chain-prepass", action="store_true", help="run the FSE chains inside cz_decode_frames_kernel (single launch)")
     ap.add_argument("--no-literals-pass", action="store_true", help="decode Huffman literals inside the decode kernel instead of next to the chain pre-pass")
-    ap.add_argument("--exec-kernel", action="store_true", help="execute pre-passed frames on cz_exec_frames_kernel (LDS ring, one workgroup per frame)")
+    ap.add_argument("--no-exec-kernel", dest="exec_kernel", action="store_false", help="diagnostic: pre-passed frames on cz_decode_frames_kernel too, not on cz_execute_frames_kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -195,7 +195,7 @@ def main():
     if chain_prepass:
         ctx.set_chain_arena(arena_bytes)
         ctx.set_exec_kernel(args.exec_kernel)
-        ctx.set_literal_arena(0 if args.no_literals_pass or args.exec_kernel else lit_bytes)
+        ctx.set_literal_arena(0 if args.no_literals_pass else lit_bytes)
 
     def decode():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
@@ -330,7 +330,7 @@ def main():
                           "all_frames_ok": okw}
             del ti, td, to, tr
         ctx.set_chain_arena(arena_bytes if chain_prepass else 0)
-        ctx.set_literal_arena(lit_bytes if chain_prepass and not args.no_literals_pass and not args.exec_kernel else 0)
+        ctx.set_literal_arena(lit_bytes if chain_prepass and not args.no_literals_pass else 0)
 
     # ---- the same batch with a content checksum on every frame, XXH64 computed and
     # compared inside cz_decode_frames_kernel (N=1 only, after the timed region)
@@ -366,9 +366,9 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        lit_pass = chain_prepass and not args.no_literals_pass and not args.exec_kernel
+        lit_pass = chain_prepass and not args.no_literals_pass
         launches = (("cz_scan_kernel x2 + cz_chain_kernel || cz_decode_frames_kernel(literals pass) + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
-                    + ("cz_exec_frames_kernel + " if args.exec_kernel else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
+                    + ("cz_execute_frames_kernel + " if args.exec_kernel and lit_pass else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
             "value": regen_all * args.steps / elapsed / 1e6,

@@ -91,8 +91,6 @@ class Context:
 
     def set_literal_arena(self, nbytes: int):
         """Enable (nbytes > 0) / disable (0) the literals pass that runs next to the pre-pass (cz_context_set_literal_arena)."""
-        if not hasattr(lib(), "cz_context_set_literal_arena"):
-            return
         st = lib().cz_context_set_literal_arena(self._h, nbytes)
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
@@ -100,26 +98,22 @@ class Context:
     def last_prepass_counts(self, n: int):
         """(frames with chain records, frames with literal nodes) of the last batch launch of n frames."""
         a, b = C.c_size_t(), C.c_size_t()
-        if hasattr(lib(), "cz_context_last_prepass_counts"):
-            lib().cz_context_last_prepass_counts(self._h, n, C.byref(a), C.byref(b))
+        lib().cz_context_last_prepass_counts(self._h, n, C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
     def last_literals_tail_ms(self) -> float:
         """Milliseconds the last launch waited for the literals pass after the chain kernel was done."""
-        if not hasattr(lib(), "cz_context_last_literals_tail_ms"):
-            return 0.0
         ms = C.c_float(0)
         lib().cz_context_last_literals_tail_ms(self._h, C.byref(ms))
         return float(ms.value)
 
     def set_exec_kernel(self, on: bool = True):
-        """Frames with chain records run on cz_exec_frames_kernel (default) or on the record path of cz_decode_frames_kernel."""
+        """Frames the pre-pass finished (chain records and literals) run on cz_execute_frames_kernel (default); off: like every
+        other frame, on cz_decode_frames_kernel."""
         lib().cz_context_set_exec_kernel(self._h, 1 if on else 0)
 
     def last_exec_ms(self) -> float:
-        """Milliseconds of the last launch spent in cz_exec_frames_kernel (0 when it did not run)."""
-        if not hasattr(lib(), "cz_context_last_exec_ms"):
-            return 0.0
+        """Milliseconds of the last launch spent in cz_execute_frames_kernel (0 when it did not run)."""
         ms = C.c_float(0)
         st = lib().cz_context_last_exec_ms(self._h, C.byref(ms))
         if st:

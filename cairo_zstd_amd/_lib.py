@@ -33,7 +33,7 @@ class BlockHeader(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the library in-tree with hipcc for gfx950 (csrc/Makefile)."""
-    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_exec.hip", "czstd_types.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_types.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("cairo_zstd_amd.h", "cairo_zstd_amd_status.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -79,20 +79,16 @@ def lib() -> C.CDLL:
     L.cz_context_set_chain_arena.argtypes = [vp, sz]
     L.cz_context_set_verify_checksum.restype = C.c_int
     L.cz_context_set_verify_checksum.argtypes = [vp, C.c_int]
-    if hasattr(L, "cz_context_last_exec_ms"):                          # absent from round-1 experiment builds
-        L.cz_context_last_exec_ms.restype = C.c_int
-        L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
-        L.cz_context_set_exec_kernel.restype = C.c_int
-        L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
-    if hasattr(L, "cz_context_last_prepass_counts"):
-        L.cz_context_last_prepass_counts.restype = C.c_int
-        L.cz_context_last_prepass_counts.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
-    if hasattr(L, "cz_context_last_literals_tail_ms"):
-        L.cz_context_last_literals_tail_ms.restype = C.c_int
-        L.cz_context_last_literals_tail_ms.argtypes = [vp, C.POINTER(C.c_float)]
-    if hasattr(L, "cz_context_set_literal_arena"):
-        L.cz_context_set_literal_arena.restype = C.c_int
-        L.cz_context_set_literal_arena.argtypes = [vp, sz]
+    L.cz_context_last_exec_ms.restype = C.c_int
+    L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cz_context_set_exec_kernel.restype = C.c_int
+    L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
+    L.cz_context_last_prepass_counts.restype = C.c_int
+    L.cz_context_last_prepass_counts.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.cz_context_last_literals_tail_ms.restype = C.c_int
+    L.cz_context_last_literals_tail_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cz_context_set_literal_arena.restype = C.c_int
+    L.cz_context_set_literal_arena.argtypes = [vp, sz]
     L.cz_context_set_chain_min_sequences.restype = C.c_int
     L.cz_context_set_chain_min_sequences.argtypes = [vp, C.c_uint32]
     L.cz_context_read_profile.restype = C.c_int
@@ -134,44 +130,42 @@ def lib() -> C.CDLL:
     L.cz_frame_decoder_read.argtypes = [vp, vp, sz]
     L.cz_frame_decoder_decode_from_to.restype = C.c_int
     L.cz_frame_decoder_decode_from_to.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
-    if hasattr(L, "cz_stream_split"):                                  # absent from round-1 experiment builds
-        L.cz_stream_split.restype = C.c_int
-        L.cz_stream_split.argtypes = [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
-        L.cz_decoder_scratch_create.restype = C.c_int
-        L.cz_decoder_scratch_create.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
-        L.cz_decoder_scratch_reset.restype = C.c_int
-        L.cz_decoder_scratch_reset.argtypes = [vp, C.c_uint64]
-        L.cz_decoder_scratch_destroy.argtypes = [vp]
-        L.cz_decoder_scratch_buffer_len.restype = sz
-        L.cz_decoder_scratch_buffer_len.argtypes = [vp]
-        L.cz_decoder_scratch_total_output.restype = C.c_uint64
-        L.cz_decoder_scratch_total_output.argtypes = [vp]
-        L.cz_decoder_scratch_drain.restype = C.c_int
-        L.cz_decoder_scratch_drain.argtypes = [vp, vp, sz, C.POINTER(sz)]
-        L.cz_decoder_scratch_drain_to_window_size.restype = C.c_int
-        L.cz_decoder_scratch_drain_to_window_size.argtypes = [vp, vp, sz, C.POINTER(sz)]
-        L.cz_decoder_scratch_hash_digest.restype = C.c_uint64
-        L.cz_decoder_scratch_hash_digest.argtypes = [vp]
-        L.cz_block_decoder_new.argtypes = [vp]
-        L.cz_block_decoder_read_block_header.restype = C.c_int
-        L.cz_block_decoder_read_block_header.argtypes = [vp, vp, sz, C.POINTER(BlockHeader), C.POINTER(C.c_uint8)]
-        L.cz_block_decoder_decode_block_content.restype = C.c_int
-        L.cz_block_decoder_decode_block_content.argtypes = [vp, C.POINTER(BlockHeader), vp, vp, sz, u64p]
-        if hasattr(L, "cz_dictionary_decode"):
-            L.cz_dictionary_decode.restype = C.c_int
-            L.cz_dictionary_decode.argtypes = [vp, vp, sz, C.POINTER(vp), u64p]
-            L.cz_dictionary_destroy.argtypes = [vp]
-            L.cz_dictionary_id.restype = C.c_uint32
-            L.cz_dictionary_id.argtypes = [vp]
-            L.cz_dictionary_content_len.restype = sz
-            L.cz_dictionary_content_len.argtypes = [vp]
-            L.cz_dictionary_offset_hist.restype = C.c_int
-            L.cz_dictionary_offset_hist.argtypes = [vp, C.POINTER(C.c_uint32)]
-            L.cz_context_set_dictionary.restype = C.c_int
-            L.cz_context_set_dictionary.argtypes = [vp, vp]
-            L.cz_decoder_scratch_init_from_dict.restype = C.c_int
-            L.cz_decoder_scratch_init_from_dict.argtypes = [vp, vp]
-        L.cz_frame_decoder_scratch.restype = vp
-        L.cz_frame_decoder_scratch.argtypes = [vp]
+    L.cz_stream_split.restype = C.c_int
+    L.cz_stream_split.argtypes = [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(sz)]
+    L.cz_decoder_scratch_create.restype = C.c_int
+    L.cz_decoder_scratch_create.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.cz_decoder_scratch_reset.restype = C.c_int
+    L.cz_decoder_scratch_reset.argtypes = [vp, C.c_uint64]
+    L.cz_decoder_scratch_destroy.argtypes = [vp]
+    L.cz_decoder_scratch_buffer_len.restype = sz
+    L.cz_decoder_scratch_buffer_len.argtypes = [vp]
+    L.cz_decoder_scratch_total_output.restype = C.c_uint64
+    L.cz_decoder_scratch_total_output.argtypes = [vp]
+    L.cz_decoder_scratch_drain.restype = C.c_int
+    L.cz_decoder_scratch_drain.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.cz_decoder_scratch_drain_to_window_size.restype = C.c_int
+    L.cz_decoder_scratch_drain_to_window_size.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.cz_decoder_scratch_hash_digest.restype = C.c_uint64
+    L.cz_decoder_scratch_hash_digest.argtypes = [vp]
+    L.cz_block_decoder_new.argtypes = [vp]
+    L.cz_block_decoder_read_block_header.restype = C.c_int
+    L.cz_block_decoder_read_block_header.argtypes = [vp, vp, sz, C.POINTER(BlockHeader), C.POINTER(C.c_uint8)]
+    L.cz_block_decoder_decode_block_content.restype = C.c_int
+    L.cz_block_decoder_decode_block_content.argtypes = [vp, C.POINTER(BlockHeader), vp, vp, sz, u64p]
+    L.cz_dictionary_decode.restype = C.c_int
+    L.cz_dictionary_decode.argtypes = [vp, vp, sz, C.POINTER(vp), u64p]
+    L.cz_dictionary_destroy.argtypes = [vp]
+    L.cz_dictionary_id.restype = C.c_uint32
+    L.cz_dictionary_id.argtypes = [vp]
+    L.cz_dictionary_content_len.restype = sz
+    L.cz_dictionary_content_len.argtypes = [vp]
+    L.cz_dictionary_offset_hist.restype = C.c_int
+    L.cz_dictionary_offset_hist.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.cz_context_set_dictionary.restype = C.c_int
+    L.cz_context_set_dictionary.argtypes = [vp, vp]
+    L.cz_decoder_scratch_init_from_dict.restype = C.c_int
+    L.cz_decoder_scratch_init_from_dict.argtypes = [vp, vp]
+    L.cz_frame_decoder_scratch.restype = vp
+    L.cz_frame_decoder_scratch.argtypes = [vp]
     _lib = L
     return L

@@ -23,7 +23,12 @@
 
 #include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
 #include "czstd_chain.hip"
-#include "czstd_exec.hip"
+/* the same kernel source once more, without its decoders: cz_execute_frames_kernel (czstd_kernels.hip, CZ_EXEC_ONLY) */
+#define CZ_EXEC_ONLY 1
+namespace czx {
+#include "czstd_kernels.hip"
+}
+#undef CZ_EXEC_ONLY
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -43,9 +48,9 @@ struct cz_context {
     uint8_t* lit_scratch = nullptr; int lit_slots = 0; uint32_t* work_counter = nullptr;
     const struct cz_dictionary* batch_dict = nullptr;                   /* cz_context_set_dictionary */
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
-    bool exec_kernel = false;              /* frames with chain records run on cz_exec_frames_kernel (one workgroup per CU); off by default:
-                                              measured slower than the one-wave record path, DESIGN.md §5 */
-    int exec_grid = 0; bool exec_attr_set = false;
+    bool exec_kernel = true;               /* frames the pre-pass finished (chain records + literals) run on cz_execute_frames_kernel; 0: all on cz_decode_frames_kernel */
+    int exec_grid = 0;
+    uint32_t* fallback_list = nullptr;                                  /* n entries, allocated with frame_first */
     int last_grid = 0;
     int last_hip_error = 0;
     /* staging for cz_decode_batch_host */
@@ -136,6 +141,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->blk_desc) (void)hipFree(c->blk_desc);
     if (c->scan_ctl) (void)hipFree(c->scan_ctl);
     if (c->frame_order) (void)hipFree(c->frame_order);
+    if (c->fallback_list) (void)hipFree(c->fallback_list);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
@@ -187,12 +193,10 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (!bytes) return CZ_OK;
     if (bytes < 4096) bytes = 4096;                                     /* header indices 0..63 are reserved (sink of the chain step) */
     if (!c->chain_top) { CZ_HIP(c, hipMalloc((void**)&c->chain_top, 64)); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
-    if (!c->exec_attr_set) {
-        /* cz_exec_frames_kernel: 128 KiB output ring + chunk summaries in dynamic LDS, one workgroup per CU */
-        CZ_HIP(c, hipFuncSetAttribute((const void*)cz_exec_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CZX_LDS_BYTES));
+    if (!c->exec_grid) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_exec_frames_kernel, CZX_THREADS, CZX_LDS_BYTES) != hipSuccess || occ <= 0) occ = 1;
-        c->exec_grid = c->num_cu * occ; c->exec_attr_set = true;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, czx::cz_execute_frames_kernel, CZ_WG_THREADS, CZ_EXEC_DYN_LDS) != hipSuccess || occ <= 0) occ = 4;
+        c->exec_grid = c->num_cu * occ;
     }
     CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
     c->chain_capacity = bytes / 8;
@@ -234,7 +238,7 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
-/* Frames that have chain records run on cz_exec_frames_kernel (default) or on cz_decode_frames_kernel's record path (0). */
+/* Frames the pre-pass finished run on cz_execute_frames_kernel (default, 1) or, like every other frame, on cz_decode_frames_kernel (0). */
 CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; return CZ_OK; }
 
 CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
@@ -274,14 +278,14 @@ CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 
-/* Part of the last launch spent in cz_exec_frames_kernel (0 when it did not run). */
+/* Part of the last launch spent in cz_execute_frames_kernel (0 when it did not run). */
 CZ_EXPORT int cz_context_last_exec_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
     *ms = 0.0f;
     if (!c->timed || !c->timed_exec) return CZ_OK;
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipEventSynchronize(c->ev_stop));
-    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_mid, c->ev_mid2));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->timed_lit ? c->ev_lit : c->ev_mid, c->ev_mid2));
     return CZ_OK;
 }
 
@@ -314,6 +318,9 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (c->frame_order) (void)hipFree(c->frame_order);
             c->frame_order = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->frame_order, n * 4));
+            if (c->fallback_list) (void)hipFree(c->fallback_list);
+            c->fallback_list = nullptr;
+            CZ_HIP(c, hipMalloc((void**)&c->fallback_list, n * 4));
         }
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
@@ -357,12 +364,12 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         } else c->timed_lit = false;
         c->timed_chain = true;
         c->timed_exec = false;
-        if (c->exec_kernel && !a.verify_checksum && (size_t)c->grid_max >= (size_t)c->exec_grid) {
-            /* pass B: one workgroup per CU executes the frames that got chain records; what it cannot
-               finish (any irregularity) stays for pass C */
-            a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24);
+        if (c->exec_kernel && lit_pass && !c->batch_dict) {
+            /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of
+               its own); it lists every other frame for the launch below */
+            a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list;
             const int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
-            hipLaunchKernelGGL(cz_exec_frames_kernel, dim3(egrid), dim3(CZX_THREADS), CZX_LDS_BYTES, c->stream, a);
+            hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
             c->timed_exec = true;

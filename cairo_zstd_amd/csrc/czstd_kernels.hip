@@ -69,6 +69,7 @@ __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_un
 enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CHAIN, CZ_P_EXTRACT, CZ_P_LITCOPY, CZ_P_MATCH, CZ_P_RAWRLE, CZ_P_OTHER,
        CZ_P_HUF_SPEC, CZ_P_HUF_SYNC, CZ_P_HUF_WRITE,                  /* sub-phases of CZ_P_HUFDEC (counted in both) */
        CZ_P_N_FAST, CZ_P_N_GENERAL, CZ_P_N_ROUNDS, CZ_P_N_BIG, CZ_P_COUNT };   /* counts: chunks on the LDS path / the general path, dependency rounds and wave-wide copies of the general path */
+#define CZX_FALLBACK 0x7FF00001   /* internal: cz_execute_frames_kernel met a block it has no pre-pass results for; the frame goes to cz_decode_frames_kernel */
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
@@ -108,6 +109,29 @@ struct CzBroadcast {
  * The Huffman table is the only carried item that does not stay in LDS: when a block that
  * created one is not the last block it is spilled to a 4 KiB global slot and re-read by
  * Treeless blocks (literals_section_decoder.cairo:82-86). */
+#ifdef CZ_EXEC_ONLY
+/* cz_execute_frames_kernel (this file compiled a second time, in namespace czx, with CZ_EXEC_ONLY): frames whose FSE chains
+ * and Huffman literals were done by the pre-pass need no decoding tables, no bit ring and no Huffman table: what is left is
+ * the chunk buffer, the block-head stage of the header parser and the broadcast slots (1.9 KB + 1 280 B of state->code maps). */
+struct CzShared {
+    uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
+    union {
+        uint16_t huf[512];                                              /* cz_xxh64_frame stages 2 x 512 B here */
+        struct { uint8_t stage[512]; } t1;
+        struct { __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16]; } t4;
+    } a;
+    struct { struct { uint32_t llml[96]; } c; } b;
+    CzBroadcast bc;
+    uint32_t frame_idx;
+    uint32_t rec_general, rec_misses, rec_next;   /* the frame in flight has left cz_sequences_rec_fast for the general loop; chunks of the block in hand
+                                                     that loop left to the general form; where it stopped */
+    uint32_t dict_lag[2];
+    uint32_t dict_ptr[2], dict_len[2];
+#ifdef CZ_PROFILE
+    unsigned long long prof[CZ_P_COUNT];
+#endif
+};
+#else
 struct CzShared {
     uint32_t hist[3]; int32_t fse_rle[3]; uint8_t fse_log[3]; uint8_t huf_max_bits;
     union {
@@ -115,13 +139,15 @@ struct CzShared {
         struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; uint32_t rank_cnt[16], rank_idx[16]; } t1;
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
         struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64];
-                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64]; } t4;   /* + one dump byte per lane */   /* mirror[8..15] == ring[2040..2047] */
+                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16]; } t4;   /* + one dump byte per lane (+ 7: cz_fast_group) */   /* mirror[8..15] == ring[2040..2047] */
     } a;
     struct {
         struct { __attribute__((aligned(4))) uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
     } b;
     CzBroadcast bc;
     uint32_t frame_idx;
+    uint32_t rec_general, rec_misses, rec_next;   /* the frame in flight has left cz_sequences_rec_fast for the general loop; chunks of the block in hand
+                                                     that loop left to the general form; where it stopped */
     uint32_t dict_lag[2];               /* cz_device_frame_state.dict_lag of the frame in flight (lo, hi) */
     uint32_t dict_ptr[2], dict_len[2];  /* DecodeBuffer.dict_content of the frame in flight: kept here, not in registers — only the rare
                                            dictionary arm of the match copy reads them */
@@ -133,6 +159,7 @@ struct CzShared {
  * LDS address space (ds_* instructions, lgkmcnt only).  Passing it by reference through a function
  * that is not inlined turns the accesses into flat_* instructions, whose waits also cover every
  * outstanding global load. */
+#endif
 __shared__ CzShared sh;
 CZ_DYNAMIC_LDS(cz_dyn_lds);                                             /* CZ_FSE_LDS_BYTES: the three FSE decoding tables */
 #define CZ_FSE_LL (cz_dyn_lds)          /* 512 entries */
@@ -175,6 +202,13 @@ __device__ static inline uint32_t cz_wave_incl_scan(uint32_t v) {
     return v;
 }
 __device__ static inline uint32_t cz_readlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+/* The lanes of a wave execute an instruction together, so the LDS writes of one instruction are all done before those of the next
+ * begin; the CPU emulator of tests/emu runs lanes as threads and needs a barrier where the kernels rely on that. */
+#ifdef CZ_EMU
+#define CZ_LOCKSTEP() cz_wave_sync()
+#else
+#define CZ_LOCKSTEP() asm volatile("" ::: "memory")   /* no instruction; the compiler must keep the program order of the LDS writes around it (it sees one lane, for which they never alias) */
+#endif
 /* A workgroup is ONE wave (CZ_WG_THREADS == 64): its LDS and vector-memory instructions execute in
  * program order, so making one lane's write visible to another lane's later read needs no wait and
  * no s_barrier — only that the compiler keeps the order. */
@@ -300,6 +334,7 @@ __device__ static inline uint32_t cz_fse_code_bits(const uint32_t* llml, uint32_
     return 0;
 }
 
+#ifndef CZ_EXEC_ONLY
 /* read_probabilities (fse_decoder.cairo:258-368); probs -> LDS.  One lane. */
 /* (the body is force-inlined where the callers' pointers are known to be LDS: a generic pointer that crosses a function call makes
    every access a flat_* instruction, which waits for global memory too — cz_chain_kernel's table set-up calls the _inl form) */
@@ -615,6 +650,7 @@ __device__ static __attribute__((noinline)) void cz_huf_stream(cz_gcptr src, uin
     *count = n; *flags = (rb.remaining != 0) ? 2u : 0u;                 /* :234-241 */
 }
 
+#endif /* !CZ_EXEC_ONLY */
 /* ------------------------------------------------------------------ frame / block headers */
 /* read_frame_header + window_size (frame.cairo:152-284, :106-129).  Lane 0. */
 __device__ static __attribute__((noinline)) int cz_parse_frame_header(cz_gcptr p, uint64_t len, CzBroadcast& bc) {
@@ -683,6 +719,9 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, 
     const uint32_t upper = type >= 2 ? comp : (type == 1 ? 1u : regen); /* block_decoder.cairo:160-172 */
     if (bsize - need < upper) return CZ_E_MALFORMED_SECTION_HEADER;     /* block_decoder.cairo:174 */
     bc.lit_type = type; bc.regen = regen; bc.nstreams = streams; bc.lit_total = need + upper; bc.huf_fill = 0;
+#ifdef CZ_EXEC_ONLY
+    if (type >= 2 && !have_literals) return CZX_FALLBACK;
+#else
     if (type >= 2 && !have_literals) {                                  /* literals_section_decoder.cairo:64-117 (skipped when the literals pass
                                                                            already decoded this block's literals, tree included) */
         uint32_t off = need, left = comp;
@@ -707,6 +746,7 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, 
             bc.stream_off[3] = off + j3; bc.stream_len[3] = left - j3;
         } else { bc.stream_off[0] = off; bc.stream_len[0] = left; }
     }
+#endif
     /* sequences header (read early; its error is only reported after the literals decoded) */
     const uint32_t so = need + upper, sl = bsize - so;
     bc.seq_hdr_err = 0; bc.nseq = 0; bc.seq_modes = 0; bc.seq_body_off = so;
@@ -740,6 +780,7 @@ __device__ static inline void cz_store_upto16(cz_gptr d, uint4 v, uint32_t m) {
     if (m & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(d, &h, 2); d += 2; v.x >>= 16; }
     if (m & 1u) *d = (uint8_t)v.x;
 }
+#ifndef CZ_EXEC_ONLY
 /* ---- self-synchronising parallel huff0 decode ---------------------------------------------
  * A huff0 stream is a prefix code read in one direction, and prefix codes resynchronise: a
  * decoder started in the middle of a codeword falls back onto true codeword boundaries after a
@@ -841,7 +882,7 @@ __device__ static inline uint32_t cz_gb_interval(CzGBits& g, uint32_t mb, int32_
                 /* the last interval of a range (or a stream that runs over its capacity): exactly the bytes that are there,
                    in at most seven stores (lanes end their ranges at different iterations, so this runs often) */
                 const uint32_t room = n0 < cap ? cap - n0 : 0u, m = n < room ? n : room;
-                cz_store_upto16(out + n0, v, m < 16u ? m : 16u);
+                (cz_store_upto16)(out + n0, v, m < 16u ? m : 16u);
 #pragma unroll
                 for (uint32_t t = 16; t < CZ_GB_SYMS - 1; t++) if (t < m) out[n0 + t] = (uint8_t)(word[4] >> (8 * (t & 3)));
             }
@@ -1021,6 +1062,7 @@ __device__ static __attribute__((noinline)) int cz_parse_seq_tables(cz_gcptr blk
     return 0;
 }
 
+#endif /* !CZ_EXEC_ONLY */
 /* sequence_execution.cairo:85-129; returns the actual offset (0 = ZeroOffset) */
 __device__ static inline uint32_t cz_offset_history(uint32_t ov, uint32_t ll, uint32_t& h0, uint32_t& h1, uint32_t& h2) {
     uint32_t a;
@@ -1069,8 +1111,8 @@ __device__ static inline void cz_lane_copy32(cz_gptr d, cz_gcptr s, uint32_t n, 
     const uint4 a = cz_load_upto16(s, n, wholeA);
     uint4 b = uint4{0, 0, 0, 0};
     if (nb) b = cz_load_upto16(s + 16, nb, wholeB);
-    cz_store_upto16(d, a, n);
-    if (nb) cz_store_upto16(d + 16, b, nb);
+    (cz_store_upto16)(d, a, n);
+    if (nb) (cz_store_upto16)(d + 16, b, nb);
 }
 /* Up to four runs of at most CZ_QCOPY_MAX bytes at once, sixteen lanes x 16 bytes per step each: run g (source s, n bytes;
    n == 0: none) belongs to lanes 16g..16g+15.  src_lim: no 16-byte load may reach beyond it (the tail is then read byte
@@ -1083,7 +1125,7 @@ __device__ static inline void cz_quarter_copy(cz_gptr d, cz_gcptr s, uint32_t n,
         if (pos < n) {
             const uint32_t m = n - pos < 16u ? n - pos : 16u;
             const uint4 v = cz_load_upto16(s + pos, m, s + pos + 16 <= src_lim);
-            cz_store_upto16(d + pos, v, m);
+            (cz_store_upto16)(d + pos, v, m);
         }
     }
 }
@@ -1252,7 +1294,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
     {
         cz_gptr od = (cz_gptr)x.out + out_start; cz_gcptr lsrc = (cz_gcptr)lit.p + lit_start; cz_gcptr llim = (cz_gcptr)lit.p + lit.len;
         if (lit.rle) {
-            if (active && ll > 0 && ll <= 32) { const uint32_t w = 0x01010101u * lit.byte; const uint4 v = uint4{w, w, w, w}; cz_store_upto16(od, v, ll); if (ll > 16) cz_store_upto16(od + 16, v, ll - 16); }
+            if (active && ll > 0 && ll <= 32) { const uint32_t w = 0x01010101u * lit.byte; const uint4 v = uint4{w, w, w, w}; (cz_store_upto16)(od, v, ll); if (ll > 16) (cz_store_upto16)(od + 16, v, ll - 16); }
         } else if (active && ll > 0 && ll <= 32) cz_lane_copy32(od, lsrc, ll, lsrc + 16 <= llim, lsrc + 32 <= llim);
         unsigned long long qm = __ballot(ll > 32 && ll <= CZ_QCOPY_MAX && !lit.rle);
         while (qm) {
@@ -1366,6 +1408,7 @@ __device__ static int cz_execute_chunk(CzExecCtx& x, const CzLit& lit, uint32_t 
  * ABSOLUTE address (ring[a & 2047]) so that global and LDS accesses are both 16-byte aligned.
  * Bytes outside [S, E) are written as zero, which is exactly the reference reader's
  * zero-extension below bit 0 (bit_reader_reverse.cairo:147-159). */
+#ifndef CZ_EXEC_ONLY
 __device__ static void cz_ring_load_block(const uint8_t* S, const uint8_t* E, uintptr_t block) {
     const uintptr_t a = block + 16u * (uintptr_t)LANE;
     uint4 v;
@@ -1388,6 +1431,7 @@ __device__ static inline uint64_t cz_ring_window(uint32_t sbits, int32_t t) {
     const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> r), lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> r);
     return ((uint64_t)hi << 32) | lo;
 }
+#endif /* !CZ_EXEC_ONLY */
 /* n-bit field (n <= 32) starting o bits below the top of W (o + n <= 64) */
 __device__ static inline uint32_t cz_field(uint64_t W, uint32_t o, uint32_t n) { return (uint32_t)(((W << o) >> 1) >> (63 - n)); }
 
@@ -1457,6 +1501,7 @@ __device__ static int cz_history_and_execute(CzExecCtx& x, const CzLit& lit, uin
     return cz_execute_chunk(x, lit, cnt, ll, ml, actual);
 }
 
+#ifndef CZ_EXEC_ONLY
 /* decode_sequences + execute_sequences for one block.  All lanes.
  * sequence_section_decoder.cairo:35-297, sequence_execution.cairo:12-83.
  * Lane 0 runs only the serial core of the three interleaved FSE state machines (one LDS
@@ -1628,6 +1673,7 @@ __device__ static int cz_sequences(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, c
     return 0;
 }
 
+#endif /* !CZ_EXEC_ONLY */
 /* Same as cz_sequences, for a block whose FSE chain was already run by cz_chain_kernel: every
  * sequence has an 8-byte record in the chain arena — low word = the 32 stream bits that start with
  * the sequence's extra bits (OF, ML, LL; sequence_section_decoder.cairo:239-256), high word = LL state |
@@ -1646,10 +1692,18 @@ __device__ static inline uint64_t cz_stream_window64(cz_gcptr S, uint32_t p) {
     if (drop) { const uint32_t lo = hb - 8 >= 0 ? S[hb - 8] : 0u; v = (v << drop) | (lo >> (8 - drop)); }
     return v;
 }
-__device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& lit, cz_gcptr64 maps, cz_gcptr64 rec,
-                                                   uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
-    uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapml = mapll + 512; uint8_t* mapof = mapll + 1024;
-    CZ_PROF_DECL; CZ_PROF_T0();
+/* ---- the record-driven chunk loops -----------------------------------------------------------------------------------
+ * cz_sequences_rec_general  the loop over chunks of 64 records in its general form: cz_chunk_plan + cz_chunk_copy per chunk (all
+ *                           checks in the reference's order, dictionary reach, long runs, wide records, partial chunks).
+ * cz_sequences_rec_fast     the same loop for frames whose positions fit 32 bits, as long as the chunks are full chunks of short
+ *                           sequences: everything uniform lives in scalar registers, positions are 32-bit offsets from two scalar
+ *                           bases, the two prefix sums are one packed scan, and the chunk is assembled in LDS without a predicate
+ *                           per match byte (cz_fast_group).  A chunk it cannot take goes, untouched, through the general form
+ *                           (one call); after a few of those it hands the rest of the block — and of the frame — to the general loop.
+ * Each is a function of its own (not inlined): the register allocation of one does not pay for the other's live values. */
+/* the state -> code maps of the tables the block defined, from its arena header into the LDS that holds FSE tables otherwise */
+__device__ static inline void cz_rec_load_maps(cz_gcptr64 maps, uint32_t mapflags) {
+    uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapof = mapll + 1024;
     __syncthreads();
     {
         const uint32_t half = (uint32_t)LANE >> 5, j = (uint32_t)LANE & 31;           /* 32 lanes x 16 B per 512-byte map */
@@ -1657,29 +1711,40 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
         if (((mapflags >> 1) & 1u) && LANE < 16) { uint4 v; __builtin_memcpy(&v, (cz_gcptr)maps + 1024u + 16u * (uint32_t)LANE, 16); *(uint4*)(mapof + 16u * (uint32_t)LANE) = v; }
     }
     __syncthreads();
+}
+__device__ static inline uint32_t cz_rec_values(uint64_t r, cz_gcptr bits, uint32_t& ll, uint32_t& ml) {
+    const uint8_t* mapll = (const uint8_t*)CZ_FSE_LL; const uint8_t* mapml = mapll + 512; const uint8_t* mapof = mapll + 1024;
+    const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
+    const uint32_t oc = mapof[(st >> 18) & 255];
+    const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
+    const uint32_t mx = tm >> 24, lx = tl >> 24;
+    uint32_t ov;
+    if (!(st & CZC_REC_WIDE)) {                                         /* <= 32 extra bits: they are the top of the record's low word */
+        ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);       /* :243 */
+        ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);     /* :249-256 */
+        ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+    } else {                                                            /* the low word says where the extra bits are in the bitstream */
+        const uint64_t W = cz_stream_window64(bits, xt);
+        ov = (1u << oc) + cz_field(W, 0, oc);
+        ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);
+        ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
+    }
+    return ov;
+}
+/* chunks [first, nseq) of a block; history in sh.hist, positions in xref.  The execution context is worked on in registers
+   (wave-uniform) and written back once. */
+__device__ static __attribute__((noinline)) int cz_sequences_rec_general(CzExecCtx& xref, const CzLit lit, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, uint32_t first) {
+    CzExecCtx x = xref;
+    x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
+    x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
+    CZ_PROF_DECL; CZ_PROF_T0();
     int exec_err = 0;
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
-    CZ_PROF_ACC(CZ_P_RING);
-    auto load_rec = [&](uint32_t first) -> uint64_t { return first + (uint32_t)LANE < nseq ? rec[first + (uint32_t)LANE] : 0; };   /* coalesced 8-byte loads */
-    auto plan = [&](uint64_t r, uint32_t first, uint64_t produced, uint32_t lit_used) -> CzPlan {
-        const uint32_t cnt = nseq - first < 64 ? nseq - first : 64;
+    auto load_rec = [&](uint32_t at) -> uint64_t { return at + (uint32_t)LANE < nseq ? rec[at + (uint32_t)LANE] : 0; };   /* coalesced 8-byte loads */
+    auto plan = [&](uint64_t r, uint32_t at, uint64_t produced, uint32_t lit_used) -> CzPlan {
+        const uint32_t cnt = nseq - at < 64 ? nseq - at : 64;
         uint32_t ll = 0, ml = 0, ov = 4;
-        if ((uint32_t)LANE < cnt) {
-            const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
-            const uint32_t oc = mapof[(st >> 18) & 255];
-            const uint32_t tl = sh.b.c.llml[mapll[st & 511]], tm = sh.b.c.llml[40 + mapml[(st >> 9) & 511]];
-            const uint32_t mx = tm >> 24, lx = tl >> 24;
-            if (!(st & CZC_REC_WIDE)) {                                 /* <= 32 extra bits: they are the top of the record's low word */
-                ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);   /* :243 */
-                ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);     /* :249-256 */
-                ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
-            } else {                                                    /* the low word says where the extra bits are in the bitstream */
-                const uint64_t W = cz_stream_window64(bits, xt);
-                ov = (1u << oc) + cz_field(W, 0, oc);
-                ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);
-                ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
-            }
-        }
+        if ((uint32_t)LANE < cnt) ov = cz_rec_values(r, bits, ll, ml);
 #ifdef CZ_EXP_NOHIST   /* diagnostic only (wrong output): instruction count of the chunk loop without the repeat-offset scan */
         const uint32_t actual = ov > 3 ? ov - 3 : h0 + ov;
 #else
@@ -1690,8 +1755,8 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
     /* Records are loaded three chunks ahead; each chunk is planned (codes -> values, repeat offsets,
      * positions, every check) and then copied.  (Planning a chunk ahead of the copy and touching its
      * source lines early was measured: once no access was a flat_* one it no longer paid.) */
-    uint64_t r1 = load_rec(0), r2 = load_rec(64), r3 = load_rec(128);
-    for (uint32_t done = 0; done < nseq; done += 64) {
+    uint64_t r1 = load_rec(first), r2 = load_rec(first + 64), r3 = load_rec(first + 128);
+    for (uint32_t done = first; done < nseq; done += 64) {
         const CzPlan cur = plan(r1, done, x.produced, x.lit_used);
         r1 = r2; r2 = r3; r3 = load_rec(done + 192);
         if (cur.err > 0) return cur.err;
@@ -1706,6 +1771,188 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
         cz_wave_sync();
     }
     if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
+    xref.produced = x.produced; xref.lit_used = x.lit_used;
+    return 0;
+}
+/* one chunk in the general form, for the fast loop; history in sh.hist, positions in x */
+__device__ static __attribute__((noinline)) int cz_rec_chunk_general(CzExecCtx& x, const CzLit& lit, uint64_t r, uint32_t cnt, cz_gcptr bits) {
+    uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
+    uint32_t ll = 0, ml = 0, ov = 4;
+    if ((uint32_t)LANE < cnt) ov = cz_rec_values(r, bits, ll, ml);
+    const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
+    const CzPlan cur = cz_chunk_plan(x, x.produced, x.lit_used, lit, cnt, ll, ml, actual);
+    cz_wave_sync();
+    if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
+    cz_wave_sync();
+    if (cur.err > 0) return cur.err;
+    return cz_chunk_copy(x, lit, cur);
+}
+/* unaligned loads from global memory (the sizes are literals: a size that depends on a template parameter makes the builtin an ordinary call) */
+__device__ static inline uint32_t cz_ldu16(cz_gcptr p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ static inline uint32_t cz_ldu32(cz_gcptr p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static inline uint64_t cz_ldu64(cz_gcptr p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ static inline uint4 cz_ldu128(cz_gcptr p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+/* First bytes of every lane's literal run and match into the chunk buffer: NL literal bytes, NMB match bytes, every load
+ * before the first LDS write.  Match bytes go first, from the LAST byte down, without a predicate: a byte a lane writes beyond
+ * its own match lands on a position whose true owner — a later sequence's match byte of lower index, or a literal byte —
+ * is written after it (LDS writes of one wave execute in program order), so the true bytes win.  Lanes whose match reads this
+ * chunk's own output write what they loaded all the same; the dependency rounds redo them.  Literal bytes follow, each
+ * with its own predicate (address select to a dump byte).  Source addresses are 32-bit offsets from two uniform bases. */
+template <int NL, int NMB>
+__device__ static inline void cz_fast_group(uint8_t* ob, uint32_t orel, uint32_t drel, uint32_t ll, cz_gcptr lbase, uint32_t loff, int lit_rle, uint32_t rle_word,
+                                            cz_gcptr obase, uint32_t moff) {
+    uint32_t lw[2] = {rle_word, rle_word}, mw[4] = {0, 0, 0, 0};
+    if (!lit_rle) {
+        if (NL <= 2) lw[0] = cz_ldu16(lbase + loff);
+        else if (NL <= 4) lw[0] = cz_ldu32(lbase + loff);
+        else { const uint64_t t = cz_ldu64(lbase + loff); lw[0] = (uint32_t)t; lw[1] = (uint32_t)(t >> 32); }
+    }
+    if (NMB == 4) mw[0] = cz_ldu32(obase + moff);
+    else if (NMB == 8) { const uint64_t t = cz_ldu64(obase + moff); mw[0] = (uint32_t)t; mw[1] = (uint32_t)(t >> 32); }
+    else { const uint4 t = cz_ldu128(obase + moff); mw[0] = t.x; mw[1] = t.y; mw[2] = t.z; mw[3] = t.w; }
+    uint8_t* const md = ob + drel;
+#pragma unroll
+    for (int j = NMB - 1; j >= 0; j--) { md[j] = (uint8_t)(mw[j >> 2] >> (8 * (j & 3))); CZ_LOCKSTEP(); }
+    const uint32_t dump = CZ_OBUF_BYTES + 16 + (uint32_t)LANE;
+#pragma unroll
+    for (int j = NL - 1; j >= 0; j--) { ob[((uint32_t)j < ll ? orel : dump) + (uint32_t)j] = (uint8_t)(lw[j >> 2] >> (8 * (j & 3))); CZ_LOCKSTEP(); }
+}
+#define CZ_FAST_MISSES 6u   /* chunks of a block the fast loop may leave to the general form before it hands over the rest */
+/* returns 0 (block done), a status, or -1: sh.rec_next is the first chunk not done — positions in xref, history in sh.hist.
+   (The count of chunks left to the general form lives in LDS: one more loop-carried scalar costs this loop a fifth of its speed.) */
+__device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec_, uint32_t nseq_, uint32_t mapflags, cz_gcptr bits_) {
+    CZ_PROF_DECL; CZ_PROF_T0();
+    cz_rec_load_maps(maps, mapflags);
+    /* uniform state of the block, in scalar registers */
+    const uint32_t nseq = cz_uni(nseq_);
+    cz_gcptr64 rec = (cz_gcptr64)cz_uni64((uint64_t)(uintptr_t)rec_);
+    cz_gcptr bits = (cz_gcptr)cz_uni64((uint64_t)(uintptr_t)bits_);
+    cz_gptr obase = (cz_gptr)cz_uni64((uint64_t)(uintptr_t)xref.out);
+    cz_gcptr lbase = (cz_gcptr)cz_uni64((uint64_t)(uintptr_t)lit.p);
+    const uint32_t lit_len = cz_uni(lit.len), rle_word = 0x01010101u * cz_uni((uint32_t)lit.byte);
+    const int lit_rle = cz_unii((int)lit.rle);
+    const uint32_t cap = cz_uni((uint32_t)xref.cap);
+    uint32_t P = cz_uni((uint32_t)xref.produced), lit_used = cz_uni(xref.lit_used);
+    uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
+    uint8_t* const ob = sh.a.t4.obuf;
+    auto load_rec = [&](uint32_t first) -> uint64_t { const uint32_t i = first + (uint32_t)LANE; return rec[i < nseq ? i : nseq - 1]; };   /* coalesced 8-byte loads */
+    uint64_t r1 = load_rec(0), r2 = load_rec(64), r3 = load_rec(128);
+    uint32_t done = 0;
+    for (; done < nseq; done += 64) {
+        const uint64_t r = r1;
+        r1 = r2; r2 = r3; r3 = load_rec(done + 192);
+        int took = 0;
+        if (nseq - done >= 64 && !__ballot((uint32_t)(r >> 32) & CZC_REC_WIDE)) {
+            const uint32_t s0 = h0, s1 = h1, s2 = h2;                   /* the history is put back when the chunk is left to the general form */
+            uint32_t ll, ml;
+            const uint32_t ov = cz_rec_values(r, bits, ll, ml);
+            const uint32_t off = cz_history(64u, ll, ov, h0, h1, h2);
+            CZ_PROF_ACC(CZ_P_EXTRACT);
+            /* both prefix sums in one scan: literal lengths in the low half, output lengths in the high half (runs of at most
+               8 / 16 bytes here: the sums stay far below 65 536) */
+            const uint32_t tot = ll + ml;
+            const int small = !__ballot(ll > 8u || ml > 16u);
+            const uint32_t pk = ll | (tot << 16), incl = cz_wave_incl_scan(pk), sums = cz_readlane(incl, 63);
+            const uint32_t sum_ll = sums & 0xFFFFu, sum_tot = sums >> 16;
+            const uint32_t excl = incl - pk, lrel = excl & 0xFFFFu, orel = excl >> 16, drel = orel + ll;
+            const uint32_t d = P + drel;                                /* where the match goes */
+            /* sequence_execution.cairo:28-36 (literals), :47 (zero offset), decode_buffer.cairo:65 (offset beyond the output so far),
+               and the capacity of the caller's buffer; the 8-byte literal loads must stay inside the literal buffer */
+            const int bad = (off - 1u >= d) | (d + ml > cap);
+            if (small && sum_tot <= CZ_OBUF_BYTES && !__ballot(bad) && lit_used + sum_ll + 8u <= lit_len) {
+                const uint32_t span = off < ml ? off : ml;
+                const int32_t srel = (int32_t)drel - (int32_t)off, send = srel + (int32_t)span;   /* source range relative to the chunk, clipped to the match's own start */
+                const int near = send > 0;
+                if (!__ballot(!near && off < ml)) {                     /* (a far match that overlaps itself: the general form does the period) */
+                    const uint32_t loff = lit_used + lrel, moff = d - off;
+                    const unsigned long long big = __ballot(ll > 4u || ml > 8u), mid = __ballot(ll > 2u || ml > 4u);
+                    if (!mid) cz_fast_group<2, 4>(ob, orel, drel, ll, lbase, loff, lit_rle, rle_word, (cz_gcptr)obase, moff);
+                    else if (!big) cz_fast_group<4, 8>(ob, orel, drel, ll, lbase, loff, lit_rle, rle_word, (cz_gcptr)obase, moff);
+                    else cz_fast_group<8, 16>(ob, orel, drel, ll, lbase, loff, lit_rle, rle_word, (cz_gcptr)obase, moff);
+                    cz_wave_sync();
+                    CZ_PROF_ACC(CZ_P_LITCOPY);
+                    /* matches that read this chunk's output: rounds.  W = destination of the first undone match; a match may go
+                       once its source range (clipped to its own destination) lies below W. */
+                    cz_gcptr cout = (cz_gcptr)obase + P;
+                    int undone = near;
+                    for (;;) {
+                        const unsigned long long pend = __ballot(undone);
+                        if (!pend) break;
+                        const int32_t W = (int32_t)cz_readlane(drel, cz_unii(__ffsll((long long)pend) - 1));
+                        if (undone && send <= W) {
+                            uint32_t idx = 0;
+                            for (uint32_t k = 0; k < ml; k++) {
+                                const int32_t q = srel + (int32_t)idx;
+                                ob[drel + k] = q < 0 ? cout[q] : ob[q];
+                                idx = idx + 1 == off ? 0 : idx + 1;
+                            }
+                            undone = 0;
+                        }
+                        cz_wave_sync();
+                    }
+                    /* write the assembled chunk: 4 bytes per lane per pass (the global address need not be aligned).  Later loads
+                       of these bytes by this wave are ordered behind the stores by the memory pipeline. */
+                    for (uint32_t i = 4u * (uint32_t)LANE; i < sum_tot; i += 256) {
+                        if (i + 4 <= sum_tot) { const uint32_t w = *(const uint32_t*)(ob + i); __builtin_memcpy(obase + (P + i), &w, 4); }
+                        else for (uint32_t j = i; j < sum_tot; j++) obase[P + j] = ob[j];
+                    }
+                    cz_wave_sync();
+                    CZ_PROF_ACC(CZ_P_MATCH);
+                    P += sum_tot; lit_used += sum_ll; took = 1;
+                    CZ_PROF_CNT(CZ_P_N_FAST);
+                }
+            }
+            if (!took) { h0 = s0; h1 = s1; h2 = s2; }
+        }
+        if (!took) {
+            cz_wave_sync();
+            if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; sh.rec_next = done; sh.rec_misses += 1; }
+            cz_wave_sync();
+            xref.produced = P; xref.lit_used = lit_used;
+            if (cz_uni(sh.rec_misses) > CZ_FAST_MISSES && nseq - done > 64) return -1;
+            const int e = cz_rec_chunk_general(xref, lit, r, nseq - done < 64 ? nseq - done : 64, bits);
+            if (e) return e;
+            cz_wave_sync();
+            P = cz_uni((uint32_t)xref.produced); lit_used = cz_uni(xref.lit_used);
+            h0 = cz_uni(sh.hist[0]); h1 = cz_uni(sh.hist[1]); h2 = cz_uni(sh.hist[2]);
+            CZ_PROF_T0();
+        }
+    }
+    cz_wave_sync();
+    if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
+    xref.produced = P; xref.lit_used = lit_used;
+    if (lit_used < lit_len) {                                           /* sequence_execution.cairo:72-78 */
+        const uint32_t rest = lit_len - lit_used;
+        if (xref.produced + rest > xref.cap) return CZ_E_OUTPUT_TOO_SMALL;
+        cz_lit_coop_copy(xref.out + xref.produced, lit, lit_used, rest);
+        xref.produced += rest; xref.lit_used = lit_len;
+    }
+    __syncthreads();
+    return 0;
+}
+
+/* One block whose sequences cz_chain_kernel left as records (header: maps of the tables it defined, then the records). */
+__device__ static int cz_sequences_rec(CzExecCtx& x, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec, uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
+    CZ_PROF_DECL; CZ_PROF_T0();
+    /* the fast loop wants every position of the frame in 32 bits, no drained bytes and no dictionary content (then offset <=
+       position is the whole reach test of decode_buffer.cairo:62-93), and a frame whose blocks it has not given up on */
+    uint32_t first = 0;
+#ifndef CZ_EXP_NOFAST
+    if (cz_uni64(x.cap) < 0xC0000000ull && cz_uni64(x.drained) == 0 && (sh.dict_len[0] | sh.dict_len[1]) == 0 && !cz_uni(sh.rec_general)) {
+        __syncthreads();
+        if (LANE == 0) sh.rec_misses = 0;
+        const int e = cz_sequences_rec_fast(x, lit, maps, rec, nseq, mapflags, bits);
+        if (e != -1) return e;
+        first = cz_uni(sh.rec_next);
+        cz_wave_sync();
+        if (LANE == 0) sh.rec_general = 1;
+        cz_wave_sync();
+    } else
+#endif
+    cz_rec_load_maps(maps, mapflags);
+    CZ_PROF_ACC(CZ_P_RING);
+    const int e = cz_sequences_rec_general(x, lit, rec, nseq, bits, first);
+    if (e) return e;
     if (x.lit_used < lit.len) {                                         /* sequence_execution.cairo:72-78 */
         const uint32_t rest = lit.len - x.lit_used;
         if (x.produced + rest > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
@@ -1715,18 +1962,6 @@ __device__ static inline int cz_sequences_rec_body(CzExecCtx& x, const CzLit& li
     __syncthreads();
     CZ_PROF_ACC(CZ_P_LITCOPY);
     return 0;
-}
-
-/* Not inlined: the chunk loop gets the whole register budget to itself.  The execution context is
- * worked on in registers (wave-uniform) and written back once. */
-__device__ static __attribute__((noinline)) int cz_sequences_rec(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec,
-                                                                 uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
-    CzExecCtx x = xref;
-    x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
-    x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
-    const int e = cz_sequences_rec_body(x, lit, maps, rec, nseq, mapflags, bits);
-    xref.produced = x.produced; xref.lit_used = x.lit_used;
-    return e;
 }
 
 /* ------------------------------------------------------------------ one compressed block */
@@ -1746,14 +1981,17 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     const int have_literals = !lit_out && lp.cursor != 0;
     if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals);
     __syncthreads();
+#ifndef CZ_EXEC_ONLY
     if (cz_unii(bc.err) == CZ_PARSE_NEED_WTAB) {                        /* an FSE-compressed tree description: its table by the wave, then the rest of the parse */
         cz_huf_weight_table();
         __syncthreads();
         if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals, 1);
         __syncthreads();
     }
+#endif
     { const int e = cz_unii(bc.err); __syncthreads(); if (e) return e; }   /* read, then fence the slot before it is rewritten */
     CZ_PROF_ACC(CZ_P_OTHER);                                            /* (diagnostic) the serial section parse, apart from the table fill */
+#ifndef CZ_EXEC_ONLY
     if (bc.huf_fill) {
         cz_huf_rank_wave(cz_uni(bc.huf_nsym)); __syncthreads();
         cz_huf_fill(bc.huf_nsym); __syncthreads();
@@ -1765,6 +2003,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         for (uint32_t i = (uint32_t)LANE; i < 1024; i += 64) ((uint32_t*)sh.a.huf)[i] = ((CZ_GLOBAL const uint32_t*)huf_global)[i];
         __syncthreads();
     }
+#endif
     CZ_PROF_ACC(CZ_P_HUFBUILD);
     /* literals */
     const uint32_t regen = cz_uni(bc.regen), lit_total = cz_uni(bc.lit_total), nseq = cz_uni(bc.nseq);
@@ -1785,6 +2024,9 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
             cz_coop_copy(x.out + x.produced, lit.p, regen);
         }
     } else {
+#ifdef CZ_EXEC_ONLY
+        return CZX_FALLBACK;                                            /* (cz_parse_sections already said so) */
+#else
         cz_gptr target = lit_scratch;
         if (lit_out) {
             /* literals pass: a node of the literal arena (one bump allocation per block) */
@@ -1813,6 +2055,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         if (e) return e;
         lit.p = target;
         __syncthreads();
+#endif
     }
     if (lit_out) { lp.last_nseq = nseq; return seq_hdr_err ? seq_hdr_err : 0; }   /* literals pass: nothing else to do in this block */
     CZ_PROF_ACC(CZ_P_HUFDEC);
@@ -1838,6 +2081,9 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         CZ_PROF_ACC(CZ_P_SEQTAB);
         return cz_sequences_rec(x, lit, maps, rec, nseq, mapflags, blk + cz_uni((uint32_t)w1));
     }
+#ifdef CZ_EXEC_ONLY
+    return CZX_FALLBACK;                                                /* a sequences section without chain records */
+#else
     /* sequence tables */
     const uint32_t so = cz_uni(bc.seq_body_off);
     /* T3: stage the table descriptions (region `a` no longer holds the T1 stage) */
@@ -1856,6 +2102,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     x.lit_used = 0;
     CZ_PROF_ACC(CZ_P_SEQTAB);
     return cz_sequences(blk, bsize, x, lit);
+#endif
 }
 
 /* ------------------------------------------------------------------ XXH64 content checksum */
@@ -1920,7 +2167,7 @@ struct CzFrameIO {
 };
 
 /* frame loop: decode_blocks (frame_decoder.cairo:156-222) / decode_from_to (:245-326) */
-__device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 huf_global, CZ_GLOBAL cz_frame_result* res,
+__device__ static int cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 huf_global, CZ_GLOBAL cz_frame_result* res,
                                     cz_gcptr64 arena, uint64_t chain_cursor, CzLitPass lp) {
     CzBroadcast& bc = sh.bc;
     uint64_t pos = 0; int err = 0, hdr_ok = 0; uint32_t blocks = 0, flags = 0, cksum = 0;
@@ -1933,7 +2180,7 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         __syncthreads();
     }
     CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
-    if (LANE == 0) { sh.dict_ptr[0] = (uint32_t)(uintptr_t)io.dict; sh.dict_ptr[1] = (uint32_t)((uint64_t)(uintptr_t)io.dict >> 32); sh.dict_len[0] = (uint32_t)io.dict_len; sh.dict_len[1] = (uint32_t)(io.dict_len >> 32); }
+    if (LANE == 0) { sh.rec_general = 0; sh.dict_ptr[0] = (uint32_t)(uintptr_t)io.dict; sh.dict_ptr[1] = (uint32_t)((uint64_t)(uintptr_t)io.dict >> 32); sh.dict_len[0] = (uint32_t)io.dict_len; sh.dict_len[1] = (uint32_t)(io.dict_len >> 32); }
     __syncthreads();
     const uint64_t produced0 = io.produced;
     while (!err) {
@@ -1992,6 +2239,9 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         if (io.strategy == 1 && blocks >= io.strategy_n) break;         /* :204-208 */
         if (io.strategy == 2 && x.produced - produced0 >= io.strategy_n) break;         /* :209-213 */
     }
+#ifdef CZ_EXEC_ONLY
+    if (err == CZX_FALLBACK) { __syncthreads(); return err; }
+#endif
     if (err && hdr_ok) pos += 3;                                         /* the reference counts the 3 header bytes before it decodes the body (frame_decoder.cairo:172) */
     uint32_t calc = 0;
     if (io.verify && !err && (flags & CZ_RESULT_HAS_CHECKSUM) && io.produced == 0) {
@@ -2006,8 +2256,10 @@ __device__ static void cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16
         res->detail[1] = io.parse_header && err == CZ_E_FH_SKIP_FRAME ? bc.d1 : pos;
     }
     __syncthreads();
+    return err;
 }
 
+#ifndef CZ_EXEC_ONLY
 /* Literals pass over one frame (args.literals_only): walks the frame's blocks and decodes the Huffman-coded literals of
  * every compressed block into nodes of the literal arena — the part of decompress_block (block_decoder.cairo:139-196) that
  * needs neither the sequences nor the window, so it can run next to cz_chain_kernel.  All or nothing per frame: on any
@@ -2041,9 +2293,10 @@ __device__ static uint64_t cz_run_frame_literals(const cz_batch_args& a, cz_gcpt
         pos = body + content;
         if (blast) break;
     }
-    return seen_seq ? lp.first : 0;
+    return seen_seq ? (lp.first ? lp.first : 1) : 0;                   /* 1: regular, has sequences, no Huffman-coded block: nothing to pre-decode */
 }
 
+#endif /* !CZ_EXEC_ONLY */
 __device__ static void cz_state_reset() {                   /* scratch.cairo:23-40 */
     if (LANE == 0) {
         sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
@@ -2053,6 +2306,7 @@ __device__ static void cz_state_reset() {                   /* scratch.cairo:23-
     }
 }
 
+#ifndef CZ_EXEC_ONLY
 /* DictionaryTrait::decode_dict (dictionary.cairo:35-91) on the device, with the decoder's own table builders, so that the
  * tables come out in the layout the kernels use: Huffman table, then the OF, ML and LL tables (max logs 8, 9, 9), three
  * repeat offsets, and the rest is content.  One workgroup, CZ_FSE_LDS_BYTES of dynamic LDS.
@@ -2125,6 +2379,39 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
     if (LANE == 0) { result[0] = (uint64_t)(uint32_t)err; result[1] = off; result[2] = id; result[3] = magic; }
 }
 
+#endif /* !CZ_EXEC_ONLY */
+#ifdef CZ_EXEC_ONLY
+/* cz_execute_frames_kernel: the frames the pre-pass finished (chain records from cz_chain_kernel AND literals from the literals
+ * pass) — block walk, record-driven execution of the sequences (sequence_execution.cairo:12-83), Raw / RLE blocks, checksum.
+ * Same source as cz_decode_frames_kernel minus every decoder (no Huffman table, no FSE tables, no bit ring in LDS: 3 KB per
+ * wave instead of 10.5 KB, and a register budget of its own).  Any other frame — and any frame that turns out to need a
+ * decoder after all — is appended to args.fallback_list for cz_decode_frames_kernel. */
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_execute_frames_kernel(cz_batch_args a) {
+    cz_init_llml();
+    for (;;) {
+        __syncthreads();
+        if (LANE == 0) sh.frame_idx = atomicAdd(a.exec_counter, 1u);
+        __syncthreads();
+        const uint32_t fi = cz_uni(sh.frame_idx);
+        if (fi >= a.n) break;
+        const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
+        int err = CZX_FALLBACK;
+        const uint64_t first = cz_uni64(a.frame_first[f]), lfirst = cz_uni64(a.lit_first[f]);
+        if (first != 0 && lfirst != 0) {
+            CzFrameIO io;
+            io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];
+            io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
+            io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum; io.dict = nullptr; io.dict_len = 0;
+            cz_state_reset();
+            __syncthreads();
+            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0; lp.cursor = lfirst;
+            err = cz_run_frame(io, nullptr, nullptr, (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena, first, lp);
+            if (err != CZX_FALLBACK && LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
+        }
+        if (err == CZX_FALLBACK && LANE == 0) a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f;
+    }
+}
+#else
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_decode_frames_kernel(cz_batch_args a) {
     cz_init_llml();
@@ -2137,8 +2424,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
         if (LANE == 0) sh.frame_idx = atomicAdd(a.work_counter, 1u);
         __syncthreads();
         const uint32_t fi = cz_uni(sh.frame_idx);
-        if (fi >= a.n) break;
-        const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;   /* the pre-pass sorted the frames: longest first */
+        /* behind cz_execute_frames_kernel: only the frames it left (args.fallback_list, in the order it met them) */
+        if (fi >= (a.fallback_list && !a.literals_only ? cz_uni(*a.fallback_count) : a.n)) break;
+        const uint32_t f = a.fallback_list && !a.literals_only ? cz_uni(a.fallback_list[fi]) : (a.frame_order ? cz_uni(a.frame_order[fi]) : fi);   /* the pre-pass sorted the frames: longest first */
         if (a.literals_only) {
             /* a frame the scan kernel found no sequences section in (or did not list) gains nothing from literal nodes:
                the main pass decodes its literals straight to where they are used */
@@ -2152,7 +2440,6 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
 #endif
             continue;
         }
-        if (!a.tasks && a.chain_arena && cz_uni64(a.frame_first[f]) == 0xFFFFFFFFFFFFFFFFull) continue;   /* finished by cz_exec_frames_kernel */
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];
@@ -2209,3 +2496,4 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
         }
     }
 }
+#endif /* CZ_EXEC_ONLY */

@@ -17,6 +17,11 @@
 #define CZ_DYNAMIC_LDS(name) extern __shared__ uint32_t name[]
 #endif
 #define CZ_WG_THREADS 64                      /* one wavefront per frame */
+#ifndef CZ_EXEC_WAVES                /* waves per SIMD cz_execute_frames_kernel is compiled for (launch bounds: caps its registers) */
+#define CZ_EXEC_WAVES 4
+#endif
+#define CZ_EXEC_DYN_LDS (CZ_CHAIN_MAP_BYTES)  /* its dynamic LDS: the state -> code maps of the block in hand */
+#define CZ_CHAIN_MAP_BYTES 1280
 #define CZ_LIT_SCRATCH_BYTES (256 * 1024 + 256) /* Huffman regenerated size < 2^18 (literals_section.cairo:156-168) */
 #define CZ_WG_SCRATCH_BYTES (CZ_LIT_SCRATCH_BYTES + 4096)  /* + the spilled Huffman table of the frame in flight */
 
@@ -81,7 +86,8 @@ typedef struct cz_batch_args {
     uint32_t* chain_counter; uint32_t chain_min_nseq;
     cz_blk_desc* blk_desc; uint32_t blk_capacity; uint32_t* scan_ctl; uint32_t scan_pass;   /* block list of the pre-pass (cz_scan_kernel) */
     uint32_t* frame_order;                    /* NULL, or the order in which the decode kernels take the frames: largest compressed size first (cz_scan_kernel) */
-    uint32_t* exec_counter;                   /* work counter of cz_exec_frames_kernel */
+    uint32_t* exec_counter;                   /* work counter of cz_execute_frames_kernel */
+    uint32_t* fallback_list; uint32_t* fallback_count;   /* frames cz_execute_frames_kernel leaves to cz_decode_frames_kernel (NULL: that kernel takes all n frames) */
     /* optional literals pass (cz_decode_frames_kernel with literals_only = 1, launched next to cz_chain_kernel): the
        Huffman-coded literals of every frame the pre-pass takes are decoded into lit_arena — per block a node
        {u64 offset of the next node | 0, u32 regenerated size, u32 0, bytes...}; lit_first[f] = offset of frame f's

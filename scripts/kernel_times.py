@@ -29,8 +29,7 @@ def child(kind, n):
         ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
         if os.environ.get("CZ_LITPASS", "1") == "1":
             ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
-        if os.environ.get("CZ_EXEC", "0") == "1":
-            ctx.set_exec_kernel(True)
+        ctx.set_exec_kernel(os.environ.get("CZ_EXEC", "1") == "1")
     tot, ch, ex, lt = [], [], [], []
     for it in range(5):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())

@@ -40,14 +40,18 @@ static void* emu_watchdog(void*) {
 
 #include "czstd_kernels.hip"
 #include "czstd_chain.hip"
-#include "czstd_exec.hip"
+#define CZ_EXEC_ONLY 1
+namespace czx {
+#include "czstd_kernels.hip"
+}
+#undef CZ_EXEC_ONLY
 
 struct lane_arg { cz_batch_args a; unsigned lane, block; int which; const uint8_t* dict_raw; uint64_t dict_len; cz_device_frame_state* dict_state; uint64_t* dict_res; };
 static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) cz_exec_frames_kernel(la->a);
+    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) czx::cz_execute_frames_kernel(la->a);
     else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
     else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
     else cz_decode_frames_kernel(la->a);                                /* 1 decode, 3 literals pass */
@@ -98,9 +102,9 @@ int main(int argc, char** argv) {
     unsigned long long lit_top[4] = {64, 0, 0, 0}; std::vector<uint64_t> lit_first(n ? n : 1, 0); uint8_t* lit_arena = nullptr;
     const size_t lit_bytes = arena && getenv("EMU_LIT") ? (size_t)atoll(getenv("EMU_LIT")) : 0;
     if (lit_bytes) { lit_arena = (uint8_t*)malloc(lit_bytes); a.lit_arena = lit_arena; a.lit_capacity = lit_bytes; a.lit_top = lit_top; a.lit_first = lit_first.data(); }
-    /* passes: [chain pre-pass, [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
-    const int with_exec = arena && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
-    if (with_exec) a.verify_checksum = 0;                               /* as the host library: cz_exec_frames_kernel does not hash */
+    /* passes: [chain pre-pass, [literals pass, [cz_execute_frames_kernel (EMU_EXEC=1),]]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
+    const int with_exec = arena && lit_bytes && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
+    uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
     std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order;
     if (arena) {
         blk_desc.resize(a.chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
@@ -130,13 +134,14 @@ int main(int argc, char** argv) {
         if (dict_res[0]) return 3;
         a.dict_state = dict_state; a.dict = dict_exact + dict_res[1]; a.dict_len = dict_raw.size() - dict_res[1];
     }
-    /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_exec_frames_kernel (EMU_EXEC=1),]] main kernel */
+    /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel */
     const int order[6] = {4, 5, 0, 3, 2, 1};
     for (int pi = arena ? 0 : 5; pi < 6; pi++) {
         const int which = order[pi];
         if (which == 2 && !with_exec) continue;
         if (which == 3 && !lit_bytes) continue;
-        const int nthreads = which == 2 ? CZX_THREADS : 64;
+        const int nthreads = 64;
+        if (which == 2) { a.fallback_list = fallback_list.data(); a.fallback_count = &fallback_count; }   /* from here on */
         const int nblocks = which >= 4 ? (int)((n + 63) / 64) : (which == 3 ? 1 : grid);
         emu_nthreads = nthreads;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
@@ -154,7 +159,7 @@ int main(int argc, char** argv) {
         pthread_barrier_destroy(&emu_barrier);
     }
     if (lit_bytes) { unsigned long long nl = 0; for (uint64_t i = 0; i < n; i++) nl += lit_first[i] != 0; fprintf(stderr, "EMU_LIT: %llu frames have literal nodes, arena top %llu\n", nl, lit_top[0]); free(lit_arena); }
-    if (with_exec) { unsigned long long donef = 0; for (uint64_t i = 0; i < n; i++) donef += frame_first[i] == ~0ull; fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_exec_frames_kernel\n", donef); }
+    if (with_exec) fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_execute_frames_kernel\n", (unsigned long long)(n - fallback_count));
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {
         fwrite(&res[i], sizeof(cz_frame_result), 1, g);

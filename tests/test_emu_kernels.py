@@ -22,8 +22,8 @@ def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0
             bad.append((i, status.name(r["status"]), status.name(st)))
         elif st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"]):
             bad.append((i, "DATA"))
-        elif st == 0 and info["has_checksum"] and not exec_kernel:
-            # the emulator runs with content-checksum verification on (except next to cz_exec_frames_kernel, like the library)
+        elif st == 0 and info["has_checksum"]:
+            # the emulator runs with content-checksum verification on
             want = oracle.xxh64(ref) & 0xFFFFFFFF
             if not (r["flags"] & 4) or int(r["calculated_checksum"]) != want or bool(r["flags"] & 8) != (want == info["checksum"]):
                 bad.append((i, "XXH64", hex(int(r["calculated_checksum"])), hex(want)))
@@ -96,10 +96,10 @@ def test_emu_chain_prepass():
     _run_and_compare(frames[:12], caps[:12], chain_bytes=4096, lit_bytes=6000)
 
 
-def test_emu_exec_kernel():
-    """cz_exec_frames_kernel (workgroups of several waves, output assembled in the LDS ring, chunks finishing out of
-    order behind done flags) under ASan/UBSan, 4 waves per workgroup: corpus frames, synthetic frames, malformed
-    frames (it must leave them to cz_decode_frames_kernel)."""
+def test_emu_execute_frames_kernel():
+    """cz_execute_frames_kernel (czstd_kernels.hip compiled without its decoders: the frames the pre-pass finished) under
+    ASan/UBSan, followed by cz_decode_frames_kernel on the frames it left: corpus frames, synthetic frames, malformed
+    frames (it must hand them over), with the content checksum verified on the device."""
     frames, caps = [], []
     for name, z, orig in corpus_pairs(max_orig=3500):
         frames.append(z)
@@ -114,8 +114,11 @@ def test_emu_exec_kernel():
         a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
         frames.append(bytes(a))
         caps.append(len(orig) * 2 + 4096)
-    _run_and_compare(frames, caps, chain_bytes=8 << 20, exec_kernel=True)
-    assert "frames finished by cz_exec_frames_kernel" in emu_runner.run.last_stderr
+    _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+    err = emu_runner.run.last_stderr
+    assert "frames finished by cz_execute_frames_kernel" in err
+    done = int(err.split("EMU_EXEC: ")[1].split()[0])
+    assert 0 < done < len(frames), (done, len(frames))                  # some frames took it, the malformed ones did not
 
 
 def test_emu_d2_weight_log_10_unsupported():

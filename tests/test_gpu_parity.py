@@ -423,7 +423,7 @@ def _large_corpus():
     return out
 
 
-@pytest.mark.parametrize("mode", ["single_kernel", "prepass", "prepass_exec_kernel"])
+@pytest.mark.parametrize("mode", ["single_kernel", "prepass", "prepass_decode_kernel_only"])
 def test_corpus_large_frames_vs_manifest(cz, mode):
     """The 31 corpus frames whose originals exceed 64 KiB (986 blocks in one frame, a 3.5 MiB window, 41 958 sequences
     and 72 521 literals in one block: src/tests/decoding.cairo:4-21 over data/decode_corpus): only the compressed side
@@ -435,10 +435,9 @@ def test_corpus_large_frames_vs_manifest(cz, mode):
     try:
         if mode != "single_kernel":
             c.set_chain_arena(512 << 20, min_sequences=0)
-            c.set_exec_kernel(mode == "prepass_exec_kernel")
-            c.set_literal_arena((64 << 20) if mode == "prepass" else 0)
-        if mode != "prepass_exec_kernel":
-            c.set_verify_checksum(True)
+            c.set_exec_kernel(mode == "prepass")                        # cz_execute_frames_kernel (default) / everything on cz_decode_frames_kernel
+            c.set_literal_arena(64 << 20)
+        c.set_verify_checksum(True)
         got = cz.decode_batch_host([z for _, z, _ in files], [e["orig_len"] + 64 for _, _, e in files], c)
         for (name, z, e), (r, out) in zip(files, got):
             assert int(r["status"]) == 0, (name, cz.status.name(r["status"]), r["detail"])
@@ -446,10 +445,10 @@ def test_corpus_large_frames_vs_manifest(cz, mode):
             assert hashlib.sha256(out).hexdigest() == e["orig_sha256"], name
             assert f"{oracle.xxh64(out):016x}" == e["xxh64"], name
             assert int(r["checksum_from_data"]) == int(e["xxh64"], 16) & 0xFFFFFFFF, name
-            if mode != "prepass_exec_kernel":
-                assert r["flags"] & cz.RESULT_CHECKSUM_MATCH, name
+            assert r["flags"] & cz.RESULT_CHECKSUM_MATCH, name
         if mode != "single_kernel":
             assert c.last_chain_ms() > 0
+            assert (c.last_exec_ms() > 0) == (mode == "prepass")
     finally:
         c.close()
 
@@ -528,12 +527,13 @@ def test_bench_configuration_all_frames(cz):
         c.close()
 
 
-def test_exec_kernel_matches_oracle(cz):
-    """The optional cz_exec_frames_kernel path (one workgroup per frame, output assembled in a 128 KiB LDS ring):
-    same results as the oracle on frames it finishes and on frames it hands back."""
+def test_execute_frames_kernel_matches_oracle(cz):
+    """cz_execute_frames_kernel (the decode kernel's source without its decoders, for the frames the pre-pass finished) followed
+    by cz_decode_frames_kernel on the frames it hands over: same results as the oracle on both kinds."""
     from cairo_zstd_amd import synth
     c = cz.Context(0)
     c.set_chain_arena(256 << 20, min_sequences=0)
+    c.set_literal_arena(128 << 20)
     c.set_exec_kernel(True)
     try:
         frames, caps = [], []
