@@ -467,25 +467,33 @@ __device__ static inline void czc_group_asm_wide(CzcLane& c, const CzcRole& ro, 
 __device__ static inline uint32_t czc_q0(uint32_t v) { return (uint32_t)__shfl((int)v, LANE & ~3); }
 __device__ static inline uint64_t czc_q0_64(uint64_t v) { return ((uint64_t)czc_q0((uint32_t)(v >> 32)) << 32) | czc_q0((uint32_t)v); }
 
-/* ---- cz_scan_kernel: the block list ----------------------------------------------------------------
- * The blocks of a frame are chained for EXECUTION (window, offset history), but the FSE chain of a block only needs that
- * block's bitstream and its three tables — described in the block itself or, in Repeat mode, in an earlier block of the
- * frame.  So the pre-pass works on blocks, not frames: one lane per frame walks the frame's block headers (no decoding:
- * block header, literals-section header, sequences header: block_decoder.cairo:237-321, literals_section.cairo:81-175,
- * sequence_section.cairo:77-114) and lists every compressed block that has sequences.  Two passes over the same walk:
- *   pass 0  counts the blocks per size class (bit length of the sequence count) and the arena units per frame
- *   pass 1  places each block's entry in descending size-class order (blocks of similar chain length end up in the same
- *           waves of cz_chain_kernel), allocates the frame's records in the chain arena, links the per-block headers
- *           in frame order and sets frame_first[f]
- * A frame is listed up to its first irregularity (malformed header, truncated block, Repeat of a table nothing
- * defined, first sequences section shorter than chain_min_nseq ...) and then NOT pre-passed: frame_first[f] = 0, its
- * entries void.  Nothing here reports errors. */
-struct CzsBlk { uint32_t blk_off, bsize, nseq, sbody, modes; };
-/* the walk of one lane over its frame; cz_scan_kernel advances all lanes of a wave together, one listed block at a time,
+/* ---- cz_scan_kernel: the work lists of the pre-pass -------------------------------------------------------------------
+ * The blocks of a frame are chained for EXECUTION (window, offset history), but three parts of the work need none of that:
+ *   - the FSE chain of a block needs that block's bitstream and its three tables — described in the block itself or, in Repeat
+ *     mode, in an earlier block of the frame (cz_chain_kernel, unit = block);
+ *   - Huffman-coded literals need the block's streams and a tree — its own or, Treeless, that of an earlier block
+ *     (literals_section_decoder.cairo:58-117; cz_huf_kernel, unit = block);
+ *   - Raw and RLE blocks, and the literals of blocks without sequences, ahead of the frame's first block WITH sequences land
+ *     at a place that follows from the headers alone (block_decoder.cairo:95-122, :229-232; cz_tile_kernel and, for Huffman
+ *     literals, cz_huf_kernel writing straight into the output).
+ * One lane per frame walks the frame's headers (no decoding: block header, literals-section header, sequences header:
+ * block_decoder.cairo:237-321, literals_section.cairo:81-175, sequence_section.cairo:77-114).  Two passes over the same walk:
+ *   pass 0  counts, per size class, the blocks with sequences and the Huffman sections, the copy runs, and the arena space
+ *           (records, literal nodes) every frame needs
+ *   pass 1  places each list entry — descending size class: entries of similar length end up in the same waves / the
+ *           longest work starts first — allocates the frame's records and literal nodes, links them in frame order and sets
+ *           frame_first[f], lit_first[f], frame_pre[f]
+ * A frame is listed only if it is regular to its last block (no malformed header, truncated block, Repeat / Treeless of
+ * something nothing defined, output beyond the caller's capacity, first sequences section shorter than chain_min_nseq ...)
+ * and its entries fit the lists and arenas: otherwise frame_first[f] = lit_first[f] = frame_pre[f] = 0, its entries are void
+ * and cz_decode_frames_kernel does the frame by itself.  Nothing here reports errors. */
+struct CzsBlk { uint32_t type, blk_off, bsize;                          /* 0 Raw, 1 RLE, 2 Compressed; content offset in the frame, Block_Size */
+                uint32_t lt, regen, lit_hdr, nseq, sbody, modes; };     /* Compressed: literals type, regenerated size, header bytes, sequences, first table description, modes */
+/* the walk of one lane over its frame; cz_scan_kernel advances all lanes of a wave together, one block at a time,
    so that the counters they share are bumped once per wave and size class (and the CPU emulator sees uniform control flow) */
-struct CzsWalk { const uint8_t* src; uint64_t len, pos; uint32_t defined; int first, active, ok; };
+struct CzsWalk { const uint8_t* src; uint64_t len, pos, end; uint32_t defined, has_checksum; int first, active, ok, have_tree; };
 __device__ static inline void czs_begin(CzsWalk& w, const uint8_t* src, uint64_t len, int valid) {
-    w.src = src; w.len = len; w.pos = 0; w.defined = 0; w.first = 1; w.active = 0; w.ok = 0;
+    w.src = src; w.len = len; w.pos = 0; w.end = 0; w.defined = 0; w.has_checksum = 0; w.first = 1; w.active = 0; w.ok = 0; w.have_tree = 0;
     if (!valid || len < 5 || len >= 0xFFFFFFF0ull) return;              /* block offsets are 32 bits */
     const uint32_t magic = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
     const uint32_t d = src[4];
@@ -494,16 +502,16 @@ __device__ static inline void czs_begin(CzsWalk& w, const uint8_t* src, uint64_t
     const uint32_t hl = 5 + (single ? 0 : 1) + dl + fl;
     if (magic != 0xFD2FB528u || len < hl) return;                       /* frame.cairo:152-284: only the header's length and validity matter here */
     if (!single) { const uint32_t wd = src[5]; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) return; }
-    w.pos = hl; w.active = 1;
+    w.pos = hl; w.active = 1; w.has_checksum = (d >> 2) & 1;
 }
-/* advances to the next compressed block that has sequences: 1 with `b` filled, or 0 — the walk is over (w.active = 0) and
-   w.ok says whether the frame was regular to its end */
+/* advances to the next block: 1 with `b` filled, or 0 — the walk is over (w.active = 0) and w.ok says whether the frame was
+   regular to its end */
 __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBlk& b) {
     const uint8_t* src = w.src; const uint64_t len = w.len;
     if (!w.active) return 0;
-    for (;;) {                                                          /* block_decoder.cairo:237-321 */
+    do {                                                                /* block_decoder.cairo:237-321 */
         uint64_t pos = w.pos;
-        if (pos == ~0ull) { w.active = 0; w.ok = !w.first; return 0; }   /* the last block was the frame's last: a frame without sequences has nothing to pre-pass */
+        if (pos == ~0ull) { w.active = 0; w.ok = 1; return 0; }          /* the last block was the frame's last */
         if (len - pos < 3) break;
         const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
         const uint32_t type = (b0 >> 1) & 3, size = (b0 >> 3) | (b1 << 5) | (b2 << 13), blast = b0 & 1;
@@ -511,7 +519,9 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         const uint64_t body = pos + 3; const uint32_t content = type == 1 ? 1u : size;
         if (len - body < content) break;
         w.pos = blast ? ~0ull : body + content;
-        if (type != 2) continue;
+        if (blast) w.end = body + content;                              /* where the content checksum, if any, begins */
+        b.type = type; b.blk_off = (uint32_t)body; b.bsize = size; b.lt = 0; b.regen = 0; b.lit_hdr = 0; b.nseq = 0; b.sbody = 0; b.modes = 0;
+        if (type != 2) return 1;
         /* literals section header (literals_section.cairo:81-175): sizes only */
         const uint8_t* p = src + body;
         if (size == 0) break;
@@ -519,10 +529,15 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         const uint32_t need = lt <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
         if (size < need) break;
         const uint32_t l1 = need > 1 ? p[1] : 0, l2 = need > 2 ? p[2] : 0, l3 = need > 3 ? p[3] : 0, l4 = need > 4 ? p[4] : 0;
-        uint32_t upper;
-        if (lt <= 1) { const uint32_t regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
-        else upper = fmt <= 1 ? (l1 >> 6) + (l2 << 2) : (fmt == 2 ? (l2 >> 2) + (l3 << 6) : (l2 >> 6) + (l3 << 2) + (l4 << 10));
+        uint32_t upper, regen;
+        if (lt <= 1) { regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
+        else {
+            regen = fmt <= 1 ? (l0 >> 4) + ((l1 & 0x3f) << 4) : (fmt == 2 ? (l0 >> 4) + (l1 << 4) + ((l2 & 3) << 12) : (l0 >> 4) + (l1 << 4) + ((l2 & 0x3f) << 12));
+            upper = fmt <= 1 ? (l1 >> 6) + (l2 << 2) : (fmt == 2 ? (l2 >> 2) + (l3 << 6) : (l2 >> 6) + (l3 << 2) + (l4 << 10));
+        }
         if (size - need < upper) break;
+        if (lt == 3 && !w.have_tree) break;                             /* Treeless with no tree before it (literals_section_decoder.cairo:82-86) */
+        if (lt == 2) w.have_tree = 1;
         const uint32_t so = need + upper, sl_ = size - so;              /* sequence_section.cairo:77-114 */
         if (sl_ == 0) break;
         const uint32_t s0 = p[so];
@@ -531,9 +546,10 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         else if (s0 <= 127) { if (sl_ < 2) break; n = s0; hb = 1; }
         else if (s0 <= 254) { if (sl_ < 3) break; n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
         else { if (sl_ < 4) break; n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
-        if (!n) continue;                                               /* (128, 0: no sequences but a modes byte) */
+        b.lt = lt; b.regen = regen; b.lit_hdr = need;
+        if (!n) return 1;                                               /* (128, 0: no sequences but a modes byte) */
         if (w.first && n < chain_min_nseq) break;
-        b.blk_off = (uint32_t)body; b.bsize = size; b.nseq = n; b.modes = p[so + hb]; b.sbody = so + hb + 1;
+        b.nseq = n; b.modes = p[so + hb]; b.sbody = so + hb + 1;
         int undefined = 0;
         for (int t = 0; t < 3; t++) {                                   /* Repeat of a table nothing defined (sequence_section_decoder.cairo:483,551,643) */
             const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
@@ -542,11 +558,11 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         if (undefined) break;
         w.first = 0;
         return 1;
-    }
-    w.active = 0; w.ok = 0;                                             /* irregular: the frame is listed up to here and not pre-passed */
+    } while (0);
+    w.active = 0; w.ok = 0;                                             /* irregular: the frame is not pre-passed */
     return 0;
 }
-__device__ static inline uint32_t czs_class(uint32_t nseq) { return cz_hbs(nseq); }   /* 1..17 */
+__device__ static inline uint32_t czs_class(uint32_t nseq) { return cz_hbs(nseq); }   /* 1..18 */
 /* counters[cls] += 1 for every lane with `has`, one atomic per wave and class; returns the lane's ticket */
 __device__ static inline uint32_t czs_ticket(uint32_t* counters, int has, uint32_t cls) {
     uint32_t ticket = 0;
@@ -562,13 +578,33 @@ __device__ static inline uint32_t czs_ticket(uint32_t* counters, int has, uint32
     }
     return ticket;
 }
+/* what one block contributes to the lists, the same in both passes.  `known`: the block's place in the output follows from the
+   headers (no block with sequences before it); kout: that place */
+struct CzsPlan { int chain, lit, copy; uint32_t copy_len, copy_fill; uint64_t copy_src; int direct; };
+__device__ static inline CzsPlan czs_plan(const CzsBlk& b, int known) {
+    CzsPlan q; q.chain = 0; q.lit = 0; q.copy = 0; q.copy_len = 0; q.copy_fill = 0; q.copy_src = 0; q.direct = 0;
+    if (b.type != 2) { if (known && b.bsize) { q.copy = 1; q.copy_len = b.bsize; q.copy_fill = b.type == 1; q.copy_src = b.blk_off; } return q; }
+    q.chain = b.nseq != 0;
+    if (b.lt >= 2) { q.lit = 1; q.direct = known && !b.nseq; }
+    else if (known && !b.nseq && b.regen) { q.copy = 1; q.copy_len = b.regen; q.copy_fill = b.lt == 1; q.copy_src = (uint64_t)b.blk_off + b.lit_hdr; }
+    return q;
+}
+/* 64-bit inclusive prefix sum over the lanes and the wave total */
+__device__ static inline uint64_t czs_scan64(uint64_t v, uint64_t* total) {
+    uint64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t lo = __shfl_up((uint32_t)incl, (unsigned)d), hi = __shfl_up((uint32_t)(incl >> 32), (unsigned)d); if (LANE >= d) incl += ((uint64_t)hi << 32) | lo; }
+    *total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63);
+    return incl;
+}
 
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_batch_args a) {
     const uint32_t f = blockIdx.x * CZ_WG_THREADS + (uint32_t)LANE;
     const int valid = f < a.n;
     CzsWalk w;
     czs_begin(w, valid ? a.in_base + a.in_off[f] : nullptr, valid ? a.in_len[f] : 0, valid);
-    CzsBlk b; b.blk_off = b.bsize = b.nseq = b.sbody = b.modes = 0;
+    CzsBlk b; b.type = b.blk_off = b.bsize = b.lt = b.regen = b.lit_hdr = b.nseq = b.sbody = b.modes = 0;
+    const uint64_t ocap = valid ? a.out_cap[f] : 0;
+    const int with_lits = a.lit_arena != nullptr;                       /* literal and copy lists only with a literal arena (cz_context_set_literal_arena) */
     /* the order in which the decode kernels take the frames: by size class of the compressed frame, largest first (one wave
        per frame there: the longest frames must not start last) */
     const uint32_t fcls = valid ? cz_hbs((uint32_t)(a.in_len[f] > 0xFFFFFFFFull ? 0xFFFFFFFFull : a.in_len[f])) : 0u;   /* 0..32 -> 0..31 */
@@ -577,52 +613,141 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
         uint32_t fb = 0; for (uint32_t cc = 31; cc > (fcls > 31 ? 31u : fcls); cc--) fb += a.scan_ctl[72 + cc];
         a.frame_order[fb + ft] = f;
     }
+    int known = 1; uint64_t kout = 0; uint32_t pre_blocks = 0;
     if (a.scan_pass == 0) {
-        uint64_t units = 0;
+        uint64_t units = 0, lbytes = 0; int seen_seq = 0;
         while (__ballot(w.active)) {
             const int has = czs_next(w, a.chain_min_nseq, b);
-            czs_ticket(a.scan_ctl, has, has ? czs_class(b.nseq) : 0u);
-            if (has) units += 4ull + CZC_MAP_WORDS + b.nseq;
+            CzsPlan q = czs_plan(b, known);
+            if (!has) { q.chain = q.lit = q.copy = 0; }
+            if (has) {
+                const uint64_t out = b.type != 2 ? b.bsize : (b.nseq ? 0 : b.regen);
+                if (known && kout + out > ocap) { w.active = 0; w.ok = 0; q.chain = q.lit = q.copy = 0; }   /* the decode kernel reports it */
+                else if (b.type == 2 && b.nseq) known = 0; else if (known) kout += out;
+            }
+            czs_ticket(a.scan_ctl, q.chain, q.chain ? czs_class(b.nseq) : 0u);
+            if (with_lits) {
+                czs_ticket(a.scan_ctl + 136, q.lit, q.lit ? czs_class(b.regen) : 0u);
+                czs_ticket(a.scan_ctl + 201, q.copy, 0u);
+            }
+            if (q.chain) { units += 4ull + CZC_MAP_WORDS + b.nseq; seen_seq = 1; }
+            if (q.lit && !q.direct) lbytes += 16ull + ((b.regen + 15u) & ~15u);
         }
-        if (valid) a.frame_first[f] = w.ok ? units : 0;                 /* between the passes: arena units the frame needs */
+        if (valid) {                                                    /* between the passes: arena units / literal bytes the frame needs */
+            a.frame_first[f] = w.ok ? units : 0;
+            if (with_lits) { a.lit_first[f] = w.ok ? lbytes : 0; a.frame_pre[f] = w.ok ? CZ_PRE_REGULAR : 0; }
+            (void)seen_seq;
+        }
         return;
     }
-    /* pass 1: the frames of the wave get their share of the arena with one atomic */
-    const uint64_t units = valid ? a.frame_first[f] : 0;
-    uint64_t at = 0;
+    /* pass 1: the frames of the wave get their share of the arenas with one atomic each */
+    const int ok0 = valid && (with_lits ? a.frame_pre[f] != 0 : a.frame_first[f] != 0);
+    const uint64_t units = ok0 ? a.frame_first[f] : 0, lbytes = ok0 && with_lits ? a.lit_first[f] : 0;
+    uint64_t at = 0, lat = 0; int placed = ok0;
     {
-        uint64_t incl = units;                                          /* inclusive prefix over the lanes */
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t lo = __shfl_up((uint32_t)incl, (unsigned)d), hi = __shfl_up((uint32_t)(incl >> 32), (unsigned)d); if (LANE >= d) incl += ((uint64_t)hi << 32) | lo; }
-        const uint64_t total = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63);
-        uint64_t wbase = 0;
+        uint64_t total, incl = czs_scan64(units, &total), wbase = 0;
         if (LANE == 0 && total) wbase = atomicAdd(a.chain_top, (unsigned long long)total);
         wbase = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(wbase >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0);
-        if (units) { at = 64ull + wbase + (incl - units); if (at + units > a.chain_capacity) at = 0; }   /* indices 0..63 are reserved: 0 = none, 8..39 = the sink of czc_group_asm */
+        if (units) { at = 64ull + wbase + (incl - units); if (at + units > a.chain_capacity) { at = 0; placed = 0; } }   /* indices 0..63 are reserved: 0 = none, 8..39 = the sink of czc_group_asm */
     }
+    if (with_lits) {
+        uint64_t total, incl = czs_scan64(lbytes, &total), wbase = 0;
+        if (LANE == 0 && total) wbase = atomicAdd(a.lit_top, (unsigned long long)total);
+        wbase = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(wbase >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0);
+        if (lbytes) { lat = wbase + (incl - lbytes); if (lat + lbytes > a.lit_capacity) { lat = 0; placed = 0; } }   /* lit_top starts at 64: offset 0 = "no node" */
+    }
+    if (!placed) { at = 0; lat = 0; }
     uint32_t base[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { base[c] = run; run += a.scan_ctl[c]; } }   /* larger classes first */
-    uint64_t first_hdr = 0, prev_hdr = 0; uint32_t defidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}; int placed = at != 0;
+    uint32_t lbase[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { lbase[c] = run; run += with_lits ? a.scan_ctl[136 + c] : 0u; } }
+    uint64_t first_hdr = 0, prev_hdr = 0, first_node = 0, prev_node = 0;
+    uint32_t defidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, tree_seg = 0xFFFFFFFFu;
+    const uint64_t ibase = valid ? a.in_off[f] : 0, obase = valid ? a.out_off[f] : 0;
     while (__ballot(w.active)) {
         const int has = czs_next(w, a.chain_min_nseq, b);
-        const uint32_t cls = has ? czs_class(b.nseq) : 0u;
-        const uint32_t ticket = czs_ticket(a.scan_ctl + 32, has, cls);
-        if (!has) continue;
-        uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == cls) bb = base[c];
-        const uint32_t idx = bb + ticket;
-        if (idx >= a.blk_capacity) { placed = 0; continue; }
-        cz_blk_desc d; d.frame = f; d.blk_off = b.blk_off; d.bsize = b.bsize; d.nseq = at ? b.nseq : 0u; d.sbody = b.sbody; d.modes = b.modes; d.pad = 0; d.hdr = at;
-        for (int t = 0; t < 3; t++) {
-            const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
-            d.def[t] = md == 3 ? defidx[t] : 0xFFFFFFFFu;
-            if (md != 3) defidx[t] = idx;
+        CzsPlan q = czs_plan(b, known);
+        if (!has) { q.chain = q.lit = q.copy = 0; }
+        const uint64_t kout_here = kout;
+        if (has) {
+            const uint64_t out = b.type != 2 ? b.bsize : (b.nseq ? 0 : b.regen);
+            if (known && kout + out > ocap) { w.active = 0; w.ok = 0; q.chain = q.lit = q.copy = 0; }
+            else if (b.type == 2 && b.nseq) known = 0; else if (known) { kout += out; pre_blocks++; }
         }
-        a.blk_desc[idx] = d;
-        if (at) {
-            a.chain_arena[at + 2] = 0;
-            if (prev_hdr) a.chain_arena[prev_hdr + 2] = at; else first_hdr = at;
-            prev_hdr = at; at += 4ull + CZC_MAP_WORDS + b.nseq;
+        /* every lane of the wave takes the same tickets as in pass 0, placed or not: the class bases depend on it */
+        const uint32_t cls = q.chain ? czs_class(b.nseq) : 0u;
+        const uint32_t ticket = czs_ticket(a.scan_ctl + 32, q.chain, cls);
+        uint32_t lticket = 0, cticket = 0; const uint32_t lcls = q.lit ? czs_class(b.regen) : 0u;
+        if (with_lits) {
+            lticket = czs_ticket(a.scan_ctl + 168, q.lit, lcls);
+            cticket = czs_ticket(a.scan_ctl + 202, q.copy, 0u);
+        }
+        if (q.chain) {
+            uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == cls) bb = base[c];
+            const uint32_t idx = bb + ticket;
+            if (idx >= a.blk_capacity) placed = 0;
+            else {
+                cz_blk_desc d; d.frame = f; d.blk_off = b.blk_off; d.bsize = b.bsize; d.nseq = at ? b.nseq : 0u; d.sbody = b.sbody; d.modes = b.modes; d.pad = 0; d.hdr = at;
+                for (int t = 0; t < 3; t++) {
+                    const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
+                    d.def[t] = md == 3 ? defidx[t] : 0xFFFFFFFFu;
+                    if (md != 3) defidx[t] = idx;
+                }
+                a.blk_desc[idx] = d;
+                if (at) {
+                    a.chain_arena[at + 2] = 0;
+                    if (prev_hdr) a.chain_arena[prev_hdr + 2] = at; else first_hdr = at;
+                    prev_hdr = at; at += 4ull + CZC_MAP_WORDS + b.nseq;
+                }
+            }
+        }
+        if (q.lit) {
+            uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == lcls) bb = lbase[c];
+            const uint32_t idx = bb + lticket;
+            if (idx >= a.lit_seg_capacity) placed = 0;
+            else {
+                cz_lit_seg d; d.frame = placed ? f : 0xFFFFFFFFu; d.blk_off = b.blk_off; d.bsize = b.bsize; d.regen = b.regen; d.direct = (uint32_t)q.direct;
+                d.def = b.lt == 3 ? tree_seg : 0xFFFFFFFFu;
+                if (b.lt == 2) tree_seg = idx;
+                d.dst = 0;
+                if (q.direct) d.dst = obase + kout_here;
+                else if (lat) {
+                    /* the node: {next, regen} then the bytes, laid out and linked here so that cz_huf_kernel only fills it */
+                    CZ_GLOBAL uint64_t* node = (CZ_GLOBAL uint64_t*)(a.lit_arena + lat);
+                    node[0] = 0; node[1] = b.regen;
+                    if (prev_node) *(CZ_GLOBAL uint64_t*)(a.lit_arena + prev_node) = lat; else first_node = lat;
+                    prev_node = lat; d.dst = lat + 16; lat += 16ull + ((b.regen + 15u) & ~15u);
+                } else d.frame = 0xFFFFFFFFu;
+                a.lit_segs[idx] = d;
+            }
+        }
+        if (q.copy) {
+            if (cticket >= a.copy_seg_capacity) placed = 0;
+            else { cz_copy_seg d; d.src = ibase + q.copy_src; d.dst = obase + kout_here; d.len = placed ? q.copy_len : 0u; d.fill = q.copy_fill; a.copy_segs[cticket] = d; }
         }
     }
-    if (valid) a.frame_first[f] = placed ? first_hdr : 0;
+    if (valid) {
+        const int good = placed && w.ok;
+        a.frame_first[f] = good ? first_hdr : 0;
+        if (with_lits) {
+            uint32_t pre = good ? (CZ_PRE_REGULAR | pre_blocks) : 0;
+            /* a frame whose every block is done by the pre-pass kernels needs no walk by the decode kernels: its result record is
+               written here (frame_decoder.cairo:189-200: finished, the stored checksum read) — unless its content checksum is to be
+               verified, or the checksum is cut short (the decode kernel reports that).  cz_huf_kernel may still take the frame
+               back (frame_pre[f] = 0): then cz_decode_frames_kernel does it from scratch and writes the record again. */
+            if (good && known && !a.verify_checksum && (!w.has_checksum || w.len - w.end >= 4)) {
+                pre |= CZ_PRE_DONE;
+                uint32_t ck = 0, fl = CZ_RESULT_FINISHED; uint64_t pos = w.end;
+                if (w.has_checksum) { const uint8_t* p = w.src + pos; ck = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); fl |= CZ_RESULT_HAS_CHECKSUM; pos += 4; }
+                cz_frame_result r; r.status = 0; r.blocks_decoded = pre_blocks; r.bytes_consumed = pos; r.bytes_produced = kout; r.checksum_from_data = ck; r.flags = fl;
+                r.detail[0] = pre_blocks; r.detail[1] = pos; r.calculated_checksum = 0; r.reserved = 0;
+                a.results[f] = r;
+            }
+            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre;
+        }
+    }
+    if (with_lits) {                                                    /* frames the decode kernels still have to walk */
+        const unsigned long long todo = __ballot(valid && !(a.frame_pre[f < a.n ? f : 0] & CZ_PRE_DONE));
+        if (LANE == 0 && todo) atomicAdd(&a.scan_ctl[204], (uint32_t)__popcll(todo));
+    }
 }
 
 /* ---- cz_chain_kernel ---------------------------------------------------------------------------------

@@ -23,6 +23,7 @@
 
 #include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
 #include "czstd_chain.hip"
+#include "czstd_pre.hip"
 /* the same kernel source once more, without its decoders: cz_execute_frames_kernel (czstd_kernels.hip, CZ_EXEC_ONLY) */
 #define CZ_EXEC_ONLY 1
 namespace czx {
@@ -66,7 +67,9 @@ struct cz_context {
     /* optional literals pass next to the pre-pass, on a stream of its own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
     uint64_t* lit_first = nullptr; size_t lit_first_cap = 0; uint32_t* lit_counter = nullptr;
-    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_lit = nullptr; int lit_grid = 0; bool timed_lit = false;
+    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_lit = nullptr; int huf_grid = 0, tile_grid = 0; bool timed_lit = false;
+    cz_lit_seg* lit_segs = nullptr; cz_copy_seg* copy_segs = nullptr; uint32_t seg_capacity = 0;   /* lists of the literal / copy pre-pass (cz_scan_kernel) */
+    uint32_t* frame_pre = nullptr;                                      /* n entries, allocated with lit_first */
     uint32_t verify_checksum = 0;
 };
 
@@ -134,6 +137,11 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->lit_first) (void)hipFree(c->lit_first);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->lit_segs) (void)hipFree(c->lit_segs);
+    if (c->copy_segs) (void)hipFree(c->copy_segs);
+    if (c->frame_pre) (void)hipFree(c->frame_pre);
     if (c->ev_lit) (void)hipEventDestroy(c->ev_lit);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->chain_top) (void)hipFree(c->chain_top);
@@ -211,30 +219,44 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     return CZ_OK;
 }
 
-/* Enables (bytes > 0) or disables (0) the literals pass: with the pre-pass on, the Huffman-coded literals of the frames
- * the pre-pass takes are decoded by a second launch of cz_decode_frames_kernel (literals only) that runs NEXT TO
- * cz_chain_kernel on a stream of its own — the chain kernel is bound by the latency of its serial chains and leaves
- * most issue slots of the chip idle.  bytes = capacity of the literal arena (decoded literal bytes + 16 per block;
- * never more than the decoded size of the batch); frames that do not fit decode their literals in the decode kernel. */
+/* Enables (bytes > 0) or disables (0) the literal / copy half of the pre-pass: with the chain arena set, cz_scan_kernel also lists
+ * every Huffman-coded literals section and every Raw / RLE run whose place in the output follows from the headers;
+ * cz_huf_kernel (unit of work: one section) and cz_tile_kernel do them NEXT TO cz_chain_kernel, on streams of their own.
+ * Literals of blocks that have sequences go to nodes of the literal arena (bytes = its capacity: decoded literal bytes + 16 per
+ * block, never more than the decoded size of the batch); literals of blocks without sequences ahead of a frame's first block
+ * with sequences, like the Raw / RLE runs, go straight into the output.  Frames that do not fit, or are irregular in any way,
+ * are decoded entirely by cz_decode_frames_kernel. */
 CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
     if (!c) return CZ_E_INVALID_ARG;
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     if (c->lit_arena) { (void)hipFree(c->lit_arena); c->lit_arena = nullptr; c->lit_capacity = 0; }
+    if (c->lit_segs) { (void)hipFree(c->lit_segs); c->lit_segs = nullptr; }
+    if (c->copy_segs) { (void)hipFree(c->copy_segs); c->copy_segs = nullptr; }
+    c->seg_capacity = 0;
     if (!bytes) return CZ_OK;
     if (bytes < 4096) bytes = 4096;
     if (!c->lit_top) { CZ_HIP(c, hipMalloc((void**)&c->lit_top, 64)); c->lit_counter = (uint32_t*)((uint8_t*)c->lit_top + 16); }
     if (!c->stream2) {
         CZ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        CZ_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
         CZ_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         CZ_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        CZ_HIP(c, hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
         CZ_HIP(c, hipEventCreate(&c->ev_lit));
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_decode_frames_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
-        c->lit_grid = c->num_cu * (occ < 8 ? occ : 8);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_huf_kernel, CZH_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
+        c->huf_grid = c->num_cu * occ;
+        c->tile_grid = c->num_cu * 8;
     }
     CZ_HIP(c, hipMalloc((void**)&c->lit_arena, (bytes + 15) & ~(size_t)15));
     c->lit_capacity = bytes;
+    /* one list entry per Huffman section / per run: bounded by the arena for sections that take a node (>= 32 bytes each); the
+       others are bounded here by one entry per 256 bytes of arena — a frame whose entries do not fit is simply not pre-passed */
+    size_t cap = bytes / 256 + 65536; if (cap > (1u << 24)) cap = 1u << 24;
+    CZ_HIP(c, hipMalloc((void**)&c->lit_segs, cap * sizeof(cz_lit_seg)));
+    CZ_HIP(c, hipMalloc((void**)&c->copy_segs, cap * sizeof(cz_copy_seg)));
+    c->seg_capacity = (uint32_t)cap;
     return CZ_OK;
 }
 
@@ -330,10 +352,14 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (c->lit_first_cap < n) {
                 if (c->lit_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->lit_first); c->lit_first = nullptr; c->lit_first_cap = 0; }
                 CZ_HIP(c, hipMalloc((void**)&c->lit_first, n * 8)); c->lit_first_cap = n;
+                if (c->frame_pre) (void)hipFree(c->frame_pre);
+                c->frame_pre = nullptr;
+                CZ_HIP(c, hipMalloc((void**)&c->frame_pre, n * 4));
             }
             static const unsigned long long top0[4] = {64, 0, 0, 0};    /* offset 0 = "no node" */
             CZ_HIP(c, hipMemcpyAsync(c->lit_top, top0, 32, hipMemcpyHostToDevice, c->stream));
             a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
+            a.lit_segs = c->lit_segs; a.lit_seg_capacity = c->seg_capacity; a.copy_segs = c->copy_segs; a.copy_seg_capacity = c->seg_capacity; a.frame_pre = c->frame_pre;
         }
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
         a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order;
@@ -342,32 +368,35 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
-        /* the literals pass may start when the chain kernel does (not before: it would take the LDS the chain kernel's
-           workgroups need and hold them up) */
+        const bool use_exec = c->exec_kernel && lit_pass && !c->batch_dict;
+        if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
+        /* the literal and copy kernels may start when the chain kernel does (not before: they would take the LDS the chain
+           kernel's workgroups need and hold them up) */
         if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
         const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
         if (lit_pass) {
-            /* the literals pass on its own stream, next to the chain kernel */
+            /* cz_huf_kernel and cz_tile_kernel on streams of their own, next to the chain kernel */
             CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            cz_batch_args l = a; l.literals_only = 1; l.work_counter = c->lit_counter;
-            const size_t lmax = (size_t)(c->lit_grid < c->lit_slots ? c->lit_grid : c->lit_slots);
-            const int lgrid = (int)(n < lmax ? n : lmax);
-            hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(lgrid), dim3(CZ_WG_THREADS), 0, c->stream2, l);
+            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+            CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+            hipLaunchKernelGGL(cz_tile_kernel, dim3(c->tile_grid), dim3(256), 0, c->stream3, a);
+            CZ_HIP(c, hipGetLastError());
+            CZ_HIP(c, hipEventRecord(c->ev_join3, c->stream3));
             CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* chain kernel done AND literals pass done */
+            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
+            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* all three done */
             c->timed_lit = true;
         } else c->timed_lit = false;
         c->timed_chain = true;
         c->timed_exec = false;
-        if (c->exec_kernel && lit_pass && !c->batch_dict) {
+        if (use_exec) {
             /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of
                its own); it lists every other frame for the launch below */
-            a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list;
             const int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
             hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
             CZ_HIP(c, hipGetLastError());

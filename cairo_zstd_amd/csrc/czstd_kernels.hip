@@ -18,9 +18,8 @@
  *                 every sequence its literal and output offsets, short chunks are assembled in LDS,
  *                 matches are resolved in dependency rounds (ballot + first-undone watermark), long
  *                 copies are done cooperatively.
- * The same kernel launched with literals_only = 1 is the literals pass (Huffman literals of every
- * pre-passed frame into the literal arena, beside cz_chain_kernel).  cz_dict_setup_kernel parses a
- * dictionary with the same table builders.
+ * cz_dict_setup_kernel parses a dictionary with the same table builders.  Compiled a second time with CZ_EXEC_ONLY (in
+ * namespace czx) this file is cz_execute_frames_kernel: the same block walk and record-driven execution without any decoder.
  *
  * Semantics follow the reference (NethermindEth/cairo_zstd) line by line where it matters;
  * each device function cites the reference file:line it restates.  Error codes mirror the
@@ -1967,18 +1966,18 @@ __device__ static int cz_sequences_rec(CzExecCtx& x, const CzLit lit, cz_gcptr64
 /* ------------------------------------------------------------------ one compressed block */
 /* decompress_block (block_decoder.cairo:139-235).  All lanes; uniform status. */
 /* Literal nodes of a frame.  Decoding: arena + cursor = node of the next Huffman-coded block (cursor 0 = this frame has
- * none: decode literals here).  Literals pass (lit_out != nullptr): cursor = the last node written, first = the first. */
-struct CzLitPass { cz_gptr arena; uint64_t cursor, first; uint32_t last_nseq; };
+ * none: decode literals here). */
+struct CzLitPass { cz_gptr arena; uint64_t cursor; int on; uint32_t pre_blocks; };   /* on: cz_huf_kernel decoded this frame's Huffman literals; cursor: node of the
+                                                                                        next such block that has one; pre_blocks: leading blocks whose output is already there */
 __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCtx& x, cz_gptr lit_scratch,
-                                           cz_gptr16 huf_global, int last_block, cz_gcptr64 arena, uint64_t& chain_cursor, CzLitPass& lp,
-                                           const cz_batch_args* lit_out = nullptr) {
+                                           cz_gptr16 huf_global, int last_block, cz_gcptr64 arena, uint64_t& chain_cursor, CzLitPass& lp, int predone) {
     CzBroadcast& bc = sh.bc;
     CZ_PROF_DECL; CZ_PROF_T0();
     /* stage the head of the block for the serial header / tree parsers */
     const uint32_t stage_hi = bsize < 512 ? bsize : 512;
     for (uint32_t i = (uint32_t)LANE; i < stage_hi; i += 64) sh.a.t1.stage[i] = blk[i];
     __syncthreads();
-    const int have_literals = !lit_out && lp.cursor != 0;
+    const int have_literals = lp.on;
     if (LANE == 0) bc.err = cz_parse_sections(blk, bsize, stage_hi, have_literals);
     __syncthreads();
 #ifndef CZ_EXEC_ONLY
@@ -2010,10 +2009,19 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
     const int seq_hdr_err = cz_unii(bc.seq_hdr_err);
     CzLit lit; lit.rle = 0; lit.byte = 0; lit.len = regen; lit.p = blk;
     const uint32_t lt = cz_uni(bc.lit_type), nseq_early = seq_hdr_err ? 1u : nseq;
+    if (predone) {
+        /* a block without sequences ahead of the frame's first block with sequences: cz_tile_kernel / cz_huf_kernel already put its
+           literals — its whole output (block_decoder.cairo:229-232) — where they belong; the scan checked the capacity */
+        if (seq_hdr_err || nseq) return CZ_E_INVALID_ARG;               /* cannot happen: the scan read the same headers */
+        x.produced += regen;
+        __syncthreads();
+        return 0;
+    }
     if (lt == 0) { lit.p = blk + (lit_total - regen); }           /* Raw: used in place (literals_section_decoder.cairo:39-42) */
     else if (lt == 1) { lit.rle = 1; lit.byte = blk[lit_total - 1]; } /* RLE :43-46 */
     else if (have_literals) {
-        /* decoded by the literals pass: node = {next, regen, 0, bytes} */
+        /* decoded by cz_huf_kernel: node = {next, regen, 0, bytes} */
+        if (lp.cursor < 64) return CZ_E_INVALID_ARG;                    /* cannot happen: the scan laid out a node for this block */
         CZ_GLOBAL const uint64_t* node = (CZ_GLOBAL const uint64_t*)(lp.arena + lp.cursor);
         const uint64_t nxt = node[0], meta = node[1];
         if ((uint32_t)meta != regen) return CZ_E_INVALID_ARG;           /* cannot happen: both passes read the same header */
@@ -2028,25 +2036,7 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         return CZX_FALLBACK;                                            /* (cz_parse_sections already said so) */
 #else
         cz_gptr target = lit_scratch;
-        if (lit_out) {
-            /* literals pass: a node of the literal arena (one bump allocation per block) */
-            if (LANE == 0) {
-                const unsigned long long need = 16ull + ((regen + 15u) & ~15u);
-                const unsigned long long at = atomicAdd(lit_out->lit_top, need);
-                bc.d0 = at + need <= lit_out->lit_capacity ? at : 0;
-            }
-            __syncthreads();
-            const uint64_t at = cz_uni64(bc.d0);
-            __syncthreads();
-            if (!at) return CZ_E_OUTPUT_TOO_SMALL;
-            if (LANE == 0) {
-                CZ_GLOBAL uint64_t* node = (CZ_GLOBAL uint64_t*)(lit_out->lit_arena + at);
-                node[0] = 0; node[1] = regen;
-                if (lp.cursor) *(CZ_GLOBAL uint64_t*)(lit_out->lit_arena + lp.cursor) = at;   /* link the previous node */
-            }
-            if (!lp.first) lp.first = at;
-            lp.cursor = at;
-            target = (cz_gptr)(lit_out->lit_arena + at + 16);
+        if (0) {
         } else if (nseq_early == 0) {                                   /* no sequences: decode straight into the output */
             if (x.produced + regen > x.cap) return CZ_E_OUTPUT_TOO_SMALL;
             target = x.out + x.produced;
@@ -2057,7 +2047,6 @@ __device__ static int cz_decompress_block(cz_gcptr blk, uint32_t bsize, CzExecCt
         __syncthreads();
 #endif
     }
-    if (lit_out) { lp.last_nseq = nseq; return seq_hdr_err ? seq_hdr_err : 0; }   /* literals pass: nothing else to do in this block */
     CZ_PROF_ACC(CZ_P_HUFDEC);
     if (seq_hdr_err) return seq_hdr_err;                                /* block_decoder.cairo:198-204 */
     if (nseq == 0) {                                                 /* :229-232 */
@@ -2163,6 +2152,7 @@ struct CzFrameIO {
     uint64_t produced, drained, window;
     uint32_t parse_header, has_checksum, strategy, streaming; uint64_t strategy_n;
     uint32_t verify;          /* compute XXH64 of the decoded frame and compare with the frame's checksum */
+    uint32_t pre_blocks;      /* leading blocks whose output cz_tile_kernel / cz_huf_kernel already produced */
     cz_gcptr dict; uint64_t dict_len;   /* dictionary content of the frame's DecodeBuffer (resumable path only) */
 };
 
@@ -2208,17 +2198,18 @@ __device__ static int cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 
         const uint32_t content = btype == 1 ? 1u : bsize;
         if (io.streaming && avail < content) break;                     /* frame_decoder.cairo:282 */
         if (avail < content) { err = CZ_E_BLOCK_TRUNCATED; break; }
+        const int predone = blocks < io.pre_blocks;                     /* the pre-pass kernels produced this block's output */
         if (btype == 0) {                                               /* Raw, block_decoder.cairo:97-103 */
             if (x.produced + bsize > x.cap) { err = CZ_E_OUTPUT_TOO_SMALL; break; }
-            cz_coop_copy(x.out + x.produced, io.src + body, bsize);
+            if (!predone) cz_coop_copy(x.out + x.produced, io.src + body, bsize);
             x.produced += bsize;
         } else if (btype == 1) {                                        /* RLE :104-123 */
             if (x.produced + bsize > x.cap) { err = CZ_E_OUTPUT_TOO_SMALL; break; }
-            cz_coop_fill(x.out + x.produced, io.src[body], bsize);
+            if (!predone) cz_coop_fill(x.out + x.produced, io.src[body], bsize);
             x.produced += bsize;
         } else {
             CZ_PROF_ACC(CZ_P_HDR);
-            err = cz_decompress_block(io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor, lp);
+            err = cz_decompress_block(io.src + body, bsize, x, lit_scratch, huf_global, (int)blast, arena, chain_cursor, lp, predone);
             CZ_PROF_T0();
             if (err) break;
         }
@@ -2259,44 +2250,6 @@ __device__ static int cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 
     return err;
 }
 
-#ifndef CZ_EXEC_ONLY
-/* Literals pass over one frame (args.literals_only): walks the frame's blocks and decodes the Huffman-coded literals of
- * every compressed block into nodes of the literal arena — the part of decompress_block (block_decoder.cairo:139-196) that
- * needs neither the sequences nor the window, so it can run next to cz_chain_kernel.  All or nothing per frame: on any
- * irregularity, on a first sequences section shorter than chain_min_nseq (the pre-pass will not take the frame) or when
- * the arena is full, lit_first[f] stays 0 and the decode kernel does the frame's literals itself. */
-__device__ static uint64_t cz_run_frame_literals(const cz_batch_args& a, cz_gcptr src, uint64_t src_len, cz_gptr lit_scratch) {
-    CzBroadcast& bc = sh.bc;
-    if (LANE == 0) { bc.d0 = 0; bc.d1 = 0; bc.err = cz_parse_frame_header(src, src_len, bc); }
-    __syncthreads();
-    int err = cz_unii(bc.err);
-    uint64_t pos = cz_uni(bc.hdr_len);
-    __syncthreads();
-    if (err) return 0;
-    CzExecCtx x; x.out = nullptr; x.cap = 0; x.produced = 0; x.drained = 0; x.window = 0; x.lit_used = 0;
-    CzLitPass lp; lp.arena = nullptr; lp.cursor = 0; lp.first = 0; lp.last_nseq = 0;
-    uint64_t no_chain = 0; int seen_seq = 0;
-    for (;;) {
-        if (src_len - pos < 3) return 0;
-        const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
-        const uint32_t btype = (b0 >> 1) & 3, bsize = (b0 >> 3) | (b1 << 5) | (b2 << 13), blast = b0 & 1;
-        if (btype == 3 || bsize > 128u * 1024u) return 0;
-        const uint64_t body = pos + 3; const uint32_t content = btype == 1 ? 1u : bsize;
-        if (src_len - body < content) return 0;
-        if (btype == 2) {
-            lp.last_nseq = 0;
-            err = cz_decompress_block(src + body, bsize, x, lit_scratch, (cz_gptr16)(lit_scratch + CZ_LIT_SCRATCH_BYTES), (int)blast, nullptr, no_chain, lp, &a);
-            if (err) return 0;
-            if (!seen_seq && lp.last_nseq) { seen_seq = 1; if (lp.last_nseq < a.chain_min_nseq) return 0; }
-        }
-        __syncthreads();
-        pos = body + content;
-        if (blast) break;
-    }
-    return seen_seq ? (lp.first ? lp.first : 1) : 0;                   /* 1: regular, has sequences, no Huffman-coded block: nothing to pre-decode */
-}
-
-#endif /* !CZ_EXEC_ONLY */
 __device__ static void cz_state_reset() {                   /* scratch.cairo:23-40 */
     if (LANE == 0) {
         sh.hist[0] = 1; sh.hist[1] = 4; sh.hist[2] = 8;
@@ -2381,12 +2334,13 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
 
 #endif /* !CZ_EXEC_ONLY */
 #ifdef CZ_EXEC_ONLY
-/* cz_execute_frames_kernel: the frames the pre-pass finished (chain records from cz_chain_kernel AND literals from the literals
- * pass) — block walk, record-driven execution of the sequences (sequence_execution.cairo:12-83), Raw / RLE blocks, checksum.
+/* cz_execute_frames_kernel: the frames the pre-pass finished (chain records from cz_chain_kernel AND literals from
+ * cz_huf_kernel) — block walk, record-driven execution of the sequences (sequence_execution.cairo:12-83), Raw / RLE blocks, checksum.
  * Same source as cz_decode_frames_kernel minus every decoder (no Huffman table, no FSE tables, no bit ring in LDS: 3 KB per
  * wave instead of 10.5 KB, and a register budget of its own).  Any other frame — and any frame that turns out to need a
  * decoder after all — is appended to args.fallback_list for cz_decode_frames_kernel. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_execute_frames_kernel(cz_batch_args a) {
+    if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
     cz_init_llml();
     for (;;) {
         __syncthreads();
@@ -2396,15 +2350,20 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
         if (fi >= a.n) break;
         const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
         int err = CZX_FALLBACK;
+        /* regular to its last block, everything listed, and cz_huf_kernel met nothing irregular; a frame whose chains
+           cz_chain_kernel gave up on (first == 0 with sequences in it) comes back from cz_run_frame */
         const uint64_t first = cz_uni64(a.frame_first[f]), lfirst = cz_uni64(a.lit_first[f]);
-        if (first != 0 && lfirst != 0) {
+        const uint32_t pre = cz_uni(a.frame_pre[f]);
+        if (((pre & CZ_PRE_DONE) && lfirst != 0) || pre == CZ_PRE_PUSHED) continue;   /* all of it done by the pre-pass kernels, result record written by the scan (or taken back and listed by cz_huf_kernel) */
+        if ((pre & CZ_PRE_REGULAR) && lfirst != 0) {
             CzFrameIO io;
             io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];
             io.produced = 0; io.drained = 0; io.window = 0; io.parse_header = 1; io.has_checksum = 0;
             io.strategy = 0; io.strategy_n = 0; io.streaming = 0; io.verify = a.verify_checksum; io.dict = nullptr; io.dict_len = 0;
+            io.pre_blocks = pre & CZ_PRE_COUNT;
             cz_state_reset();
             __syncthreads();
-            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0; lp.cursor = lfirst;
+            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.on = 1; lp.cursor = lfirst;
             err = cz_run_frame(io, nullptr, nullptr, (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena, first, lp);
             if (err != CZX_FALLBACK && LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
         }
@@ -2414,6 +2373,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
 #else
 /* Persistent grid: every workgroup (one wavefront) pulls frames off a shared counter. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_decode_frames_kernel(cz_batch_args a) {
+    if (a.fallback_list && cz_uni(*a.fallback_count) == 0) return;      /* behind cz_execute_frames_kernel, and it left nothing */
     cz_init_llml();
     cz_gptr lit_scratch = (cz_gptr)(a.lit_scratch + (uint64_t)blockIdx.x * a.lit_scratch_stride);
 #ifdef CZ_PROFILE
@@ -2425,28 +2385,15 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
         __syncthreads();
         const uint32_t fi = cz_uni(sh.frame_idx);
         /* behind cz_execute_frames_kernel: only the frames it left (args.fallback_list, in the order it met them) */
-        if (fi >= (a.fallback_list && !a.literals_only ? cz_uni(*a.fallback_count) : a.n)) break;
-        const uint32_t f = a.fallback_list && !a.literals_only ? cz_uni(a.fallback_list[fi]) : (a.frame_order ? cz_uni(a.frame_order[fi]) : fi);   /* the pre-pass sorted the frames: longest first */
-        if (a.literals_only) {
-            /* a frame the scan kernel found no sequences section in (or did not list) gains nothing from literal nodes:
-               the main pass decodes its literals straight to where they are used */
-            if (a.chain_arena && cz_uni64(a.frame_first[f]) == 0) { if (LANE == 0) a.lit_first[f] = 0; continue; }
-            cz_state_reset();
-            __syncthreads();
-            const uint64_t first = cz_run_frame_literals(a, (cz_gcptr)(a.in_base + a.in_off[f]), a.in_len[f], lit_scratch);
-            if (LANE == 0) a.lit_first[f] = first;
-#ifdef CZ_PROFILE
-            if (LANE == 0 && a.prof) for (int i = 0; i < 11; i++) { atomicAdd(&a.prof[20 + i], sh.prof[i]); sh.prof[i] = 0; }   /* the literals pass has phase slots of its own */
-#endif
-            continue;
-        }
+        if (fi >= (a.fallback_list ? cz_uni(*a.fallback_count) : a.n)) break;
+        const uint32_t f = a.fallback_list ? cz_uni(a.fallback_list[fi]) : (a.frame_order ? cz_uni(a.frame_order[fi]) : fi);   /* the pre-pass sorted the frames: longest first */
         CzFrameIO io;
         if (a.tasks) {
             const cz_device_task t = a.tasks[f];
             io.src = (cz_gcptr)t.src; io.src_len = t.src_len; io.dst = (cz_gptr)t.dst; io.dst_cap = t.dst_cap; io.produced = t.produced;
             io.drained = t.drained; io.window = t.window_size; io.parse_header = 0; io.has_checksum = t.has_checksum;
             io.strategy = t.strategy; io.strategy_n = t.strategy_n; io.streaming = t.streaming; io.verify = 0;
-            io.dict = (cz_gcptr)t.dict; io.dict_len = t.dict_len;
+            io.dict = (cz_gcptr)t.dict; io.dict_len = t.dict_len; io.pre_blocks = 0;
             /* restore carried state (the Huffman table stays in t.state->huf until a Treeless block asks for it) */
             cz_device_frame_state* gs = t.state;
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { CZ_FSE_LL[i] = gs->fse[0][i]; CZ_FSE_ML[i] = gs->fse[2][i]; }
@@ -2457,7 +2404,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
                 sh.dict_lag[0] = (uint32_t)gs->dict_lag; sh.dict_lag[1] = (uint32_t)(gs->dict_lag >> 32);
             }
             __syncthreads();
-            CzLitPass nolit; nolit.arena = nullptr; nolit.cursor = 0; nolit.first = 0; nolit.last_nseq = 0;
+            CzLitPass nolit; nolit.arena = nullptr; nolit.cursor = 0; nolit.on = 0;
             cz_run_frame(io, lit_scratch, (cz_gptr16)gs->huf, (CZ_GLOBAL cz_frame_result*)&a.results[f], nullptr, 0, nolit);
             for (uint32_t i = (uint32_t)LANE; i < 512; i += 64) { gs->fse[0][i] = CZ_FSE_LL[i]; gs->fse[2][i] = CZ_FSE_ML[i]; }
             for (uint32_t i = (uint32_t)LANE; i < 256; i += 64) gs->fse[1][i] = CZ_FSE_OF[i];
@@ -2485,8 +2432,10 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
                 }
             }
             __syncthreads();
-            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena; lp.first = 0; lp.last_nseq = 0;
-            lp.cursor = a.lit_arena ? cz_uni64(a.lit_first[f]) : 0;
+            /* what the pre-pass left for this frame: literal nodes / literals done (cz_huf_kernel) and leading blocks already in place */
+            CzLitPass lp; lp.arena = (cz_gptr)a.lit_arena;
+            lp.cursor = a.lit_arena ? cz_uni64(a.lit_first[f]) : 0; lp.on = lp.cursor != 0;
+            io.pre_blocks = lp.on ? cz_uni(a.frame_pre[f]) & CZ_PRE_COUNT : 0u;
             cz_run_frame(io, lit_scratch, (cz_gptr16)(lit_scratch + CZ_LIT_SCRATCH_BYTES), (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena,
                          a.chain_arena ? cz_uni64(a.frame_first[f]) : 0, lp);
 #ifdef CZ_PROFILE

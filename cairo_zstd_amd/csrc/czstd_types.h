@@ -65,8 +65,33 @@ typedef struct cz_blk_desc {
     uint32_t pad;
     uint64_t hdr;             /* index of the block's header in the chain arena */
 } cz_blk_desc;
-#define CZ_SCAN_CTL_WORDS 136  /* scan_ctl: [0..31] blocks per size class (class = bit length of nseq), [32..63] fill counters, [64] block work counter,
-                                  [72..103] frames per size class (bit length of the compressed size), [104..135] fill counters */
+#define CZ_SCAN_CTL_WORDS 224  /* scan_ctl: [0..31] blocks per size class (class = bit length of nseq), [32..63] fill counters, [64] block work counter,
+                                  [72..103] frames per size class (bit length of the compressed size), [104..135] fill counters,
+                                  [136..167] Huffman literal sections per size class (bit length of the regenerated size), [168..199] fill counters,
+                                  [200] work counter of cz_huf_kernel, [201] copy segments counted, [202] placed, [203] work counter of cz_tile_kernel,
+                                  [204] frames that are not CZ_PRE_DONE (cz_execute_frames_kernel has nothing to do when there are none) */
+/* One Huffman-coded literals section, as cz_scan_kernel lists it for cz_huf_kernel. */
+typedef struct cz_lit_seg {
+    uint32_t frame;           /* batch entry */
+    uint32_t blk_off;         /* offset of the block's content in the frame */
+    uint32_t bsize;           /* size of the content */
+    uint32_t def;             /* Treeless: list entry of the block whose tree description it reuses; ~0: its own */
+    uint64_t dst;             /* where the literals go: offset into the output arena (direct) or into the literal arena (node payload) */
+    uint32_t regen;           /* regenerated size */
+    uint32_t direct;          /* 1: the block has no sequences and its place in the frame's output is known: the literals ARE its output */
+} cz_lit_seg;
+/* One run of output bytes whose source and place are known without decoding: a Raw or RLE block, or the Raw / RLE literals of
+ * a block without sequences, ahead of the frame's first block with sequences (cz_scan_kernel -> cz_tile_kernel). */
+typedef struct cz_copy_seg {
+    uint64_t src;             /* offset into the input arena: the bytes (copy) or the one byte (fill) */
+    uint64_t dst;             /* offset into the output arena */
+    uint32_t len;
+    uint32_t fill;            /* 0 copy, 1 fill */
+} cz_copy_seg;
+#define CZ_PRE_REGULAR 0x80000000u   /* frame_pre[f]: the scan walked the frame to its end and listed all of it; low bits: leading blocks done by the pre-pass kernels */
+#define CZ_PRE_DONE    0x40000000u   /* ... and ALL its blocks are done by them: the scan also wrote the frame's result record (no content checksum to verify) */
+#define CZ_PRE_PUSHED  0x20000000u   /* (without CZ_PRE_REGULAR) cz_huf_kernel took a CZ_PRE_DONE frame back and listed it for cz_decode_frames_kernel itself */
+#define CZ_PRE_COUNT   0x1FFFFFFFu
 
 typedef struct cz_batch_args {
     const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
@@ -88,12 +113,15 @@ typedef struct cz_batch_args {
     uint32_t* frame_order;                    /* NULL, or the order in which the decode kernels take the frames: largest compressed size first (cz_scan_kernel) */
     uint32_t* exec_counter;                   /* work counter of cz_execute_frames_kernel */
     uint32_t* fallback_list; uint32_t* fallback_count;   /* frames cz_execute_frames_kernel leaves to cz_decode_frames_kernel (NULL: that kernel takes all n frames) */
-    /* optional literals pass (cz_decode_frames_kernel with literals_only = 1, launched next to cz_chain_kernel): the
-       Huffman-coded literals of every frame the pre-pass takes are decoded into lit_arena — per block a node
-       {u64 offset of the next node | 0, u32 regenerated size, u32 0, bytes...}; lit_first[f] = offset of frame f's
-       first node, 0 = none: the decode kernels then decode that frame's literals themselves */
+    /* literals and copies of the pre-pass (cz_huf_kernel, cz_tile_kernel next to cz_chain_kernel): cz_scan_kernel lists every
+       Huffman-coded literals section and every run of bytes whose place is known without decoding.  Literals of a block that
+       has sequences (or whose place is not known) go to lit_arena — per block a node {u64 offset of the next node | 0,
+       u32 regenerated size, u32 0, bytes...} laid out and linked by the scan; lit_first[f] = offset of frame f's first node,
+       1 = the frame's literals are done and it has no node, 0 = the decode kernels decode that frame's literals themselves.
+       frame_pre[f]: CZ_PRE_REGULAR | leading blocks whose output the pre-pass kernels produce; 0 = nothing (the scan or
+       cz_huf_kernel met something irregular: cz_decode_frames_kernel does the frame from scratch). */
     uint8_t* lit_arena; uint64_t lit_capacity; unsigned long long* lit_top; uint64_t* lit_first;
-    uint32_t literals_only;
+    cz_lit_seg* lit_segs; uint32_t lit_seg_capacity; cz_copy_seg* copy_segs; uint32_t copy_seg_capacity; uint32_t* frame_pre;
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
 } cz_batch_args;
 

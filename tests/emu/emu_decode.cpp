@@ -12,6 +12,7 @@
 
 thread_local emu_dim3 threadIdx;
 thread_local emu_dim3 blockIdx;
+emu_dim3 gridDim;
 pthread_barrier_t emu_barrier;
 pthread_barrier_t emu_wbar[EMU_MAX_WAVES];
 volatile uint64_t emu_xchg_all[EMU_MAX_WAVES][64];
@@ -40,6 +41,7 @@ static void* emu_watchdog(void*) {
 
 #include "czstd_kernels.hip"
 #include "czstd_chain.hip"
+#include "czstd_pre.hip"
 #define CZ_EXEC_ONLY 1
 namespace czx {
 #include "czstd_kernels.hip"
@@ -53,8 +55,10 @@ static void* lane_main(void* p) {
     emu_lane_done[la->lane] = 0;
     if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) czx::cz_execute_frames_kernel(la->a);
     else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
+    else if (la->which == 7) cz_huf_kernel(la->a);
+    else if (la->which == 8) cz_tile_kernel(la->a);
     else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
-    else cz_decode_frames_kernel(la->a);                                /* 1 decode, 3 literals pass */
+    else cz_decode_frames_kernel(la->a);
     emu_lane_done[la->lane] = 1;
     return nullptr;
 }
@@ -98,10 +102,16 @@ int main(int argc, char** argv) {
     { pthread_t wd; pthread_create(&wd, nullptr, emu_watchdog, nullptr); pthread_detach(wd); }
     for (int w = 0; w < EMU_MAX_WAVES; w++) pthread_barrier_init(&emu_wbar[w], nullptr, 64);
     uint32_t exec_counter = 0; a.exec_counter = &exec_counter;
-    /* EMU_LIT=<bytes>: literals pass (literals_only launch of the decode kernel) with an arena of that many bytes */
+    /* EMU_LIT=<bytes>: the literal / copy half of the pre-pass (cz_huf_kernel, cz_tile_kernel) with a literal arena of that many bytes */
     unsigned long long lit_top[4] = {64, 0, 0, 0}; std::vector<uint64_t> lit_first(n ? n : 1, 0); uint8_t* lit_arena = nullptr;
     const size_t lit_bytes = arena && getenv("EMU_LIT") ? (size_t)atoll(getenv("EMU_LIT")) : 0;
-    if (lit_bytes) { lit_arena = (uint8_t*)malloc(lit_bytes); a.lit_arena = lit_arena; a.lit_capacity = lit_bytes; a.lit_top = lit_top; a.lit_first = lit_first.data(); }
+    std::vector<cz_lit_seg> lit_segs; std::vector<cz_copy_seg> copy_segs; std::vector<uint32_t> frame_pre(n ? n : 1, 0);
+    if (lit_bytes) {
+        lit_arena = (uint8_t*)malloc(lit_bytes); a.lit_arena = lit_arena; a.lit_capacity = lit_bytes; a.lit_top = lit_top; a.lit_first = lit_first.data();
+        const size_t cap = getenv("EMU_SEGS") ? (size_t)atoll(getenv("EMU_SEGS")) : lit_bytes / 256 + 4096;
+        lit_segs.resize(cap); copy_segs.resize(cap);
+        a.lit_segs = lit_segs.data(); a.lit_seg_capacity = (uint32_t)cap; a.copy_segs = copy_segs.data(); a.copy_seg_capacity = (uint32_t)cap; a.frame_pre = frame_pre.data();
+    }
     /* passes: [chain pre-pass, [literals pass, [cz_execute_frames_kernel (EMU_EXEC=1),]]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
     const int with_exec = arena && lit_bytes && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
     uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
@@ -135,30 +145,34 @@ int main(int argc, char** argv) {
         a.dict_state = dict_state; a.dict = dict_exact + dict_res[1]; a.dict_len = dict_raw.size() - dict_res[1];
     }
     /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel */
-    const int order[6] = {4, 5, 0, 3, 2, 1};
-    for (int pi = arena ? 0 : 5; pi < 6; pi++) {
+    if (with_exec) { a.fallback_list = fallback_list.data(); a.fallback_count = &fallback_count; }   /* as the host library: set before cz_huf_kernel, which may list frames too */
+    const int order[7] = {4, 5, 0, 7, 8, 2, 1};
+    for (int pi = arena ? 0 : 6; pi < 7; pi++) {
         const int which = order[pi];
         if (which == 2 && !with_exec) continue;
-        if (which == 3 && !lit_bytes) continue;
-        const int nthreads = 64;
-        if (which == 2) { a.fallback_list = fallback_list.data(); a.fallback_count = &fallback_count; }   /* from here on */
-        const int nblocks = which >= 4 ? (int)((n + 63) / 64) : (which == 3 ? 1 : grid);
-        emu_nthreads = nthreads;
+        if ((which == 7 || which == 8) && !lit_bytes) continue;
+        const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : 64);
+
+        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 ? 1 : grid);
+        emu_nthreads = nthreads; gridDim.x = (unsigned)nblocks;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
-        uint32_t lit_counter = 0;
         for (int b = 0; b < nblocks; b++) {
             std::vector<pthread_t> th((size_t)nthreads); std::vector<lane_arg> la((size_t)nthreads);
             for (int l = 0; l < nthreads; l++) {
                 la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which;
-                if (which == 3) { la[l].a.literals_only = 1; la[l].a.work_counter = &lit_counter; }
-                if (which >= 4) la[l].a.scan_pass = (uint32_t)(which - 4);
+                if (which == 4 || which == 5) la[l].a.scan_pass = (uint32_t)(which - 4);
                 pthread_create(&th[l], nullptr, lane_main, &la[l]);
             }
             for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);
         }
         pthread_barrier_destroy(&emu_barrier);
     }
-    if (lit_bytes) { unsigned long long nl = 0; for (uint64_t i = 0; i < n; i++) nl += lit_first[i] != 0; fprintf(stderr, "EMU_LIT: %llu frames have literal nodes, arena top %llu\n", nl, lit_top[0]); free(lit_arena); }
+    if (lit_bytes) {
+        unsigned long long nl = 0, np = 0; for (uint64_t i = 0; i < n; i++) { nl += lit_first[i] != 0; np += (frame_pre[i] & CZ_PRE_COUNT) != 0; }
+        fprintf(stderr, "EMU_LIT: %llu frames have their literals done, %llu have leading blocks in place, arena top %llu, %u sections, %u runs\n", nl, np, lit_top[0],
+                scan_ctl[168] + scan_ctl[169] + scan_ctl[170] + scan_ctl[171] + scan_ctl[172] + scan_ctl[173] + scan_ctl[174] + scan_ctl[175] + scan_ctl[176] + scan_ctl[177] + scan_ctl[178] + scan_ctl[179] + scan_ctl[180] + scan_ctl[181] + scan_ctl[182] + scan_ctl[183] + scan_ctl[184] + scan_ctl[185] + scan_ctl[186] + scan_ctl[187], scan_ctl[202]);
+        free(lit_arena);
+    }
     if (with_exec) fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_execute_frames_kernel\n", (unsigned long long)(n - fallback_count));
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {

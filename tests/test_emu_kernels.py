@@ -91,7 +91,7 @@ def test_emu_chain_prepass():
         frames.append(z[: len(z) // 2])
         caps.append(len(orig) * 2 + 4096)
     _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20)
-    assert "frames have literal nodes" in emu_runner.run.last_stderr
+    assert "frames have their literals done" in emu_runner.run.last_stderr
     _run_and_compare(frames[::4], caps[::4], chain_bytes=8 << 20)
     _run_and_compare(frames[:12], caps[:12], chain_bytes=4096, lit_bytes=6000)
 
