@@ -4,10 +4,11 @@
     python bench.py --gpus N --steps K --warmup W [--workload full_4a|huf_literals|raw_rle|full_4b|mix]
 
 A "step" is one pass of the hot path (one cz_decode_batch_device call) over one batch of synthetic
-frames that already sits in HBM.  With the pre-pass on (full_4a, full_4b, mix) the call launches
-    cz_scan_kernel x2  ->  cz_chain_kernel  ||  cz_decode_frames_kernel(literals pass, second stream)
-                       ->  cz_decode_frames_kernel
-and without it (raw_rle, huf_literals) the one persistent-grid cz_decode_frames_kernel.
+frames that already sits in HBM.  The call launches
+    cz_scan_kernel x2  ->  cz_chain_kernel || cz_huf_kernel || cz_tile_kernel   (three streams: FSE chains, Huffman literals
+                                                                                  and Raw / RLE runs, unit of work = a block)
+                       ->  cz_execute_frames_kernel (frames the pre-pass finished)  ->  cz_decode_frames_kernel (the rest)
+(--no-chain-prepass: the one persistent-grid cz_decode_frames_kernel of round 1).
 Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full compressed
 128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
 
@@ -21,13 +22,16 @@ of the decoded bytes to rank 0 as a separate leg.
 Prints ONE JSON line on rank 0 (see the driver contract in the task description), with
   roofline      achieved = algorithmic bytes / mean duration of the step's kernels (hipEvents inside
                 the library, on the streams the kernels run on), against the 8 TB/s HBM peak;
-                serial_chain_floor = what one FSE chain per block allows at the measured minimum
-                step latency; traffic = PMC bytes from profiles/r2 when that file was measured on
+                chain_latency_floor = how long cz_chain_kernel's slots need for this batch at the
+                measured minimum step latency (a property of its slot count, not of zstd);
+                traffic = PMC bytes from profiles/r3 when that file was measured on
                 these very kernel sources (kernel_source_hash), else null
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on all host cores over the whole
-                batch, on one thread over a bounded sample, and libzstd on one thread (rank 0, N=1)
+                batch, on one thread over a bounded sample, and libzstd on one thread and on all
+                cores (rank 0, N=1)
   bit_exact     the last launch decodes into a 0xA5-poisoned buffer and EVERY frame is compared
-                with the oracle's output by XXH64
+                with the oracle's output by XXH64 — for the headline workload and for every entry of
+                other_workloads
 """
 import argparse
 import json
@@ -80,7 +84,7 @@ def _kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cairo_zstd_amd", "csrc")
-    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_host.hip", "czstd_types.h"):
+    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_pre.hip", "czstd_host.hip", "czstd_types.h"):
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -115,8 +119,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--no-verify-all", action="store_true", help="check only a sample of the frames against the oracle (default: every frame, by XXH64)")
-    ap.add_argument("--no-chain-prepass", action="store_true", help="run the FSE chains inside cz_decode_frames_kernel (single launch)")
-    ap.add_argument("--no-literals-pass", action="store_true", help="decode Huffman literals inside the decode kernel instead of next to the chain pre-pass")
+    ap.add_argument("--no-chain-prepass", action="store_true", help="diagnostic: everything inside cz_decode_frames_kernel (single launch, as in round 1)")
+    ap.add_argument("--no-literals-pass", action="store_true", help="diagnostic: no cz_huf_kernel / cz_tile_kernel; literals and Raw / RLE blocks inside the decode kernel")
     ap.add_argument("--no-exec-kernel", dest="exec_kernel", action="store_false", help="diagnostic: pre-passed frames on cz_decode_frames_kernel too, not on cz_execute_frames_kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
@@ -188,8 +192,8 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
-    # the FSE-chain pre-pass (block-parallel: cz_scan_kernel + cz_chain_kernel) for every workload that has sequences
-    chain_prepass = not args.no_chain_prepass and args.workload in ("full_4a", "full_4b", "mix")
+    # the block-parallel pre-pass (cz_scan_kernel + cz_chain_kernel || cz_huf_kernel || cz_tile_kernel) for every workload
+    chain_prepass = not args.no_chain_prepass
     arena_bytes = int(batch.length.sum()) * 8 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
     lit_bytes = regen_bytes + (16 << 20)                               # decoded literal bytes never exceed the decoded size
     if chain_prepass:
@@ -220,12 +224,13 @@ def main():
     # Per-launch kernel durations for the roofline: K more launches of the same step, each read
     # from the hipEvent pair the library records around the kernel on the stream it runs on
     # (reading a pair needs a sync, which must stay out of the timed region above).
-    kernel_ms, chain_ms, exec_ms = [], [], []
+    kernel_ms, chain_ms, exec_ms, tail_ms = [], [], [], []
     for _ in range(args.steps):
         decode()
         kernel_ms.append(ctx.last_kernel_ms())
-        chain_ms.append(ctx.last_chain_ms())
-        exec_ms.append(ctx.last_exec_ms())
+        chain_ms.append(ctx.last_chain_ms())                              # scans + cz_chain_kernel
+        exec_ms.append(ctx.last_exec_ms())                                # cz_execute_frames_kernel
+        tail_ms.append(ctx.last_literals_tail_ms())                       # how long cz_huf_kernel / cz_tile_kernel ran on after cz_chain_kernel
     torch.cuda.synchronize()
 
     # ---- decode + gather (config 5's exchange step), timed separately
@@ -308,7 +313,7 @@ def main():
             nf = 12500 if wl == "mix" else 10000
             # the chain pre-pass only pays for frames with long sequences sections
             ob = synth.generate(wl, nf, nthreads=max(1, min(32, ncpu)))
-            pre = wl in ("full_4a", "full_4b", "mix") and not args.no_chain_prepass
+            pre = not args.no_chain_prepass
             ctx.set_chain_arena(int(ob.length.sum()) * 8 + (64 << 20) if pre else 0)
             ctx.set_literal_arena(int(ob.regen.sum()) + (16 << 20) if pre and not args.no_literals_pass else 0)
             o_off, o_cap, o_total = ob.out_layout(256)
@@ -321,13 +326,32 @@ def main():
                 ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, to.data_ptr(), td[2].data_ptr(),
                                         td[3].data_ptr(), tr.data_ptr())
                 ms.append(ctx.last_kernel_ms())
+            # one more launch into a poisoned buffer, every frame compared with the oracle by XXH64 (as for the headline workload)
+            to.fill_(0xA5)
+            tr.zero_()
+            torch.cuda.synchronize()
+            ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, to.data_ptr(), td[2].data_ptr(),
+                                    td[3].data_ptr(), tr.data_ptr())
+            torch.cuda.synchronize()
             r2 = tr.cpu().numpy().view(cz.RESULT_DTYPE)
             okw = bool((r2["status"] == 0).all() and (r2["bytes_produced"] == ob.regen).all())
+            exact, nver = None, 0
+            if not args.no_verify_all:
+                oh = to.cpu().numpy()
+                oref, olen2, ost2 = oracle.decode_batch(ob.base, ob.off, ob.length, o_off, o_cap, o_total, nthreads=threads)
+                exact = okw and bool((ost2 == 0).all() and (olen2 == ob.regen).all())
+                for i in range(nf):
+                    lo, hi = int(o_off[i]), int(o_off[i] + ob.regen[i])
+                    if oracle.xxh64(oh[lo:hi]) != oracle.xxh64(oref[lo:hi]):
+                        exact = False
+                        break
+                    nver += 1
+                del oh, oref
             ab = int(ob.length.sum() + ob.regen.sum())
             k = float(np.mean(ms[1:]))
             others[wl] = {"frames": nf, "decompressed_MBps": float(ob.regen.sum()) / (k * 1e-3) / 1e6, "kernel_ms": k,
                           "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "all_frames_ok": okw}
+                          "all_frames_ok": okw, "bit_exact": exact, "frames_verified_vs_oracle": nver}
             del ti, td, to, tr
         ctx.set_chain_arena(arena_bytes if chain_prepass else 0)
         ctx.set_literal_arena(lit_bytes if chain_prepass and not args.no_literals_pass else 0)
@@ -367,7 +391,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         lit_pass = chain_prepass and not args.no_literals_pass
-        launches = (("cz_scan_kernel x2 + cz_chain_kernel || cz_decode_frames_kernel(literals pass) + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
+        launches = (("cz_scan_kernel x2 + (cz_chain_kernel || cz_huf_kernel || cz_tile_kernel) + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
                     + ("cz_execute_frames_kernel + " if args.exec_kernel and lit_pass else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
@@ -392,30 +416,34 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_mean": k_ms,
                          "kernel_ms_all": [round(float(x), 4) for x in kernel_ms],
-                         "chain_kernel_ms_mean": float(np.mean(chain_ms)), "exec_kernel_ms_mean": float(np.mean(exec_ms)),
-                         "decode_kernel_ms_mean": k_ms - float(np.mean(chain_ms)) - float(np.mean(exec_ms)),
+                         "chain_kernel_ms_mean": float(np.mean(chain_ms)), "prepass_tail_ms_mean": float(np.mean(tail_ms)),
+                         "exec_kernel_ms_mean": float(np.mean(exec_ms)),
+                         "decode_kernel_ms_mean": k_ms - float(np.mean(chain_ms)) - float(np.mean(tail_ms)) - float(np.mean(exec_ms)),
                          "slowest_rank_kernel_ms_mean": k_ms_all,
                          **ctx.launch_info()},
             "synth_seconds": round(gen_s, 2),
         }
         if args.workload in ("full_4a", "full_4b"):
-            # what the zstd format itself allows on this config: ONE serial FSE chain per block; with every frame in flight
-            # the chains cannot finish before (sequences per block) x (latency of one dependent LDS table lookup)
+            # a property of cz_chain_kernel's layout, not of zstd: 10 240 slots (40 per CU, LDS-bound) each run ONE block's chain, so a
+            # batch of F blocks lasts ceil(F / 10 240) x (sequences per block) x (step latency); 32.3 ns is the dependent table
+            # chase alone on one wave (profiles/r2/microbench_chain_step.txt, variant 6) — a finer split of a chain, or more
+            # slots, would lower it
             nseq = 32768 if args.workload == "full_4a" else 65536
-            step_ns = 32.3                                                 # profiles/r2/microbench_chain_step.txt: ffbh + shift + or + address + ds_read, one wave
-            line["roofline"]["serial_chain_floor"] = {"sequences_per_block": nseq, "min_step_ns": step_ns, "floor_ms": nseq * step_ns * 1e-6,
-                                                      "frac_of_hbm_peak_at_floor": alg_bytes / (nseq * step_ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
-                                                      "source": "profiles/r2/microbench_chain_step.txt (variant 6: the dependent table chase alone)"}
+            step_ns, slots = 32.3, 10240
+            rounds = -(-F // slots)
+            line["roofline"]["chain_latency_floor"] = {"sequences_per_block": nseq, "chain_slots": slots, "rounds": rounds, "min_step_ns": step_ns,
+                                                       "floor_ms": rounds * nseq * step_ns * 1e-6,
+                                                       "source": "profiles/r2/microbench_chain_step.txt (variant 6: the dependent table chase alone)"}
         # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
         # this same command and committed under profiles/ together with the hash of the kernel sources it was made on
-        pmc = os.path.join(ROOT, "profiles", "r2", f"pmc_hbm_traffic_{args.workload}.json")
+        pmc = os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{args.workload}.json")
         if os.path.exists(pmc) and world == 1 and F == 10000:
             t = json.load(open(pmc))
             if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel):
                 line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
-                line["roofline"]["traffic_source"] = f"profiles/r2/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
+                line["roofline"]["traffic_source"] = f"profiles/r3/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
             else:
-                line["roofline"]["traffic_source"] = "profiles/r2 PMC file is from other kernel sources or launch options: not quoted"
+                line["roofline"]["traffic_source"] = "profiles/r3 PMC file is from other kernel sources or launch options: not quoted"
         if copy_ceiling is not None:
             line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling
@@ -461,6 +489,13 @@ def main():
                     zdone += 1
                 cpu_leg["libzstd_single_thread"] = {"value": zbytes / zs / 1e6 if zs else None, "unit": "MB/s", "cores": 1, "all_frames_decoded": bool(zok),
                                                     "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} on the first {zdone} frames, {zs:.2f} s"}
+                # all cores: the same libzstd on a pthread pool inside the oracle library (a Python thread per core spends its time on the GIL)
+                t1 = time.perf_counter()
+                good = oracle.libzstd_batch(batch.base, batch.off, batch.length, out_off, out_cap, out_total, batch.regen, nthreads=threads)
+                zall = time.perf_counter() - t1
+                if good >= 0:
+                    cpu_leg["libzstd_all_cores"] = {"value": regen_bytes / zall / 1e6, "unit": "MB/s", "cores": threads, "all_frames_decoded": bool(good == F),
+                                                    "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} over the whole batch ({F} frames) on {threads} pthreads, one frame per task, {zall:.2f} s wall"}
             line["cpu_baseline"] = cpu_leg
         print(json.dumps(line), flush=True)
     ctx.close()

@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         L.czo_kat_huf_table.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32),
                                         C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32)]
         L.czo_set_d1_reference_nibbles.argtypes = [C.c_int]
+        L.czo_libzstd_batch.restype = C.c_long
+        L.czo_libzstd_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -267,3 +269,13 @@ def decode_frame_with_dict(src, dictionary: Dictionary, cap: int = 1 << 24):
     if st:
         return st, b""
     return 0, fd.collect(cap)
+
+
+def libzstd_batch(in_base: np.ndarray, in_off, in_len, out_off, out_cap, out_total: int, expected_len, nthreads: int = 1):
+    """bench.py's second CPU baseline: the HOST's libzstd (ZSTD_decompress, dlopen) over the batch on `nthreads` pthreads.
+    Returns the number of frames that decoded to their expected length, or -1 when the host has no libzstd.so.1."""
+    in_base = np.ascontiguousarray(in_base, dtype=np.uint8)
+    a = [np.ascontiguousarray(x, dtype=np.uint64) for x in (in_off, in_len, out_off, out_cap, expected_len)]
+    out = np.empty(out_total, dtype=np.uint8)
+    return int(lib().czo_libzstd_batch(in_base.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[0].size, out.ctypes.data,
+                                       a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data, nthreads))

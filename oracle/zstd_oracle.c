@@ -1155,3 +1155,42 @@ CZO_API int czo_decode_single_block(const uint8_t* src, size_t len, uint8_t* dst
     s.buf = NULL; scratch_free(&s); return e;
 }
 CZO_API int czo_abi_version(void) { return 1; }
+
+/* ------------------------------------------------------------------ bench.py's second CPU baseline
+ * The HOST's libzstd (dlopen, when there is one) over a batch of frames on a pthread pool: same argument meaning as
+ * czo_decode_batch.  Not part of the restatement — it only times the production C decoder beside it.
+ * Returns the number of frames that decoded to exactly out_len_expected[i] bytes, or -1 when libzstd.so.1 is absent. */
+#include <dlfcn.h>
+typedef size_t (*czo_zdec_fn)(void*, size_t, const void*, size_t);
+typedef unsigned (*czo_ziserr_fn)(size_t);
+typedef struct { const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len; uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
+                 const uint64_t* want; size_t n; volatile size_t* next; volatile long* good; czo_zdec_fn dec; czo_ziserr_fn iserr; } zbatch_job;
+static void* zbatch_worker(void* p) {
+    zbatch_job* j = (zbatch_job*)p;
+    long ok = 0;
+    for (;;) {
+        const size_t i = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (i >= j->n) break;
+        const size_t r = j->dec(j->out_base + j->out_off[i], (size_t)j->out_cap[i], j->in_base + j->in_off[i], (size_t)j->in_len[i]);
+        if (!j->iserr(r) && r == (size_t)j->want[i]) ok++;
+    }
+    __atomic_fetch_add(j->good, ok, __ATOMIC_RELAXED);
+    return NULL;
+}
+CZO_API long czo_libzstd_batch(const uint8_t* in_base, const uint64_t* in_off, const uint64_t* in_len, size_t n, uint8_t* out_base, const uint64_t* out_off,
+                               const uint64_t* out_cap, const uint64_t* out_len_expected, int nthreads) {
+    void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    czo_zdec_fn dec = (czo_zdec_fn)dlsym(h, "ZSTD_decompress");
+    czo_ziserr_fn iserr = (czo_ziserr_fn)dlsym(h, "ZSTD_isError");
+    if (!dec || !iserr) { dlclose(h); return -1; }
+    volatile size_t next = 0; volatile long good = 0;
+    zbatch_job j = { in_base, in_off, in_len, out_base, out_off, out_cap, out_len_expected, n, &next, &good, dec, iserr };
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, zbatch_worker, &j);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    dlclose(h);
+    return good;
+}

@@ -6,6 +6,11 @@ other (equally valid) bytes, which is why the outputs are committed.
     dict.bin                 ZDICT_trainFromBuffer over 400 small records (magic 0xEC30A437, tables, content)
     frame_XX.zst / .orig     records compressed with ZSTD_compress_usingDict (level 3 / 19): their first sequences
                              reach into the dictionary content and their first block uses the dictionary's tables
+    dict_hist.bin            dict.bin with its three repeat offsets (dictionary.cairo:81-85) patched from (1, 4, 8) — which is
+                             also the default history of a reset workspace — to (21, 7, 96)
+    hist_XX.zst / .orig      inputs that begin with the dictionary content found 21 / 7 / 96 bytes before its end, compressed with
+                             dict_hist.bin: their first sequences are repeat-offset codes, so they decode to .orig only when the
+                             workspace really starts from the DICTIONARY's history (checked below: with dict.bin they do not)
 """
 import ctypes as C
 import os
@@ -61,6 +66,39 @@ def main():
         open(os.path.join(OUT, f"frame_{k:02d}.orig"), "wb").write(orig)
         print(f"frame_{k:02d}: {len(orig)} -> {len(z)} bytes (level {level})")
     print(f"dict.bin: {len(d)} bytes")
+    # ---- the same dictionary with a repeat-offset history that is not the reset default
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import oracle
+    co = oracle.Dictionary(d).info["content_off"]
+    hist = (21, 7, 96)
+    dh = d[:co - 12] + b"".join(int(h).to_bytes(4, "little") for h in hist) + d[co:]
+    open(os.path.join(OUT, "dict_hist.bin"), "wb").write(dh)
+    content = d[co:]
+    made = 0
+    for k, h in enumerate(hist + (21,)):
+        tail = record(rng, 5000 + k)
+        orig = (content[len(content) - h: len(content) - h + 24] if h >= 24 else (content[len(content) - h:] * 8)[:24]) + tail
+        for level in (3, 19):
+            cap = L.ZSTD_compressBound(C.c_size_t(len(orig)))
+            cbuf = C.create_string_buffer(cap)
+            m = L.ZSTD_compress_usingDict(cctx, cbuf, C.c_size_t(cap), orig, C.c_size_t(len(orig)), dh, C.c_size_t(len(dh)), C.c_int(level))
+            assert not L.ZSTD_isError(C.c_size_t(m))
+            z = cbuf.raw[:m]
+            back = C.create_string_buffer(len(orig))
+            r = L.ZSTD_decompress_usingDict(dctx, back, C.c_size_t(len(orig)), z, C.c_size_t(len(z)), dh, C.c_size_t(len(dh)))
+            assert r == len(orig) and back.raw == orig
+            st_h, out_h = oracle.decode_frame_with_dict(z, oracle.Dictionary(dh), cap=len(orig) + 64)
+            st_d, out_d = oracle.decode_frame_with_dict(z, oracle.Dictionary(d), cap=len(orig) + 64)
+            assert st_h == 0 and out_h == orig
+            if st_d == 0 and out_d == orig:
+                continue                                          # this frame does not depend on the history: not a fixture
+            open(os.path.join(OUT, f"hist_{made:02d}.zst"), "wb").write(z)
+            open(os.path.join(OUT, f"hist_{made:02d}.orig"), "wb").write(orig)
+            print(f"hist_{made:02d}: offset {h}, level {level}: {len(orig)} -> {len(z)} bytes; with the default history the oracle gives status {st_d}" + ("" if st_d else " and other bytes"))
+            made += 1
+            break
+    assert made >= 2, "no frame depends on the patched history"
 
 
 if __name__ == "__main__":

@@ -143,3 +143,31 @@ def test_emu_dictionary_frames():
         for i, ((r, out), (_, orig)) in enumerate(zip(got, pairs)):
             assert int(r["status"]) == 0, (i, int(r["status"]))
             assert out == orig, i
+
+
+def test_emu_prepass_kernels_and_divergence_vectors():
+    """cz_huf_kernel (workgroups of several waves) and cz_tile_kernel under ASan/UBSan: Raw / RLE frames, literals-only frames
+    (the scan writes their result records), the D1 vector (direct weights, unequal nibbles), the D5 vector (uneven 4-stream
+    split: cz_huf_kernel hands it back), corpus frames, and lists that are too short."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors")
+    man = json.load(open(os.path.join(d, "manifest_r3.json")))
+    frames, caps = [], []
+    for name in ("d1_unequal_direct_weights.zst", "d5_uneven_4stream_split.zst"):
+        frames.append(open(os.path.join(d, name), "rb").read())
+        caps.append(man[name]["orig_len"] + 16)
+    b = synth.generate("raw_rle", 2, first_index=5, nthreads=2)
+    frames += [b.frame(i) for i in range(2)]
+    caps += [int(r) + 8 for r in b.regen]
+    for name, z, orig in corpus_pairs(max_orig=9000)[-8:]:              # multi-block frames with Huffman (also Treeless) literals
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+    err = emu_runner.run.last_stderr
+    assert "frames have their literals done" in err
+    assert int(err.split("EMU_LIT: ")[1].split()[0]) == len(frames) - 1     # all but the D5 frame
+    os.environ["EMU_SEGS"] = "3"                                            # lists far too short: most frames are not pre-passed at all
+    try:
+        _run_and_compare(frames[:6], caps[:6], chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+    finally:
+        del os.environ["EMU_SEGS"]

@@ -688,3 +688,109 @@ def test_batch_decode_with_a_context_dictionary(cz, ctx, prepass):
     for (name, z, orig), (r, out) in zip(pairs, cz.decode_batch_host([z for _, z, _ in pairs], [len(o) + 32 for _, _, o in pairs], ctx)):
         assert int(r["status"]) == 0 and out == orig, name
     gd.close()
+
+
+# ---------------------------------------------------------------- round 3: block-parallel literal / copy pre-pass, new vectors
+def _r3_vectors():
+    import json
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors")
+    man = json.load(open(os.path.join(d, "manifest_r3.json")))
+    return [(n, open(os.path.join(d, n), "rb").read(), man[n]) for n in sorted(man)]
+
+
+@pytest.mark.parametrize("prepass", [False, True])
+def test_r3_vectors_vs_manifest(cz, prepass):
+    """libzstd output at levels 1 / 3 / 19, a frame with OF in Repeat mode, direct Huffman weights with unequal nibbles (D1:
+    the device follows the zstd nibble order, like libzstd) and an uneven 4-stream split (D5: accepted like the reference):
+    sha256 and XXH64 against the manifest written when the vectors were made.  With the pre-pass on, cz_huf_kernel must hand
+    the D5 frame back (its streams do not split ceil(regen / 4)) and cz_decode_frames_kernel redoes them back to back."""
+    vec = _r3_vectors()
+    c = cz.Context(0)
+    try:
+        if prepass:
+            c.set_chain_arena(64 << 20, min_sequences=0)
+            c.set_literal_arena(16 << 20)
+        got = cz.decode_batch_host([z for _, z, _ in vec], [e["orig_len"] + 64 for _, _, e in vec], c)
+        for (name, z, e), (r, out) in zip(vec, got):
+            assert int(r["status"]) == 0, (name, cz.status.name(r["status"]))
+            assert len(out) == e["orig_len"] and int(r["bytes_consumed"]) == len(z), name
+            assert hashlib.sha256(out).hexdigest() == e["orig_sha256"] and f"{oracle.xxh64(out):016x}" == e["xxh64"], name
+        if prepass:
+            with_chain, with_lits = c.last_prepass_counts(len(vec))
+            assert with_lits == len(vec) - 1, (with_chain, with_lits)      # all but the D5 frame kept their pre-decoded literals
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("kind,n", [("raw_rle", 300), ("huf_literals", 40), ("mix", 600)])
+def test_prepass_kernels_finish_frames_without_sequences(cz, kind, n):
+    """cz_tile_kernel (Raw / RLE runs) and cz_huf_kernel (Huffman literals straight into the output) produce whole frames; the
+    scan writes their result records and neither decode kernel walks them: same bytes, sizes and block counts as the oracle,
+    also with the content checksum verified on the device (then cz_execute_frames_kernel walks the frames to hash them)."""
+    from cairo_zstd_amd import synth
+    b = synth.generate(kind, n, first_index=17)
+    frames = [b.frame(i) for i in range(n)]
+    caps = [int(r) + 8 for r in b.regen]
+    refs = [oracle.decode_frame(fr, cap=cap) for fr, cap in zip(frames, caps)]
+    for verify in (False, True):
+        c = cz.Context(0)
+        try:
+            c.set_chain_arena(128 << 20, min_sequences=0)
+            c.set_literal_arena(int(b.regen.sum()) + (8 << 20))
+            c.set_verify_checksum(verify)
+            got = cz.decode_batch_host(frames, caps, c)
+            for i, ((st, ref, info), (r, out)) in enumerate(zip(refs, got)):
+                assert int(r["status"]) == st == 0 and out == ref, (kind, i, cz.status.name(r["status"]))
+                assert int(r["bytes_consumed"]) == info["consumed"] and int(r["blocks_decoded"]) == info["blocks"], (kind, i)
+                assert bool(r["flags"] & cz.RESULT_FINISHED), (kind, i)
+            _, with_lits = c.last_prepass_counts(n)
+            assert with_lits == n
+        finally:
+            c.close()
+
+
+def test_dictionary_history_is_taken_from_the_dictionary(cz, ctx):
+    """dict.bin's repeat offsets equal the reset default (1, 4, 8), so nothing distinguished "history from the
+    dictionary" from "history reset".  dict_hist.bin carries (21, 7, 96) and the hist_* frames start with repeat-offset codes:
+    block level (init_from_dict), batch (cz_context_set_dictionary) without and with the pre-pass."""
+    import glob
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dict")
+    raw = open(os.path.join(d, "dict_hist.bin"), "rb").read()
+    pairs = [(open(z, "rb").read(), open(z[:-4] + ".orig", "rb").read()) for z in sorted(glob.glob(os.path.join(d, "hist_*.zst")))]
+    assert len(pairs) >= 2
+    gd = cz.Dictionary(ctx, raw)
+    assert gd.offset_hist == (21, 7, 96)
+    for z, orig in pairs:
+        assert cz.decode_frame_with_dict(z, gd, ctx) == orig
+    for prepass in (False, True):
+        ctx.set_chain_arena((8 << 20) if prepass else 0)
+        ctx.set_literal_arena((4 << 20) if prepass else 0)
+        ctx.set_dictionary(gd)
+        try:
+            got = cz.decode_batch_host([z for z, _ in pairs] * 3, [len(o) + 32 for _, o in pairs] * 3, ctx)
+            for i, ((r, out), (_, orig)) in enumerate(zip(got, pairs * 3)):
+                assert int(r["status"]) == 0 and out == orig, (prepass, i, cz.status.name(r["status"]))
+        finally:
+            ctx.set_dictionary(None)
+            ctx.set_chain_arena(0)
+            ctx.set_literal_arena(0)
+    gd.close()
+
+
+def test_treeless_literals_and_large_frames_through_huf_kernel(cz):
+    """cz_huf_kernel on real frames: every block of the corpus' large frames is a unit of its own (Treeless sections rebuild the
+    tree of the block that defined it); sha256 against the manifest, content checksum verified on the device."""
+    files = _large_corpus()
+    c = cz.Context(0)
+    try:
+        c.set_chain_arena(512 << 20, min_sequences=0)
+        c.set_literal_arena(128 << 20)
+        c.set_verify_checksum(True)
+        got = cz.decode_batch_host([z for _, z, _ in files], [e["orig_len"] + 64 for _, _, e in files], c)
+        for (name, z, e), (r, out) in zip(files, got):
+            assert int(r["status"]) == 0 and hashlib.sha256(out).hexdigest() == e["orig_sha256"], name
+            assert r["flags"] & cz.RESULT_CHECKSUM_MATCH, name
+        _, with_lits = c.last_prepass_counts(len(files))
+        assert with_lits == len(files)
+    finally:
+        c.close()

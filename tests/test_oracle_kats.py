@@ -285,3 +285,66 @@ def test_oracle_decodes_frames_compressed_with_a_dictionary():
         assert st == 0 and out == orig, name
         st2 = oracle.decode_frame(z, cap=len(orig) + 64)[0]
         assert st2 != 0, f"{name} decodes without its dictionary"
+
+
+# ---------------------------------------------------------------- round-3 vectors (scripts/gen_r3_vectors.py, gen_dict_vectors.py)
+def _r3_vectors():
+    import json
+    d = os.path.join(GOLDEN, "vectors")
+    man = json.load(open(os.path.join(d, "manifest_r3.json")))
+    return [(n, open(os.path.join(d, n), "rb").read(), man[n]) for n in sorted(man)]
+
+
+def test_oracle_r3_vectors_vs_manifest():
+    """Real encoder output (libzstd levels 1 / 3 / 19, a frame with OF in Repeat mode) and the two hand-built divergence vectors:
+    the oracle reproduces what libzstd decoded when the files were made (length, sha256, XXH64 in the manifest)."""
+    import hashlib
+    for name, z, e in _r3_vectors():
+        st, out, info = oracle.decode_frame(z, cap=e["orig_len"] + 64)
+        assert st == 0 and len(out) == e["orig_len"] and info["consumed"] == len(z), name
+        assert hashlib.sha256(out).hexdigest() == e["orig_sha256"] and f"{oracle.xxh64(out):016x}" == e["xxh64"], name
+
+
+def test_d1_direct_weight_nibble_order_is_observable():
+    """with direct weights of unequal nibbles the zstd order (even index = high nibble; what libzstd decoded to
+    .orig) and the reference's literal test at src/huff0/huff0_decoder.cairo:302 (low nibble for indices 0 and 1 only) give
+    different tables — the oracle's switch reproduces the literal behaviour."""
+    d = os.path.join(GOLDEN, "vectors")
+    z = open(os.path.join(d, "d1_unequal_direct_weights.zst"), "rb").read()
+    orig = open(os.path.join(d, "d1_unequal_direct_weights.orig"), "rb").read()
+    st, out, _ = oracle.decode_frame(z, cap=1024)
+    assert st == 0 and out == orig
+    oracle.lib().czo_set_d1_reference_nibbles(1)
+    try:
+        st_ref, out_ref, _ = oracle.decode_frame(z, cap=1024)
+    finally:
+        oracle.lib().czo_set_d1_reference_nibbles(0)
+    assert st_ref != 0 or out_ref != orig
+    st2, out2, _ = oracle.decode_frame(z, cap=1024)                      # the switch is off again
+    assert st2 == 0 and out2 == orig
+
+
+def test_d5_uneven_four_stream_split_is_accepted():
+    """four huff0 streams of 144 / 48 / 48 / 48 symbols (not ceil(288 / 4) each): the reference concatenates what
+    every stream yields and checks the total only (src/decoding/literals_section_decoder.cairo:112-115, :172-178)."""
+    d = os.path.join(GOLDEN, "vectors")
+    z = open(os.path.join(d, "d5_uneven_4stream_split.zst"), "rb").read()
+    st, out, _ = oracle.decode_frame(z, cap=1024)
+    assert st == 0 and out == open(os.path.join(d, "d5_uneven_4stream_split.orig"), "rb").read()
+
+
+def test_oracle_dictionary_history_fixtures():
+    """dict_hist.bin = dict.bin with repeat offsets (21, 7, 96): the hist_* frames begin with repeat-offset codes, so they decode
+    to their originals from the dictionary's history (dictionary.cairo:81-85, scratch.cairo:60-65) and NOT from (1, 4, 8)."""
+    import glob
+    d = os.path.join(GOLDEN, "dict")
+    dh, d0 = oracle.Dictionary(open(os.path.join(d, "dict_hist.bin"), "rb").read()), oracle.Dictionary(open(os.path.join(d, "dict.bin"), "rb").read())
+    assert (dh.info["hist0"], dh.info["hist1"], dh.info["hist2"]) == (21, 7, 96)
+    files = sorted(glob.glob(os.path.join(d, "hist_*.zst")))
+    assert len(files) >= 2
+    for zf in files:
+        z, orig = open(zf, "rb").read(), open(zf[:-4] + ".orig", "rb").read()
+        st, out = oracle.decode_frame_with_dict(z, dh, cap=len(orig) + 64)
+        assert st == 0 and out == orig, zf
+        st0, out0 = oracle.decode_frame_with_dict(z, d0, cap=len(orig) + 64)
+        assert st0 != 0 or out0 != orig, zf
