@@ -1035,4 +1035,5 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
 #ifdef CZ_PROFILE
     if (LANE == 0 && a.prof) { for (int i = 0; i < 8; i++) atomicAdd(&a.prof[32 + i], cprof[i]); for (int i = 8; i < 14; i++) atomicAdd(&a.prof[50 + i - 8], cprof[i]); }
 #endif
+    if (LANE == 0) atomicAdd(&a.scan_ctl[205], 1u);                     /* counted out: cz_huf1_kernel leaves the rest of the literals to cz_huf_kernel once all waves have */
 }

@@ -67,7 +67,7 @@ struct cz_context {
     /* optional literals pass next to the pre-pass, on a stream of its own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
     uint64_t* lit_first = nullptr; size_t lit_first_cap = 0; uint32_t* lit_counter = nullptr;
-    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_lit = nullptr; int huf_grid = 0, tile_grid = 0; bool timed_lit = false;
+    hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_lit = nullptr; int huf_grid = 0, huf1_grid = 0, tile_grid = 0; bool timed_lit = false;
     cz_lit_seg* lit_segs = nullptr; cz_copy_seg* copy_segs = nullptr; uint32_t seg_capacity = 0;   /* lists of the literal / copy pre-pass (cz_scan_kernel) */
     uint32_t* frame_pre = nullptr;                                      /* n entries, allocated with lit_first */
     uint32_t verify_checksum = 0;
@@ -248,6 +248,7 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_huf_kernel, CZH_THREADS, 0) != hipSuccess || occ <= 0) occ = 4;
         c->huf_grid = c->num_cu * occ;
         c->tile_grid = c->num_cu * 8;
+        c->huf1_grid = c->num_cu * 4;                                   /* what fits on a CU next to four chain waves */
     }
     CZ_HIP(c, hipMalloc((void**)&c->lit_arena, (bytes + 15) & ~(size_t)15));
     c->lit_capacity = bytes;
@@ -374,22 +375,26 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
            kernel's workgroups need and hold them up) */
         if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
         const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
+        a.chain_grid = (uint32_t)cgrid;
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
         if (lit_pass) {
-            /* cz_huf_kernel and cz_tile_kernel on streams of their own, next to the chain kernel */
+            /* next to the chain kernel, on streams of their own: cz_huf1_kernel (one wave per literals section: what fits beside the
+               chain kernel's LDS) and cz_tile_kernel; behind the chain kernel, with the whole chip: cz_huf_kernel for what is left */
             CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream2, a);
+            hipLaunchKernelGGL(cz_huf1_kernel, dim3(c->huf1_grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
             CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
             hipLaunchKernelGGL(cz_tile_kernel, dim3(c->tile_grid), dim3(256), 0, c->stream3, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join3, c->stream3));
+            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream, a);
+            CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
-            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* all three done */
+            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* all of the pre-pass done */
             c->timed_lit = true;
         } else c->timed_lit = false;
         c->timed_chain = true;

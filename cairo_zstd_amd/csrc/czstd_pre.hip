@@ -344,6 +344,68 @@ extern "C" __global__ void __launch_bounds__(CZH_THREADS, CZH_WAVES == 2 ? 6 : 8
     }
 }
 
+/* cz_huf1_kernel: the same list, ONE wave per section, with the decode kernel's own stream decoder (cz_decode_huf_literals:
+ * sixteen bit ranges per stream, one lane each, bits straight from global memory).  Per symbol it does less work than
+ * cz_huf_kernel and it needs 5.5 KB of LDS, so four of its workgroups fit on a CU next to cz_chain_kernel's 135 KB — it is the
+ * form that runs WHILE the chain kernel runs (cz_huf_kernel's workgroups would get one CU slot in eight there).  It stops taking
+ * sections once the chain kernel's waves have all counted themselves out; cz_huf_kernel, launched behind the chain kernel,
+ * finishes the list with the whole chip.  A batch without chains leaves everything to cz_huf_kernel. */
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_huf1_kernel(cz_batch_args a) {
+    uint32_t nseg = 0, nchain = 0;
+    for (int c = 0; c < 20; c++) { nseg += a.scan_ctl[136 + c]; nchain += a.scan_ctl[c]; }
+    if (nseg > a.lit_seg_capacity) nseg = a.lit_seg_capacity;
+    if (!nchain) return;
+    CzBroadcast& bc = sh.bc;
+    for (;;) {
+        __syncthreads();
+        if (LANE == 0) {
+            const uint32_t out = *(volatile uint32_t*)&a.scan_ctl[205];
+            sh.frame_idx = out >= a.chain_grid ? 0xFFFFFFFFu : atomicAdd(&a.scan_ctl[200], 1u);
+        }
+        __syncthreads();
+        const uint32_t si = cz_uni(sh.frame_idx);
+        if (si >= nseg) break;
+        const cz_lit_seg sg = a.lit_segs[si];
+        if (sg.frame == 0xFFFFFFFFu) continue;
+        const uint32_t f = cz_uni(sg.frame);
+        cz_gcptr frame = (cz_gcptr)(a.in_base + a.in_off[f]);
+        cz_gcptr blk = frame + cz_uni(sg.blk_off); const uint32_t bsize = cz_uni(sg.bsize);
+        int bad = 0;
+        if (LANE == 0) sh.huf_max_bits = 0;
+        cz_wave_sync();
+        if (cz_uni(sg.def) != 0xFFFFFFFFu) {
+            /* Treeless: sizes of this block first, then the tree of the block that defined it (the table shares its LDS with the
+               parser's stage), then the sizes back into the broadcast slots the stream decoder reads */
+            const cz_lit_seg dg = a.lit_segs[cz_uni(sg.def) < nseg ? cz_uni(sg.def) : 0];
+            if (cz_uni(sg.def) >= nseg || cz_uni(dg.frame) != f) bad = 1;
+            else {
+                if (LANE == 0) sh.huf_max_bits = 1;
+                bad = czh_parse_block(blk, bsize) != 0 || cz_uni(bc.lit_type) != 3;
+                const uint32_t regen = cz_uni(bc.regen), ns = cz_uni(bc.nstreams);
+                const uint32_t o0 = cz_uni(bc.stream_off[0]), o1 = cz_uni(bc.stream_off[1]), o2 = cz_uni(bc.stream_off[2]), o3 = cz_uni(bc.stream_off[3]);
+                const uint32_t l0 = cz_uni(bc.stream_len[0]), l1 = cz_uni(bc.stream_len[1]), l2 = cz_uni(bc.stream_len[2]), l3 = cz_uni(bc.stream_len[3]);
+                cz_wave_sync();
+                if (LANE == 0) sh.huf_max_bits = 0;
+                cz_wave_sync();
+                if (!bad) bad = czh_parse_block(frame + cz_uni(dg.blk_off), cz_uni(dg.bsize)) != 0 || cz_uni(bc.lit_type) != 2;
+                cz_wave_sync();
+                if (LANE == 0) { bc.regen = regen; bc.nstreams = ns; bc.stream_off[0] = o0; bc.stream_off[1] = o1; bc.stream_off[2] = o2; bc.stream_off[3] = o3;
+                                 bc.stream_len[0] = l0; bc.stream_len[1] = l1; bc.stream_len[2] = l2; bc.stream_len[3] = l3; }
+                cz_wave_sync();
+            }
+        } else bad = czh_parse_block(blk, bsize) != 0 || cz_uni(bc.lit_type) != 2;
+        if (!bad && (cz_uni(bc.regen) != cz_uni(sg.regen) || cz_uni(sh.huf_max_bits) == 0)) bad = 1;
+        __syncthreads();
+        if (!bad) bad = cz_decode_huf_literals(blk, (cz_gptr)((sg.direct ? a.out_base : a.lit_arena) + sg.dst)) != 0;
+        __syncthreads();
+        if (bad && LANE == 0) {
+            a.lit_first[f] = 0;
+            const uint32_t old = atomicExch(&a.frame_pre[f], 0u);
+            if ((old & CZ_PRE_DONE) && a.fallback_list) { a.frame_pre[f] = CZ_PRE_PUSHED; a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
+        }
+    }
+}
+
 /* Raw / RLE runs.  One workgroup per run; the list is in no particular order (runs are at most 128 KiB). */
 /* written once, read by another kernel later: keep the lines out of the caches' way */
 #ifdef CZ_EMU

@@ -69,7 +69,8 @@ typedef struct cz_blk_desc {
                                   [72..103] frames per size class (bit length of the compressed size), [104..135] fill counters,
                                   [136..167] Huffman literal sections per size class (bit length of the regenerated size), [168..199] fill counters,
                                   [200] work counter of cz_huf_kernel, [201] copy segments counted, [202] placed, [203] work counter of cz_tile_kernel,
-                                  [204] frames that are not CZ_PRE_DONE (cz_execute_frames_kernel has nothing to do when there are none) */
+                                  [204] frames that are not CZ_PRE_DONE (cz_execute_frames_kernel has nothing to do when there are none),
+                                  [205] waves of cz_chain_kernel that have finished (cz_huf1_kernel stops when all have) */
 /* One Huffman-coded literals section, as cz_scan_kernel lists it for cz_huf_kernel. */
 typedef struct cz_lit_seg {
     uint32_t frame;           /* batch entry */
@@ -108,7 +109,7 @@ typedef struct cz_batch_args {
        (bit position | LL,ML,OF codes << 32); frame_first[f] = index of frame f's first header, 0 = the
        frame has no chain info and cz_decode_frames_kernel runs the chains itself */
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
-    uint32_t* chain_counter; uint32_t chain_min_nseq;
+    uint32_t* chain_counter; uint32_t chain_min_nseq; uint32_t chain_grid;   /* chain_grid: workgroups of the cz_chain_kernel launch */
     cz_blk_desc* blk_desc; uint32_t blk_capacity; uint32_t* scan_ctl; uint32_t scan_pass;   /* block list of the pre-pass (cz_scan_kernel) */
     uint32_t* frame_order;                    /* NULL, or the order in which the decode kernels take the frames: largest compressed size first (cz_scan_kernel) */
     uint32_t* exec_counter;                   /* work counter of cz_execute_frames_kernel */

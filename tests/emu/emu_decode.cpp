@@ -56,6 +56,7 @@ static void* lane_main(void* p) {
     if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) czx::cz_execute_frames_kernel(la->a);
     else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
     else if (la->which == 7) cz_huf_kernel(la->a);
+    else if (la->which == 9) cz_huf1_kernel(la->a);
     else if (la->which == 8) cz_tile_kernel(la->a);
     else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
     else cz_decode_frames_kernel(la->a);
@@ -146,14 +147,18 @@ int main(int argc, char** argv) {
     }
     /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel */
     if (with_exec) { a.fallback_list = fallback_list.data(); a.fallback_count = &fallback_count; }   /* as the host library: set before cz_huf_kernel, which may list frames too */
-    const int order[7] = {4, 5, 0, 7, 8, 2, 1};
-    for (int pi = arena ? 0 : 6; pi < 7; pi++) {
+    /* EMU_HUF1=1: cz_huf1_kernel (the one-wave form that runs beside the chain kernel on the device) never sees the chain kernel
+       "done" and takes every literals section; default: it sees it done at once and cz_huf_kernel takes them all */
+    const int huf1_all = getenv("EMU_HUF1") && atoi(getenv("EMU_HUF1")) > 0;
+    a.chain_grid = (uint32_t)grid;
+    const int order[8] = {4, 5, 0, 9, 7, 8, 2, 1};
+    for (int pi = arena ? 0 : 7; pi < 8; pi++) {
         const int which = order[pi];
         if (which == 2 && !with_exec) continue;
-        if ((which == 7 || which == 8) && !lit_bytes) continue;
+        if ((which == 7 || which == 8 || which == 9) && !lit_bytes) continue;
         const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : 64);
 
-        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 ? 1 : grid);
+        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 || which == 9 ? 1 : grid);
         emu_nthreads = nthreads; gridDim.x = (unsigned)nblocks;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
         for (int b = 0; b < nblocks; b++) {
@@ -161,6 +166,7 @@ int main(int argc, char** argv) {
             for (int l = 0; l < nthreads; l++) {
                 la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which;
                 if (which == 4 || which == 5) la[l].a.scan_pass = (uint32_t)(which - 4);
+                if (which == 9 && huf1_all) la[l].a.chain_grid = 0x7FFFFFFFu;
                 pthread_create(&th[l], nullptr, lane_main, &la[l]);
             }
             for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);

@@ -165,6 +165,12 @@ def test_emu_prepass_kernels_and_divergence_vectors():
     err = emu_runner.run.last_stderr
     assert "frames have their literals done" in err
     assert int(err.split("EMU_LIT: ")[1].split()[0]) == len(frames) - 1     # all but the D5 frame
+    os.environ["EMU_HUF1"] = "1"                                            # the same batch with every literals section on cz_huf1_kernel
+    try:
+        _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+        assert int(emu_runner.run.last_stderr.split("EMU_LIT: ")[1].split()[0]) == len(frames)   # its stream decoder redoes an uneven split itself: D5 stays
+    finally:
+        del os.environ["EMU_HUF1"]
     os.environ["EMU_SEGS"] = "3"                                            # lists far too short: most frames are not pre-passed at all
     try:
         _run_and_compare(frames[:6], caps[:6], chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
