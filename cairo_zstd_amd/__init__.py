@@ -176,6 +176,40 @@ def decode_batch_host(frames, caps, ctx: Context | None = None):
             ctx.close()
 
 
+def partition_balanced(weights, parts: int) -> np.ndarray:
+    """cz_partition_balanced: deals items to `parts` parts by weight (heaviest first, to the lightest part).  No device needed."""
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    out = np.zeros(w.size, dtype=np.uint32)
+    st = lib().cz_partition_balanced(w.ctypes.data if w.size else None, w.size, parts, out.ctypes.data if w.size else None)
+    if st:
+        raise CzError(st, "cz_partition_balanced")
+    return out
+
+
+def decode_batch_multi(frames, caps, ctxs):
+    """cz_decode_batch_multi: one batch over several contexts (one per GPU).  Returns ([(result, bytes)], device_of)."""
+    lens = np.array([len(f) for f in frames], dtype=np.uint64)
+    in_off = np.zeros(len(frames), dtype=np.uint64)
+    if len(frames) > 1:
+        in_off[1:] = np.cumsum(lens[:-1])
+    in_base = np.frombuffer(b"".join(frames) + b"\0" * 16, dtype=np.uint8)
+    caps = np.array(caps, dtype=np.uint64)
+    pad = (caps + np.uint64(255)) // np.uint64(256) * np.uint64(256)
+    out_off = np.zeros(len(frames), dtype=np.uint64)
+    if len(frames) > 1:
+        out_off[1:] = np.cumsum(pad[:-1])
+    total = int(pad.sum())
+    out = np.zeros(total + 16, dtype=np.uint8)
+    res = np.zeros(len(frames), dtype=RESULT_DTYPE)
+    dev = np.zeros(len(frames), dtype=np.uint32)
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = lib().cz_decode_batch_multi(handles, len(ctxs), in_base.ctypes.data, in_base.size, in_off.ctypes.data, lens.ctypes.data, len(frames),
+                                     out.ctypes.data, total, out_off.ctypes.data, caps.ctypes.data, res.ctypes.data, dev.ctypes.data)
+    if st:
+        raise CzError(st, "cz_decode_batch_multi")
+    return [(res[i], out[int(out_off[i]): int(out_off[i]) + min(int(res[i]["bytes_produced"]), int(caps[i]))].tobytes()) for i in range(len(frames))], dev
+
+
 def read_frame_header(src):
     """read_frame_header (src/frame.cairo:152-284).  Returns (status, FrameHeader, detail)."""
     a = _as_u8(src)

@@ -97,6 +97,10 @@ def lib() -> C.CDLL:
     L.cz_decode_batch_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp]
     L.cz_decode_batch_host.restype = C.c_int
     L.cz_decode_batch_host.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.cz_partition_balanced.restype = C.c_int
+    L.cz_partition_balanced.argtypes = [vp, sz, sz, vp]
+    L.cz_decode_batch_multi.restype = C.c_int
+    L.cz_decode_batch_multi.argtypes = [vp, sz, vp, sz, vp, vp, sz, vp, sz, vp, vp, vp, vp]
     L.cz_read_frame_header.restype = C.c_int
     L.cz_read_frame_header.argtypes = [vp, sz, C.POINTER(FrameHeader), u64p]
     L.cz_read_block_header.restype = C.c_int

@@ -16,7 +16,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <functional>
 #include <new>
+#include <queue>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "czstd_types.h"
@@ -463,6 +468,71 @@ CZ_EXPORT int cz_decode_batch_host(cz_context* c, const void* in_base, size_t in
     CZ_HIP(c, hipMemcpyAsync(out_base, d + o_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     CZ_HIP(c, hipMemcpyAsync(results, d + o_res, n * sizeof(cz_frame_result), hipMemcpyDeviceToHost, c->stream));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
+    return CZ_OK;
+}
+
+/* ------------------------------------------------------------------ several devices */
+CZ_EXPORT int cz_partition_balanced(const uint64_t* weights, size_t n, size_t parts, uint32_t* part_of) {
+    if (!parts || (n && (!weights || !part_of))) return CZ_E_INVALID_ARG;
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weights[a] > weights[b]; });   /* heaviest first, index breaks ties */
+    typedef std::pair<unsigned long long, size_t> load_t;                /* (load, part): the lightest part first, ties to the lower index */
+    std::priority_queue<load_t, std::vector<load_t>, std::greater<load_t>> heap;
+    for (size_t r = 0; r < parts; r++) heap.push(load_t(0ull, r));
+    for (size_t k = 0; k < n; k++) {
+        load_t t = heap.top(); heap.pop();
+        part_of[order[k]] = (uint32_t)t.second;
+        t.first += weights[order[k]];
+        heap.push(t);
+    }
+    return CZ_OK;
+}
+
+CZ_EXPORT int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx, const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
+                                    void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap, cz_frame_result* results, uint32_t* device_of) {
+    if (!ctxs || !n_ctx) return CZ_E_INVALID_ARG;
+    for (size_t d = 0; d < n_ctx; d++) if (!ctxs[d]) return CZ_E_INVALID_ARG;
+    if (n == 0) return CZ_OK;
+    if (!in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !results) return CZ_E_INVALID_ARG;
+    for (size_t i = 0; i < n; i++) {
+        if (in_off[i] > in_bytes || in_len[i] > in_bytes - in_off[i]) return CZ_E_INVALID_ARG;
+        if (out_off[i] > out_bytes || out_cap[i] > out_bytes - out_off[i]) return CZ_E_INVALID_ARG;
+    }
+    std::vector<uint64_t> weight(n);
+    for (size_t i = 0; i < n; i++) weight[i] = in_len[i] + out_cap[i];
+    std::vector<uint32_t> part(n);
+    int st = cz_partition_balanced(weight.data(), n, n_ctx, part.data());
+    if (st) return st;
+    if (device_of) memcpy(device_of, part.data(), n * sizeof(uint32_t));
+    std::vector<int> status(n_ctx, CZ_OK);
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < n_ctx; d++) {
+        workers.emplace_back([&, d]() {
+            /* this device's share, packed: compressed frames back to back (16-byte aligned), outputs in a layout of its own */
+            std::vector<size_t> mine;
+            for (size_t i = 0; i < n; i++) if (part[i] == d) mine.push_back(i);
+            if (mine.empty()) return;
+            std::vector<uint64_t> ioff(mine.size()), ilen(mine.size()), ooff(mine.size()), ocap(mine.size());
+            size_t ib = 0, ob = 0;
+            for (size_t k = 0; k < mine.size(); k++) {
+                ioff[k] = ib; ilen[k] = in_len[mine[k]]; ib += (size_t)((in_len[mine[k]] + 15) & ~15ull);
+                ooff[k] = ob; ocap[k] = out_cap[mine[k]]; ob += (size_t)((out_cap[mine[k]] + 255) & ~255ull);
+            }
+            std::vector<uint8_t> ibuf(ib + 16), obuf(ob + 16);
+            for (size_t k = 0; k < mine.size(); k++) memcpy(ibuf.data() + ioff[k], (const uint8_t*)in_base + in_off[mine[k]], (size_t)ilen[k]);
+            std::vector<cz_frame_result> res(mine.size());
+            status[d] = cz_decode_batch_host(ctxs[d], ibuf.data(), ib, ioff.data(), ilen.data(), mine.size(), obuf.data(), ob, ooff.data(), ocap.data(), res.data());
+            if (status[d]) return;
+            for (size_t k = 0; k < mine.size(); k++) {
+                results[mine[k]] = res[k];
+                const uint64_t w = res[k].bytes_produced < ocap[k] ? res[k].bytes_produced : ocap[k];
+                memcpy((uint8_t*)out_base + out_off[mine[k]], obuf.data() + ooff[k], (size_t)w);
+            }
+        });
+    }
+    for (auto& t : workers) t.join();
+    for (size_t d = 0; d < n_ctx; d++) if (status[d]) return status[d];
     return CZ_OK;
 }
 

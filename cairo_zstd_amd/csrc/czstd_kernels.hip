@@ -2349,6 +2349,11 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
         const uint32_t fi = cz_uni(sh.frame_idx);
         if (fi >= a.n) break;
         const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
+#ifdef CZ_EXEC_PRIO_FRAC
+        /* the launch ends with its longest frames, each on one wave: the first frames of the (largest first) order get the
+           issue slots before the others */
+        if (fi < a.n / CZ_EXEC_PRIO_FRAC) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
         int err = CZX_FALLBACK;
         /* regular to its last block, everything listed, and cz_huf_kernel met nothing irregular; a frame whose chains
            cz_chain_kernel gave up on (first == 0 with sequences in it) comes back from cz_run_frame */

@@ -93,6 +93,24 @@ int cz_decode_batch_host(cz_context* ctx,
                          void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,
                          cz_frame_result* results);
 
+/* Several devices: frames share nothing (FrameDecoderStateTrait::reset, src/frame_decoder.cairo:78-104),
+ * so a batch shards by frame with no exchange between the devices.
+ *
+ * cz_partition_balanced deals n items of the given weights (a frame's algorithmic bytes: compressed + decoded) to `parts`
+ * parts so that the sums are balanced — heaviest first, each to the part that is lightest so far, ties to the lower index:
+ * deterministic, every caller computes the same dealing.  part_of[i] = part of item i.  No device needed.
+ *
+ * cz_decode_batch_multi decodes ONE batch of host buffers on n_ctx contexts (normally one per GPU of the node): it deals the
+ * frames with cz_partition_balanced (weight = in_len + out_cap), runs every share through cz_decode_batch_host on a thread
+ * of its own — stage, launch, copy back, all concurrently across the devices — and leaves outputs and results in the
+ * caller's layout, exactly as one cz_decode_batch_host call would.  device_of (optional, n entries): the context index every
+ * frame went to.  Every context keeps its own arenas and options (cz_context_set_chain_arena ... per context). */
+int cz_partition_balanced(const uint64_t* weights, size_t n, size_t parts, uint32_t* part_of);
+int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx,
+                          const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
+                          void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,
+                          cz_frame_result* results, uint32_t* device_of);
+
 /* Enables (bytes > 0) or disables (0) the FSE-chain pre-pass for batch decodes on this context and sizes its record
  * arena (8 bytes per sequence + 1312 per block with sequences; 8x the compressed bytes + 64 MiB covers every BASELINE
  * config).  With the pre-pass a batch decode is: cz_scan_kernel twice (lists the blocks of all frames, sorted by

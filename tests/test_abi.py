@@ -108,3 +108,20 @@ def test_block_decoder_state_machine_without_a_device():
     st, bh, used = bd.read_block_header(bytes([0b010 | (5 << 3), 0, 0]))  # RLE, size 5
     assert st == 0 and used == 3 and bd.internal_state == cz.BlockDecoder.READY_FOR_BODY
     assert (bh.block_type, bh.content_size, bh.decompressed_size) == (1, 1, 5)
+
+
+def test_partition_balanced_matches_the_python_dealing():
+    """cz_partition_balanced (the dealing cz_decode_batch_multi uses; no device needed) == cairo_zstd_amd.dist.partition_balanced,
+    which bench.py uses across ranks: heaviest first, to the lightest part, ties to the lower index."""
+    import numpy as np
+    import cairo_zstd_amd as cz
+    from cairo_zstd_amd import dist as czdist
+    rng = np.random.default_rng(3)
+    for n, parts in ((0, 3), (1, 8), (7, 8), (1000, 8), (257, 2), (64, 1)):
+        w = np.concatenate([rng.integers(1, 300, n - n // 10), rng.integers(50_000, 900_000, n // 10)]).astype(np.uint64) if n else np.zeros(0, np.uint64)
+        got = cz.partition_balanced(w, parts)
+        want = czdist.partition_balanced(w, parts)
+        assert (got == want).all(), (n, parts)
+        if n >= 100:
+            loads = np.array([w[got == r].sum() for r in range(parts)], dtype=np.float64)
+            assert loads.max() / loads.mean() < 1.05

@@ -138,3 +138,58 @@ def test_bench_gpus_flag_fails_loudly_without_the_gpus():
         pytest.skip("needs a box with fewer than 2 GPUs")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "needs 2 GPUs" in p.stderr and "n_gpus" not in p.stdout
+
+
+def _world8_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    f8 = 6
+    batch = synth.generate("mix", f8, first_index=czdist.shard_first_index(f8, rank), nthreads=1)
+    nb, noff, nlen, nregen, idx = czdist.rebalance_frames(batch.base, batch.off, batch.length, batch.regen, dev)
+    nbatch = synth.Batch(nb, noff, nlen, nregen)
+    arena = torch.from_numpy(_decode_shard(nbatch)) if nbatch.n else torch.zeros(0, dtype=torch.uint8)
+    sizes = czdist.all_sizes(arena.numel(), dev)
+    bufs = [torch.empty(s, dtype=torch.uint8) for s in sizes] if rank == 0 else None
+    czdist.gather_to_root(arena, bufs, 0)
+    out_off, _, _ = nbatch.out_layout(64) if nbatch.n else (np.zeros(0, np.uint64), None, 0)
+    mine = {int(i): hashlib.sha256(arena.numpy()[int(o): int(o + r)].tobytes()).hexdigest() for i, o, r in zip(idx, out_off, nregen)}
+    if rank == 0:
+        gathered = [hashlib.sha256(arena.numpy().tobytes()).hexdigest()] + [hashlib.sha256(bufs[r].numpy().tobytes()).hexdigest() for r in range(1, world)]
+        q.put((rank, mine, hashlib.sha256(arena.numpy().tobytes()).hexdigest(), float((nlen + nregen).sum()), gathered))
+    else:
+        q.put((rank, mine, hashlib.sha256(arena.numpy().tobytes()).hexdigest(), float((nlen + nregen).sum()), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_8_deal_decode_and_gather():
+    """BASELINE config 5 rehearsed at its real world size on the CPU (gloo): 8 ranks x 6 corpus-like frames — deal by algorithmic
+    bytes (partition_balanced + one all_to_all), decode every share (the oracle stands in for the GPU here), gather the eight
+    decoded arenas to rank 0 by direct peer sends.  Every frame of the global batch is decoded exactly once and correctly, the
+    loads are balanced, and rank 0 ends up with every rank's arena bit for bit."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = sorted([q.get(timeout=300) for _ in range(world)], key=lambda m: m[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    whole = synth.generate("mix", 8 * 6, nthreads=1)
+    seen = {}
+    for rank, mine, arena_hash, load, gathered in msgs:
+        for i, h in mine.items():
+            assert i not in seen
+            seen[i] = h
+    assert sorted(seen) == list(range(48))
+    for i, h in seen.items():
+        st, ref, _ = oracle.decode_frame(whole.frame(i), cap=int(whole.regen[i]) + 64)
+        assert st == 0 and hashlib.sha256(ref).hexdigest() == h, i
+    root = msgs[0]
+    assert root[4] == [m[2] for m in msgs]                               # rank 0 holds every rank's decoded arena
+    loads = np.array([m[3] for m in msgs])
+    assert loads.max() - loads.min() <= float((whole.length + whole.regen).max())

@@ -796,3 +796,32 @@ def test_treeless_literals_and_large_frames_through_huf_kernel(cz):
         assert with_lits == len(files)
     finally:
         c.close()
+
+
+def test_decode_batch_multi_deals_frames_over_contexts(cz):
+    """cz_decode_batch_multi: one host batch dealt by algorithmic bytes over several contexts — here two
+    contexts on the one GPU of the box, with different options — decoded concurrently, outputs and results back in the
+    caller's layout: same as the oracle, and the dealing is cz_partition_balanced's."""
+    from cairo_zstd_amd import synth
+    frames, caps = [], []
+    for kind, n in (("mix", 300), ("full_4a", 6), ("raw_rle", 10), ("huf_literals", 4)):
+        b = synth.generate(kind, n, first_index=23)
+        frames += [b.frame(i) for i in range(n)]
+        caps += [int(r) + 16 for r in b.regen]
+    for name, z, orig in corpus_pairs(max_orig=8000):
+        frames.append(z[: len(z) // 2] if name.endswith("7") else z)       # a few malformed ones among them
+        caps.append(len(orig) + 32)
+    c0, c1 = cz.Context(0), cz.Context(0)
+    try:
+        c0.set_chain_arena(128 << 20, min_sequences=0)
+        c0.set_literal_arena(64 << 20)
+        got, dev = cz.decode_batch_multi(frames, caps, [c0, c1])
+        w = np.array([len(f) + c for f, c in zip(frames, caps)], dtype=np.uint64)
+        assert (dev == cz.partition_balanced(w, 2)).all() and 0 < int(dev.sum()) < len(frames)
+        for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+            st, ref, info = oracle.decode_frame(fr, cap=cap)
+            assert int(r["status"]) == st, (i, cz.status.name(r["status"]), cz.status.name(st))
+            assert st != 0 or out == ref, i
+    finally:
+        c0.close()
+        c1.close()
