@@ -725,7 +725,7 @@ CZ_EXPORT void cz_decoder_scratch_destroy(cz_decoder_scratch* s) {
     delete s;
 }
 CZ_EXPORT size_t cz_decoder_scratch_buffer_len(const cz_decoder_scratch* s) { return s ? (size_t)(s->produced - s->drained) : 0; }   /* buffer.len() */
-CZ_EXPORT uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s) { return s ? s->produced : 0; }              /* total_output_counter */
+CZ_EXPORT uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s) { return s ? s->produced : 0; }              /* bytes decoded so far (the reference's total_output_counter lags behind it after whole-dictionary matches: see the header) */
 
 /* DictionaryTrait::decode_dict (dictionary.cairo:35-91) */
 CZ_EXPORT int cz_dictionary_decode(cz_context* c, const uint8_t* raw, size_t len, cz_dictionary** out, uint64_t* detail) {

@@ -213,7 +213,10 @@ int  cz_decoder_scratch_create(cz_context* ctx, uint64_t window_size, cz_decoder
 int  cz_decoder_scratch_reset(cz_decoder_scratch* s, uint64_t window_size);                        /* reset, scratch.cairo:42-58 */
 void cz_decoder_scratch_destroy(cz_decoder_scratch* s);
 size_t cz_decoder_scratch_buffer_len(const cz_decoder_scratch* s);                                 /* buffer.len() */
-uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s);                             /* buffer.total_output_counter */
+uint64_t cz_decoder_scratch_total_output(const cz_decoder_scratch* s);                             /* bytes decoded into the buffer so far.  Equals buffer.total_output_counter except
+                                                                                                      after matches copied WHOLLY from a dictionary: the reference's counter skips
+                                                                                                      those (decode_buffer.cairo:85-90); the device keeps that lag for its window
+                                                                                                      test but this getter does not subtract it */
 /* DecodeBuffer::drain (decode_buffer.cairo:157-166): moves the whole buffer to dst and feeds the XXH64 state. */
 int  cz_decoder_scratch_drain(cz_decoder_scratch* s, uint8_t* dst, size_t cap, size_t* written);
 /* DecodeBuffer::drain_to_window_size (:145-155): 1 = Some (bytes beyond window_size moved), 0 = None, < 0 = -cz_status. */
