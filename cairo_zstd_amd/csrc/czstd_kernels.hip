@@ -2340,6 +2340,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
  * wave instead of 10.5 KB, and a register budget of its own).  Any other frame — and any frame that turns out to need a
  * decoder after all — is appended to args.fallback_list for cz_decode_frames_kernel. */
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_execute_frames_kernel(cz_batch_args a) {
+#ifdef CZ_PROFILE
+    if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
+#endif
     if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
     cz_init_llml();
     for (;;) {
@@ -2349,11 +2352,6 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
         const uint32_t fi = cz_uni(sh.frame_idx);
         if (fi >= a.n) break;
         const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
-#ifdef CZ_EXEC_PRIO_FRAC
-        /* the launch ends with its longest frames, each on one wave: the first frames of the (largest first) order get the
-           issue slots before the others */
-        if (fi < a.n / CZ_EXEC_PRIO_FRAC) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
         int err = CZX_FALLBACK;
         /* regular to its last block, everything listed, and cz_huf_kernel met nothing irregular; a frame whose chains
            cz_chain_kernel gave up on (first == 0 with sequences in it) comes back from cz_run_frame */
@@ -2373,6 +2371,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
             if (err != CZX_FALLBACK && LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
         }
         if (err == CZX_FALLBACK && LANE == 0) a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f;
+#ifdef CZ_PROFILE
+        if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
+#endif
     }
 }
 #else

@@ -274,9 +274,6 @@ __device__ static int czh_parse_block(cz_gcptr blk, uint32_t bsize) {
 
 extern "C" __global__ void __launch_bounds__(CZH_THREADS, CZH_WAVES == 2 ? 6 : 8) cz_huf_kernel(cz_batch_args a) {
     const uint32_t wave = threadIdx.x >> 6;
-#ifdef CZH_PRIO
-    __builtin_amdgcn_s_setprio(CZH_PRIO);                               /* (experiment) next to cz_chain_kernel: short work, let it through */
-#endif
     uint32_t nseg = 0; for (int c = 0; c < 20; c++) nseg += a.scan_ctl[136 + c];
     if (nseg > a.lit_seg_capacity) nseg = a.lit_seg_capacity;
     CzBroadcast& bc = sh.bc;

@@ -15,7 +15,7 @@ import cairo_zstd_amd as cz
 from cairo_zstd_amd import synth
 
 PHASES = ["hdr", "huf_build", "huf_decode", "seq_tables", "ring", "chain", "extract", "lit_copy", "match", "raw_rle", "other",
-          "(huf_spec)", "(huf_sync)", "(huf_write)"]
+          "(huf_spec)", "(huf_sync)", "(huf_write)", "#chunks_lds", "#chunks_general", "#rounds_general", "#wave_copies"]
 
 
 def main():
@@ -30,6 +30,7 @@ def main():
     ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
     if len(sys.argv) > 3 and sys.argv[3] == "prepass":
         ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
+        ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
     buf = (C.c_uint64 * 64)()
     for it in range(2):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())

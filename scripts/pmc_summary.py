@@ -52,8 +52,7 @@ def main():
     line = json.load(open(bj))
     cfg = line["config"]
     res = {"workload": cfg["workload"], "frames": cfg["frames_per_gpu"], "steps_averaged": [nf, nw],
-           "launch_naming": "a kernel launched more than once per step is numbered in launch order: with the pre-pass and the "
-                            "literals pass, cz_decode_frames_kernel#1 is the literals pass (second stream) and #2 the main pass",
+           "launch_naming": "a kernel launched more than once per step is numbered in launch order (cz_scan_kernel#1 counts, #2 places)",
            "per_kernel": {},
            "algorithmic_read_bytes": cfg.get("compressed_bytes_rank0", cfg.get("compressed_bytes_per_gpu")),
            "algorithmic_write_bytes": cfg.get("decoded_bytes_rank0", cfg.get("decoded_bytes_per_gpu")),
