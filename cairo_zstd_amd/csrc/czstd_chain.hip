@@ -795,6 +795,7 @@ __device__ static inline __attribute__((always_inline)) int czc_parse_tables(cz_
 
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
     __shared__ CzChainShared cs;
+    __builtin_amdgcn_s_setprio(3);                                      /* the launch lasts as long as its longest chain: its waves issue ahead of cz_huf1_kernel's beside them */
     for (uint32_t i = (uint32_t)LANE; i < 36; i += 64) cs.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
     for (uint32_t i = (uint32_t)LANE; i < 53; i += 64) cs.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
     if (LANE < 2) cs.idle[LANE] = (uint16_t)CZC_E16_IDLE;
