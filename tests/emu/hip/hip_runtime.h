@@ -83,6 +83,7 @@ __attribute__((noinline)) static unsigned long long __ballot(int pred) {
     emu_sync(); return m;
 }
 #define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() do { __label__ emu_wb; emu_wb: emu_site[threadIdx.x] = &&emu_wb; emu_note(&&emu_wb); emu_sync(); } while (0)
 static inline uint32_t __builtin_amdgcn_ubfe(uint32_t x, uint32_t off, uint32_t width) { off &= 31; width &= 31; return width ? (x >> off) & ((1u << width) - 1u) : 0u; }
 /* v_perm_b32: result byte i = byte (selector byte i) of the 8 bytes {S0 (4..7), S1 (0..3)}; 0x0C -> 0x00 */
