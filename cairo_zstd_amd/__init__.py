@@ -90,7 +90,7 @@ class Context:
         return float(ms.value)
 
     def set_literal_arena(self, nbytes: int):
-        """Enable (nbytes > 0) / disable (0) the literals pass that runs next to the pre-pass (cz_context_set_literal_arena)."""
+        """Enable (nbytes > 0) / disable (0) the block-parallel huff0 / tile kernels and the execute-only frame kernel (cz_context_set_literal_arena)."""
         st = lib().cz_context_set_literal_arena(self._h, nbytes)
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")
@@ -102,7 +102,7 @@ class Context:
         return int(a.value), int(b.value)
 
     def last_literals_tail_ms(self) -> float:
-        """Milliseconds the last launch waited for the literals pass after the chain kernel was done."""
+        """Milliseconds the last launch went on with the huff0 / tile kernels after the chain kernel was done."""
         ms = C.c_float(0)
         lib().cz_context_last_literals_tail_ms(self._h, C.byref(ms))
         return float(ms.value)

@@ -69,7 +69,7 @@ struct cz_context {
     cz_blk_desc* blk_desc = nullptr; uint32_t blk_capacity = 0; uint32_t* scan_ctl = nullptr;   /* block list of the pre-pass */
     uint32_t* frame_order = nullptr;                                    /* n entries, allocated with frame_first */
     int chain_grid = 0; uint32_t chain_min_nseq = 0;
-    /* optional literals pass next to the pre-pass, on a stream of its own */
+    /* optional: block-parallel huff0 and tile kernels next to / behind the chain kernel, on streams of their own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
     uint64_t* lit_first = nullptr; size_t lit_first_cap = 0; uint32_t* lit_counter = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr, ev_lit = nullptr; int huf_grid = 0, huf1_grid = 0, tile_grid = 0; bool timed_lit = false;
@@ -124,7 +124,7 @@ CZ_EXPORT int cz_context_read_profile(cz_context* c, unsigned long long* out, in
     (void)hipMemset(c->d_prof, 0, sizeof tmp);
     int n = CZ_P_COUNT < cap ? CZ_P_COUNT : cap;
     for (int i = 0; i < n; i++) out[i] = tmp[i];
-    for (int i = 20; i < 58 && i < cap; i++) out[i] = tmp[i];        /* literals pass: 20..30; cz_chain_kernel: see CZC_PROF_*; cz_exec_frames_kernel: CZX_PROF */
+    for (int i = 20; i < 58 && i < cap; i++) out[i] = tmp[i];        /* (20..30: unused since the literals pass went); cz_chain_kernel: see CZC_PROF_* */
     return n;
 }
 
@@ -276,7 +276,7 @@ CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) re
 CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
 
 /* Diagnostics of the last batch launch (synchronises): how many of its n frames got chain records from the pre-pass,
- * and how many got literal nodes from the literals pass. */
+ * and how many had their literals decoded by the huff0 kernels. */
 CZ_EXPORT int cz_context_last_prepass_counts(cz_context* c, size_t n, size_t* with_chain, size_t* with_literals) {
     if (!c) return CZ_E_INVALID_ARG;
     if (with_chain) *with_chain = 0;
@@ -295,7 +295,7 @@ CZ_EXPORT int cz_context_last_prepass_counts(cz_context* c, size_t n, size_t* wi
     return CZ_OK;
 }
 
-/* How long the last launch went on waiting for the literals pass after cz_chain_kernel was done (0: no literals pass). */
+/* How long the last launch went on with cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel after cz_chain_kernel was done (0: no literal arena). */
 CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
     *ms = 0.0f;
@@ -378,6 +378,25 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         /* the literal and copy kernels may start when the chain kernel does (not before: they would take the LDS the chain
            kernel's workgroups need and hold them up) */
+#ifdef CZ_EXPERIMENT
+        /* diagnostic (CZ_EXP_OVERLAP = workgroups per CU): what cz_execute_frames_kernel and cz_chain_kernel cost each other when they
+           run side by side.  The execute kernel works on the records the PREVIOUS launch left in the arena (same batch, same
+           bytes), after all literals; its output is the same bytes again.  Read the kernel trace, not the event times. */
+        const char* ovl = use_exec ? getenv("CZ_EXP_OVERLAP") : nullptr;
+        if (ovl) {
+            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream, a);
+            CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            cz_batch_args a2 = a; a2.exec_counter = c->work_counter;
+            hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(atoi(ovl) * c->num_cu), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a2);
+            CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+            a.chain_grid = (uint32_t)c->chain_grid;
+            hipLaunchKernelGGL(cz_chain_kernel, dim3(c->chain_grid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
+            CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        }
+#endif
         if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
         const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
         a.chain_grid = (uint32_t)cgrid;
@@ -407,7 +426,10 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         if (use_exec) {
             /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of
                its own); it lists every other frame for the launch below */
-            const int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
+            int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
+#ifdef CZ_EXPERIMENT
+            if (const char* e = getenv("CZ_EXEC_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < egrid) egrid = g; }
+#endif
             hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));

@@ -122,8 +122,7 @@ struct CzShared {
     struct { struct { uint32_t llml[96]; } c; } b;
     CzBroadcast bc;
     uint32_t frame_idx;
-    uint32_t rec_general, rec_misses, rec_next;   /* the frame in flight has left cz_sequences_rec_fast for the general loop; chunks of the block in hand
-                                                     that loop left to the general form; where it stopped */
+    uint32_t rec_next, rec_misses;      /* the chunk cz_sequences_rec_fast stopped at; chunks of the frame in flight it has left to the general form */
     uint32_t dict_lag[2];
     uint32_t dict_ptr[2], dict_len[2];
 #ifdef CZ_PROFILE
@@ -145,8 +144,7 @@ struct CzShared {
     } b;
     CzBroadcast bc;
     uint32_t frame_idx;
-    uint32_t rec_general, rec_misses, rec_next;   /* the frame in flight has left cz_sequences_rec_fast for the general loop; chunks of the block in hand
-                                                     that loop left to the general form; where it stopped */
+    uint32_t rec_next, rec_misses;      /* the chunk cz_sequences_rec_fast stopped at; chunks of the frame in flight it has left to the general form */
     uint32_t dict_lag[2];               /* cz_device_frame_state.dict_lag of the frame in flight (lo, hi) */
     uint32_t dict_ptr[2], dict_len[2];  /* DecodeBuffer.dict_content of the frame in flight: kept here, not in registers — only the rare
                                            dictionary arm of the match copy reads them */
@@ -1697,9 +1695,10 @@ __device__ static inline uint64_t cz_stream_window64(cz_gcptr S, uint32_t p) {
  * cz_sequences_rec_fast     the same loop for frames whose positions fit 32 bits, as long as the chunks are full chunks of short
  *                           sequences: everything uniform lives in scalar registers, positions are 32-bit offsets from two scalar
  *                           bases, the two prefix sums are one packed scan, and the chunk is assembled in LDS without a predicate
- *                           per match byte (cz_fast_group).  A chunk it cannot take goes, untouched, through the general form
- *                           (one call); after a few of those it hands the rest of the block — and of the frame — to the general loop.
- * Each is a function of its own (not inlined): the register allocation of one does not pay for the other's live values. */
+ *                           per match byte (cz_fast_group).  It stops at a chunk it cannot take: that chunk and the next few go
+ *                           through the general loop (cz_sequences_rec), then it is entered again.
+ * Each is a function of its own (not inlined), and neither calls the other: the register allocation of one does not pay for the
+ * other's live values. */
 /* the state -> code maps of the tables the block defined, from its arena header into the LDS that holds FSE tables otherwise */
 __device__ static inline void cz_rec_load_maps(cz_gcptr64 maps, uint32_t mapflags) {
     uint8_t* mapll = (uint8_t*)CZ_FSE_LL; uint8_t* mapof = mapll + 1024;
@@ -1730,9 +1729,9 @@ __device__ static inline uint32_t cz_rec_values(uint64_t r, cz_gcptr bits, uint3
     }
     return ov;
 }
-/* chunks [first, nseq) of a block; history in sh.hist, positions in xref.  The execution context is worked on in registers
-   (wave-uniform) and written back once. */
-__device__ static __attribute__((noinline)) int cz_sequences_rec_general(CzExecCtx& xref, const CzLit lit, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, uint32_t first) {
+/* chunks [first, end) of a block (end: a multiple of 64 past first, or nseq); history in sh.hist, positions in xref.  The execution
+   context is worked on in registers (wave-uniform) and written back once. */
+__device__ static __attribute__((noinline)) int cz_sequences_rec_general(CzExecCtx& xref, const CzLit lit, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, uint32_t first, uint32_t end) {
     CzExecCtx x = xref;
     x.out = (cz_gptr)cz_uni64((uint64_t)x.out); x.cap = cz_uni64(x.cap); x.produced = cz_uni64(x.produced); x.drained = cz_uni64(x.drained);
     x.window = cz_uni64(x.window); x.lit_used = cz_uni(x.lit_used);
@@ -1755,7 +1754,7 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_general(CzExecC
      * positions, every check) and then copied.  (Planning a chunk ahead of the copy and touching its
      * source lines early was measured: once no access was a flat_* one it no longer paid.) */
     uint64_t r1 = load_rec(first), r2 = load_rec(first + 64), r3 = load_rec(first + 128);
-    for (uint32_t done = first; done < nseq; done += 64) {
+    for (uint32_t done = first; done < end; done += 64) {
         const CzPlan cur = plan(r1, done, x.produced, x.lit_used);
         r1 = r2; r2 = r3; r3 = load_rec(done + 192);
         if (cur.err > 0) return cur.err;
@@ -1772,19 +1771,6 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_general(CzExecC
     if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
     xref.produced = x.produced; xref.lit_used = x.lit_used;
     return 0;
-}
-/* one chunk in the general form, for the fast loop; history in sh.hist, positions in x */
-__device__ static __attribute__((noinline)) int cz_rec_chunk_general(CzExecCtx& x, const CzLit& lit, uint64_t r, uint32_t cnt, cz_gcptr bits) {
-    uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
-    uint32_t ll = 0, ml = 0, ov = 4;
-    if ((uint32_t)LANE < cnt) ov = cz_rec_values(r, bits, ll, ml);
-    const uint32_t actual = cz_history(cnt, ll, ov, h0, h1, h2);
-    const CzPlan cur = cz_chunk_plan(x, x.produced, x.lit_used, lit, cnt, ll, ml, actual);
-    cz_wave_sync();
-    if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; }
-    cz_wave_sync();
-    if (cur.err > 0) return cur.err;
-    return cz_chunk_copy(x, lit, cur);
 }
 /* unaligned loads from global memory (the sizes are literals: a size that depends on a template parameter makes the builtin an ordinary call) */
 __device__ static inline uint32_t cz_ldu16(cz_gcptr p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
@@ -1816,10 +1802,10 @@ __device__ static inline void cz_fast_group(uint8_t* ob, uint32_t orel, uint32_t
 #pragma unroll
     for (int j = NL - 1; j >= 0; j--) { ob[((uint32_t)j < ll ? orel : dump) + (uint32_t)j] = (uint8_t)(lw[j >> 2] >> (8 * (j & 3))); CZ_LOCKSTEP(); }
 }
-#define CZ_FAST_MISSES 6u   /* chunks of a block the fast loop may leave to the general form before it hands over the rest */
-/* returns 0 (block done), a status, or -1: sh.rec_next is the first chunk not done — positions in xref, history in sh.hist.
-   (The count of chunks left to the general form lives in LDS: one more loop-carried scalar costs this loop a fifth of its speed.) */
-__device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec_, uint32_t nseq_, uint32_t mapflags, cz_gcptr bits_) {
+/* Chunks [first_, nseq) of a block.  Returns 0 (block done: the literals after the last sequence are copied too), a status, or -2:
+   the chunk at sh.rec_next needs the general form — positions in xref, history in sh.hist.  The loop makes no call (a call
+   inside it would keep its live values in the callee-saved half of the registers: 113 spills at 96 registers, none like this). */
+__device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx& xref, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec_, uint32_t nseq_, uint32_t mapflags, cz_gcptr bits_, uint32_t first_) {
     CZ_PROF_DECL; CZ_PROF_T0();
     cz_rec_load_maps(maps, mapflags);
     /* uniform state of the block, in scalar registers */
@@ -1835,8 +1821,8 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx&
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
     uint8_t* const ob = sh.a.t4.obuf;
     auto load_rec = [&](uint32_t first) -> uint64_t { const uint32_t i = first + (uint32_t)LANE; return rec[i < nseq ? i : nseq - 1]; };   /* coalesced 8-byte loads */
-    uint64_t r1 = load_rec(0), r2 = load_rec(64), r3 = load_rec(128);
-    uint32_t done = 0;
+    uint32_t done = cz_uni(first_);
+    uint64_t r1 = load_rec(done), r2 = load_rec(done + 64), r3 = load_rec(done + 128);
     for (; done < nseq; done += 64) {
         const uint64_t r = r1;
         r1 = r2; r2 = r3; r3 = load_rec(done + 192);
@@ -1905,16 +1891,10 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx&
         }
         if (!took) {
             cz_wave_sync();
-            if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; sh.rec_next = done; sh.rec_misses += 1; }
+            if (LANE == 0) { sh.hist[0] = h0; sh.hist[1] = h1; sh.hist[2] = h2; sh.rec_next = done; }
             cz_wave_sync();
             xref.produced = P; xref.lit_used = lit_used;
-            if (cz_uni(sh.rec_misses) > CZ_FAST_MISSES && nseq - done > 64) return -1;
-            const int e = cz_rec_chunk_general(xref, lit, r, nseq - done < 64 ? nseq - done : 64, bits);
-            if (e) return e;
-            cz_wave_sync();
-            P = cz_uni((uint32_t)xref.produced); lit_used = cz_uni(xref.lit_used);
-            h0 = cz_uni(sh.hist[0]); h1 = cz_uni(sh.hist[1]); h2 = cz_uni(sh.hist[2]);
-            CZ_PROF_T0();
+            return -2;
         }
     }
     cz_wave_sync();
@@ -1930,27 +1910,40 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx&
     return 0;
 }
 
-/* One block whose sequences cz_chain_kernel left as records (header: maps of the tables it defined, then the records). */
+/* One block whose sequences cz_chain_kernel left as records (header: maps of the tables it defined, then the records).  A chunk
+   the fast loop cannot take goes through the general loop on its own; after CZ_FAST_MISSES of those the general loop takes the
+   rest of the frame.  (Handing blocks back to the fast loop — after every chunk, after stretches of 2..8 chunks, or after 4..16
+   chunks in a row that it would have taken — was measured on the corpus-like mix: every variant lost, 8.0-12.8 ms against 7.6.) */
+#ifndef CZ_FAST_MISSES
+#define CZ_FAST_MISSES 6u
+#endif
 __device__ static int cz_sequences_rec(CzExecCtx& x, const CzLit lit, cz_gcptr64 maps, cz_gcptr64 rec, uint32_t nseq, uint32_t mapflags, cz_gcptr bits) {
     CZ_PROF_DECL; CZ_PROF_T0();
     /* the fast loop wants every position of the frame in 32 bits, no drained bytes and no dictionary content (then offset <=
-       position is the whole reach test of decode_buffer.cairo:62-93), and a frame whose blocks it has not given up on */
+       position is the whole reach test of decode_buffer.cairo:62-93) */
     uint32_t first = 0;
 #ifndef CZ_EXP_NOFAST
-    if (cz_uni64(x.cap) < 0xC0000000ull && cz_uni64(x.drained) == 0 && (sh.dict_len[0] | sh.dict_len[1]) == 0 && !cz_uni(sh.rec_general)) {
-        __syncthreads();
-        if (LANE == 0) sh.rec_misses = 0;
-        const int e = cz_sequences_rec_fast(x, lit, maps, rec, nseq, mapflags, bits);
-        if (e != -1) return e;
-        first = cz_uni(sh.rec_next);
-        cz_wave_sync();
-        if (LANE == 0) sh.rec_general = 1;
-        cz_wave_sync();
+    if (cz_uni64(x.cap) < 0xC0000000ull && cz_uni64(x.drained) == 0 && (sh.dict_len[0] | sh.dict_len[1]) == 0 && cz_uni(sh.rec_misses) <= CZ_FAST_MISSES) {
+        uint32_t flags = mapflags;
+        for (;;) {
+            const int e = cz_sequences_rec_fast(x, lit, maps, rec, nseq, flags, bits, first);   /* (it loads the maps, and copies the literals after the last sequence) */
+            if (e != -2) return e;
+            first = cz_uni(sh.rec_next); flags = 0;
+            cz_wave_sync();
+            if (LANE == 0) sh.rec_misses += 1;
+            cz_wave_sync();
+            if (cz_uni(sh.rec_misses) > CZ_FAST_MISSES) break;
+            const uint32_t end = nseq - first > 64u ? first + 64u : nseq;
+            const int e2 = cz_sequences_rec_general(x, lit, rec, nseq, bits, first, end);
+            if (e2) return e2;
+            cz_wave_sync();
+            first = end;
+        }
     } else
 #endif
     cz_rec_load_maps(maps, mapflags);
     CZ_PROF_ACC(CZ_P_RING);
-    const int e = cz_sequences_rec_general(x, lit, rec, nseq, bits, first);
+    const int e = cz_sequences_rec_general(x, lit, rec, nseq, bits, first, nseq);
     if (e) return e;
     if (x.lit_used < lit.len) {                                         /* sequence_execution.cairo:72-78 */
         const uint32_t rest = lit.len - x.lit_used;
@@ -2170,7 +2163,7 @@ __device__ static int cz_run_frame(CzFrameIO io, cz_gptr lit_scratch, cz_gptr16 
         __syncthreads();
     }
     CzExecCtx x; x.out = io.dst; x.cap = io.dst_cap; x.produced = io.produced; x.drained = io.drained; x.window = io.window; x.lit_used = 0;
-    if (LANE == 0) { sh.rec_general = 0; sh.dict_ptr[0] = (uint32_t)(uintptr_t)io.dict; sh.dict_ptr[1] = (uint32_t)((uint64_t)(uintptr_t)io.dict >> 32); sh.dict_len[0] = (uint32_t)io.dict_len; sh.dict_len[1] = (uint32_t)(io.dict_len >> 32); }
+    if (LANE == 0) { sh.rec_misses = 0; sh.dict_ptr[0] = (uint32_t)(uintptr_t)io.dict; sh.dict_ptr[1] = (uint32_t)((uint64_t)(uintptr_t)io.dict >> 32); sh.dict_len[0] = (uint32_t)io.dict_len; sh.dict_len[1] = (uint32_t)(io.dict_len >> 32); }
     __syncthreads();
     const uint64_t produced0 = io.produced;
     while (!err) {

@@ -115,15 +115,19 @@ int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx,
  * arena (8 bytes per sequence + 1312 per block with sequences; 8x the compressed bytes + 64 MiB covers every BASELINE
  * config).  With the pre-pass a batch decode is: cz_scan_kernel twice (lists the blocks of all frames, sorted by
  * sequence count, and allocates their arena space) -> cz_chain_kernel (ten blocks per wave, the three FSE state
- * machines of a block on three lanes; writes one record per sequence) -> cz_decode_frames_kernel, which consumes the
- * records.  Frames the arena cannot hold, or that are irregular in any way, are decoded entirely by
- * cz_decode_frames_kernel: errors are only ever reported by it. */
+ * machines of a block on three lanes; writes one record per sequence) -> the frame kernels, which consume the
+ * records (sequence_section_decoder.cairo:223-297 is what the records replace).  Frames the arena cannot hold, or
+ * that are irregular in any way, are decoded entirely by cz_decode_frames_kernel: errors are only ever reported by it. */
 int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
-/* Enables (bytes > 0) or disables (0) the literals pass that goes with the pre-pass: the Huffman-coded literals of the
- * frames the pre-pass takes are decoded (tree description, table, streams: literals_section_decoder.cairo:58-243) by a
- * literals-only launch of cz_decode_frames_kernel on a stream of its own, NEXT TO cz_chain_kernel, into an arena of
- * `bytes` (decoded literal bytes + 16 per block; at most the decoded size of the batch).  The decode kernels then read
- * the literals from the arena; frames that did not fit, or that are irregular in any way, decode theirs as before. */
+/* Enables (bytes > 0) or disables (0) the rest of the pre-pass, which needs the chain arena too: cz_scan_kernel also lists
+ * every Huffman-coded literals section and every run of bytes whose place in the output is known without decoding
+ * (Raw / RLE blocks ahead of a frame's first block with sequences); the sections are decoded block-parallel
+ * (tree description, table, streams: literals_section_decoder.cairo:58-243) by cz_huf1_kernel NEXT TO cz_chain_kernel and
+ * cz_huf_kernel behind it — into nodes of an arena of `bytes` (decoded literal bytes + 16 per block; at most the decoded
+ * size of the batch), or straight into the output for blocks without sequences — and the runs are copied by
+ * cz_tile_kernel.  Frames the pre-pass finishes need no frame kernel at all; the others go to cz_execute_frames_kernel
+ * (sequence execution only: sequence_execution.cairo:12-129) unless cz_context_set_exec_kernel turned it off; frames that
+ * did not fit, or that are irregular in any way, are decoded from scratch by cz_decode_frames_kernel in the same call. */
 int cz_context_set_literal_arena(cz_context* ctx, size_t bytes);
 /* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 0: every frame
  * with sequences takes it — the pre-pass works block by block, so short chains cost little). */
@@ -142,15 +146,17 @@ int cz_context_last_kernel_ms(cz_context* ctx, float* ms);
 /* The part of it spent in the FSE-chain pre-pass kernel (0 when the pre-pass is off). */
 int cz_context_last_chain_ms(cz_context* ctx, float* ms);
 /* Diagnostics of the most recent batch launch of n frames (synchronises): frames that got chain records from the
- * pre-pass, frames that got literal nodes from the literals pass. */
+ * pre-pass, frames whose literals the huff0 kernels decoded. */
 int cz_context_last_prepass_counts(cz_context* ctx, size_t n, size_t* with_chain, size_t* with_literals);
-/* How long that launch went on waiting for the literals pass after the chain kernel was done (0: no literals pass). */
+/* How long that launch went on with cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel after the chain kernel was done
+ * (0: no literal arena). */
 int cz_context_last_literals_tail_ms(cz_context* ctx, float* ms);
-/* The part of it spent in cz_exec_frames_kernel (0 when it did not run). */
+/* The part of it spent in cz_execute_frames_kernel (0 when it did not run). */
 int cz_context_last_exec_ms(cz_context* ctx, float* ms);
-/* With the pre-pass on, frames that got chain records run on cz_decode_frames_kernel's record path (one wave per
- * frame; default, the faster of the two as measured) or, with on = 1, on cz_exec_frames_kernel: one workgroup of
- * 16 waves per frame, the block's output assembled in a 128 KiB LDS ring and written to HBM once. */
+/* With both arenas set, frames the pre-pass prepared completely are executed by cz_execute_frames_kernel (one wave per
+ * frame, sequence execution only: no decoders in LDS or registers) — on = 1, the default; on = 0 sends them to
+ * cz_decode_frames_kernel's record path instead (the round-2 arrangement, kept for A/B runs: bench.py --no-exec-kernel).
+ * Batches that start from a dictionary (cz_context_set_dictionary) always take cz_decode_frames_kernel. */
 int cz_context_set_exec_kernel(cz_context* ctx, int on);
 
 /* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the

@@ -20,8 +20,9 @@ b = synth.generate("mix", n, nthreads=16)
 order = np.argsort(-b.regen.astype(np.int64))
 dev = torch.device("cuda:0")
 ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
-for rank in [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]:
-    idx = order[rank:rank + 1]
+picks = [("rank", int(a)) for a in sys.argv[1:] if a.isdigit()] + [("frame", int(a[1:])) for a in sys.argv[1:] if a[0] == "f" and a[1:].isdigit()]
+for how, rank in picks or [("rank", 0)]:
+    idx = order[rank:rank + 1] if how == "rank" else np.array([rank])
     off, ln, rg = b.off[idx], b.length[idx], b.regen[idx]
     t = [torch.from_numpy(x).to(dev) for x in (b.base, off.astype(np.int64), ln.astype(np.int64), np.zeros(1, dtype=np.int64), rg.astype(np.int64))]
     t_out = torch.empty(int(rg[0]) + 256, dtype=torch.uint8, device=dev)
@@ -36,7 +37,7 @@ for rank in [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]:
     res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
     vals = [buf[i] for i in range(11)]
     tot = sum(vals) or 1
-    print(f"frame rank {rank}: {int(rg[0])} B decoded, {int(ln[0])} B compressed, {int(res['blocks_decoded'][0])} blocks, total {ctx.last_kernel_ms():.3f} ms chain {ctx.last_chain_ms():.3f} ms status {int(res['status'][0])}")
+    print(f"{how} {rank}: {int(rg[0])} B decoded, {int(ln[0])} B compressed, {int(res['blocks_decoded'][0])} blocks, total {ctx.last_kernel_ms():.3f} ms chain {ctx.last_chain_ms():.3f} ms exec {ctx.last_exec_ms():.3f} ms status {int(res['status'][0])}")
     print("   " + "  ".join(f"{nm} {100.0 * v / tot:.1f}%" for nm, v in zip(PHASES, vals) if v))
     lv = [buf[20 + i] for i in range(11)]
     if sum(lv):

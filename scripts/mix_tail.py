@@ -28,15 +28,17 @@ for label, idx in [("largest 1", order[:1]), ("2nd largest", order[1:2]), ("larg
     t_out = torch.empty(total, dtype=torch.uint8, device=dev)
     t_res = torch.zeros(idx.size * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     line = f"{label:22s} frames {idx.size:6d}  MB {rg.sum() / 1e6:8.1f}"
-    for pre in (0, 1):
-        ctx.set_chain_arena(int(ln.sum()) * 8 + (64 << 20) if pre else 0, min_sequences=0)
+    line += f" max {rg.max() / 1e6:6.2f} MB"
+    for pre in (1,):
+        ctx.set_chain_arena(int(ln.sum()) * 8 + (64 << 20) if pre else 0)
+        ctx.set_literal_arena(int(rg.sum()) + (16 << 20) if pre else 0)
         tot, ch = [], []
         for it in range(3):
             ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), idx.size, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
             tot.append(ctx.last_kernel_ms())
-            ch.append(ctx.last_chain_ms())
+            ch.append(ctx.last_exec_ms() if pre else 0.0)
         res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
         ok = bool((res["status"] == 0).all())
-        line += (f" [{ctx.last_prepass_counts(idx.size)[0]} pre-passed]" if pre else "") + f"   {'prepass' if pre else 'single '} total {np.mean(tot[1:]):7.3f} chain {np.mean(ch[1:]):7.3f} ok={ok}"
+        line += (f" [{ctx.last_prepass_counts(idx.size)[0]} pre-passed]" if pre else "") + f"   {'prepass' if pre else 'single '} total {np.mean(tot[1:]):7.3f} exec {np.mean(ch[1:]):7.3f} ok={ok}"
     print(line, flush=True)
 ctx.close()

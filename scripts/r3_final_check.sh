@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU parity suite, smoke() and the default bench line in one call
+set -o pipefail
+mkdir -p gpurun_out/r3
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3/pytest_gpu.log 2>&1; rc=$?; tail -3 gpurun_out/r3/pytest_gpu.log; [ $rc = 0 ] || exit $rc
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 || exit 1
+timeout -k 10 600 python bench.py > gpurun_out/r3/bench_default.json 2> gpurun_out/r3/bench_default.err || { tail -5 gpurun_out/r3/bench_default.err; exit 1; }
+python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r3/bench_default.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value", "ms_per_step", "bit_exact", "kernel_source_hash")}, d["roofline"]["frac"], d["roofline"]["traffic"])
+for o in d.get("other_workloads", []): print("  ", o["workload"] if "workload" in o else o.get("name"), o.get("ms_per_step"), o.get("roofline_frac"), o.get("bit_exact"))
+PY
