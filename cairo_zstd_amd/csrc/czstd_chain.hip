@@ -491,18 +491,30 @@ struct CzsBlk { uint32_t type, blk_off, bsize;                          /* 0 Raw
                 uint32_t lt, regen, lit_hdr, nseq, sbody, modes; };     /* Compressed: literals type, regenerated size, header bytes, sequences, first table description, modes */
 /* the walk of one lane over its frame; cz_scan_kernel advances all lanes of a wave together, one block at a time,
    so that the counters they share are bumped once per wave and size class (and the CPU emulator sees uniform control flow) */
-struct CzsWalk { const uint8_t* src; uint64_t len, pos, end; uint32_t defined, has_checksum; int first, active, ok, have_tree; };
+struct CzsWalk { const uint8_t* src; uint64_t len, pos, end, h8; uint32_t h8sh, defined, has_checksum; int first, active, ok, have_tree; };   /* h8 >> (8 * h8sh), or 0 when h8sh >= 8: the 8 bytes at pos, asked for a block ahead */
+/* up to 8 bytes at `at` (little endian), zeros beyond the end of the frame (len >= 8).  ONE load whatever the position — the
+   last 8 bytes of the frame shifted down when `at` is nearer to its end: a byte-by-byte tail path would be taken by some lane
+   of the wave in nearly every step of the walk, and it costs every lane eight dependent loads. */
+__device__ static inline uint64_t czs_ld8_issue(const uint8_t* src, uint64_t len, uint64_t at, uint32_t* sh) {   /* the load; its use (czs_ld8_value) may come much later */
+    const uint64_t a2 = at + 8 <= len ? at : len - 8;
+    uint64_t v; __builtin_memcpy(&v, src + a2, 8);
+    *sh = (uint32_t)(at - a2);                                          /* 0 when the load is where it was asked for */
+    return v;
+}
+__device__ static inline uint64_t czs_ld8_value(uint64_t raw, uint32_t sh) { return sh >= 8 ? 0 : raw >> (8 * sh); }
+__device__ static inline uint64_t czs_ld8(const uint8_t* src, uint64_t len, uint64_t at) { uint32_t sh; const uint64_t v = czs_ld8_issue(src, len, at, &sh); return czs_ld8_value(v, sh); }
 __device__ static inline void czs_begin(CzsWalk& w, const uint8_t* src, uint64_t len, int valid) {
-    w.src = src; w.len = len; w.pos = 0; w.end = 0; w.defined = 0; w.has_checksum = 0; w.first = 1; w.active = 0; w.ok = 0; w.have_tree = 0;
-    if (!valid || len < 5 || len >= 0xFFFFFFF0ull) return;              /* block offsets are 32 bits */
-    const uint32_t magic = (uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24);
-    const uint32_t d = src[4];
+    w.src = src; w.len = len; w.pos = 0; w.end = 0; w.h8 = 0; w.h8sh = 8; w.defined = 0; w.has_checksum = 0; w.first = 1; w.active = 0; w.ok = 0; w.have_tree = 0;
+    if (!valid || len < 8 || len >= 0xFFFFFFF0ull) return;              /* block offsets are 32 bits; a frame with a block is 8 bytes at least (shorter ones: the decode kernel) */
+    const uint64_t h0 = czs_ld8(src, len, 0);
+    const uint32_t magic = (uint32_t)h0;
+    const uint32_t d = (uint32_t)(h0 >> 32) & 0xFF;
     const uint32_t single = (d >> 5) & 1, didf = d & 3, dl = didf == 3 ? 4 : didf, flag = d >> 6;
     const uint32_t fl = flag == 0 ? (single ? 1u : 0u) : flag == 1 ? 2u : flag == 2 ? 4u : 8u;
     const uint32_t hl = 5 + (single ? 0 : 1) + dl + fl;
     if (magic != 0xFD2FB528u || len < hl) return;                       /* frame.cairo:152-284: only the header's length and validity matter here */
-    if (!single) { const uint32_t wd = src[5]; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) return; }
-    w.pos = hl; w.active = 1; w.has_checksum = (d >> 2) & 1;
+    if (!single) { const uint32_t wd = (uint32_t)(h0 >> 40) & 0xFF; const uint64_t base = 1ull << (10 + (wd >> 3)); if (base + (base / 8) * (wd & 7) >= 4123168604160ull) return; }
+    w.pos = hl; w.active = 1; w.has_checksum = (d >> 2) & 1; w.h8 = czs_ld8_issue(src, len, hl, &w.h8sh);
 }
 /* advances to the next block: 1 with `b` filled, or 0 — the walk is over (w.active = 0) and w.ok says whether the frame was
    regular to its end */
@@ -513,22 +525,26 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         uint64_t pos = w.pos;
         if (pos == ~0ull) { w.active = 0; w.ok = 1; return 0; }          /* the last block was the frame's last */
         if (len - pos < 3) break;
-        const uint32_t b0 = src[pos], b1 = src[pos + 1], b2 = src[pos + 2];
+        /* the block header and the literals section header behind it came with ONE load, issued while the previous block was
+           looked at; the next block's are asked for as soon as this block's size is known, so the walk waits for memory once
+           per block (the sequences header below is fetched beside it) */
+        const uint64_t h = czs_ld8_value(w.h8, w.h8sh);
+        const uint32_t b0 = (uint32_t)h & 0xFF, b1 = (uint32_t)(h >> 8) & 0xFF, b2 = (uint32_t)(h >> 16) & 0xFF;
         const uint32_t type = (b0 >> 1) & 3, size = (b0 >> 3) | (b1 << 5) | (b2 << 13), blast = b0 & 1;
         if (type == 3 || size > 128u * 1024u) break;
         const uint64_t body = pos + 3; const uint32_t content = type == 1 ? 1u : size;
         if (len - body < content) break;
         w.pos = blast ? ~0ull : body + content;
         if (blast) w.end = body + content;                              /* where the content checksum, if any, begins */
+        else w.h8 = czs_ld8_issue(src, len, body + content, &w.h8sh);
         b.type = type; b.blk_off = (uint32_t)body; b.bsize = size; b.lt = 0; b.regen = 0; b.lit_hdr = 0; b.nseq = 0; b.sbody = 0; b.modes = 0;
         if (type != 2) return 1;
         /* literals section header (literals_section.cairo:81-175): sizes only */
-        const uint8_t* p = src + body;
         if (size == 0) break;
-        const uint32_t l0 = p[0], lt = l0 & 3, fmt = (l0 >> 2) & 3;
+        const uint32_t l0 = (uint32_t)(h >> 24) & 0xFF, lt = l0 & 3, fmt = (l0 >> 2) & 3;
         const uint32_t need = lt <= 1 ? ((fmt == 0 || fmt == 2) ? 1u : (fmt == 1 ? 2u : 3u)) : (fmt <= 1 ? 3u : (fmt == 2 ? 4u : 5u));
         if (size < need) break;
-        const uint32_t l1 = need > 1 ? p[1] : 0, l2 = need > 2 ? p[2] : 0, l3 = need > 3 ? p[3] : 0, l4 = need > 4 ? p[4] : 0;
+        const uint32_t l1 = need > 1 ? (uint32_t)(h >> 32) & 0xFF : 0, l2 = need > 2 ? (uint32_t)(h >> 40) & 0xFF : 0, l3 = need > 3 ? (uint32_t)(h >> 48) & 0xFF : 0, l4 = need > 4 ? (uint32_t)(h >> 56) & 0xFF : 0;
         uint32_t upper, regen;
         if (lt <= 1) { regen = (fmt == 0 || fmt == 2) ? l0 >> 3 : (fmt == 1 ? (l0 >> 4) + (l1 << 4) : (l0 >> 4) + (l1 << 4) + (l2 << 12)); upper = lt == 1 ? 1u : regen; }
         else {
@@ -540,16 +556,17 @@ __device__ static inline int czs_next(CzsWalk& w, uint32_t chain_min_nseq, CzsBl
         if (lt == 2) w.have_tree = 1;
         const uint32_t so = need + upper, sl_ = size - so;              /* sequence_section.cairo:77-114 */
         if (sl_ == 0) break;
-        const uint32_t s0 = p[so];
+        const uint64_t sq = czs_ld8(src, len, body + so);               /* the sequences header: count (1..3 bytes) and the modes byte */
+        const uint32_t s0 = (uint32_t)sq & 0xFF, s1 = (uint32_t)(sq >> 8) & 0xFF, s2 = (uint32_t)(sq >> 16) & 0xFF;
         uint32_t n = 0, hb = 0;
         if (s0 == 0) { }
         else if (s0 <= 127) { if (sl_ < 2) break; n = s0; hb = 1; }
-        else if (s0 <= 254) { if (sl_ < 3) break; n = ((s0 - 128) << 8) + p[so + 1]; hb = 2; }
-        else { if (sl_ < 4) break; n = p[so + 1] + ((uint32_t)p[so + 2] << 8) + 0x7F00u; hb = 3; }
+        else if (s0 <= 254) { if (sl_ < 3) break; n = ((s0 - 128) << 8) + s1; hb = 2; }
+        else { if (sl_ < 4) break; n = s1 + (s2 << 8) + 0x7F00u; hb = 3; }
         b.lt = lt; b.regen = regen; b.lit_hdr = need;
         if (!n) return 1;                                               /* (128, 0: no sequences but a modes byte) */
         if (w.first && n < chain_min_nseq) break;
-        b.nseq = n; b.modes = p[so + hb]; b.sbody = so + hb + 1;
+        b.nseq = n; b.modes = (uint32_t)(sq >> (8 * hb)) & 0xFF; b.sbody = so + hb + 1;
         int undefined = 0;
         for (int t = 0; t < 3; t++) {                                   /* Repeat of a table nothing defined (sequence_section_decoder.cairo:483,551,643) */
             const uint32_t md = (b.modes >> (6 - 2 * t)) & 3;
@@ -578,6 +595,15 @@ __device__ static inline uint32_t czs_ticket(uint32_t* counters, int has, uint32
     }
     return ticket;
 }
+/* The lists are filled by class (blocks by sequence count, literal sections by size, copies), and every lane of every wave adds
+ * to them once per block of its frame.  One global atomic per block and class was the whole cost of the scan on batches of
+ * many-block frames (230 000 atomics on 40 addresses: 0.3 ms per pass on the corpus-like mix): the wave counts in LDS instead
+ * — czs_cnt[0..31] blocks per sequence-count class, [32..63] literal sections per size class, [64] copy runs — adds its totals
+ * to the global counters once at the end of pass 0 and leaves them in scan_wave; pass 1 takes the wave's share of every class
+ * range with one atomic at its start (czs_base) and hands out places from LDS.  Both passes walk the same blocks and make the
+ * same decisions, so the counts agree. */
+#define CZS_WAVE_WORDS 72u
+__shared__ uint32_t czs_cnt[CZS_WAVE_WORDS], czs_base[CZS_WAVE_WORDS];
 /* what one block contributes to the lists, the same in both passes.  `known`: the block's place in the output follows from the
    headers (no block with sequences before it); kout: that place */
 struct CzsPlan { int chain, lit, copy; uint32_t copy_len, copy_fill; uint64_t copy_src; int direct; };
@@ -614,6 +640,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
         a.frame_order[fb + ft] = f;
     }
     int known = 1; uint64_t kout = 0; uint32_t pre_blocks = 0;
+    for (uint32_t i = (uint32_t)LANE; i < CZS_WAVE_WORDS; i += 64u) {
+        czs_cnt[i] = 0; czs_base[i] = 0;
+        if (a.scan_pass == 1) {                                         /* the wave's share of every class range: what it counted in pass 0, taken with one atomic */
+            const uint32_t v = a.scan_wave[(uint64_t)blockIdx.x * CZS_WAVE_WORDS + i];
+            if (v) czs_base[i] = atomicAdd(&a.scan_ctl[i < 32u ? 32u + i : (i < 64u ? 168u + (i - 32u) : 202u)], v);
+        }
+    }
+    __syncthreads();
     if (a.scan_pass == 0) {
         uint64_t units = 0, lbytes = 0; int seen_seq = 0;
         while (__ballot(w.active)) {
@@ -625,13 +659,19 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                 if (known && kout + out > ocap) { w.active = 0; w.ok = 0; q.chain = q.lit = q.copy = 0; }   /* the decode kernel reports it */
                 else if (b.type == 2 && b.nseq) known = 0; else if (known) kout += out;
             }
-            czs_ticket(a.scan_ctl, q.chain, q.chain ? czs_class(b.nseq) : 0u);
+            if (q.chain) atomicAdd(&czs_cnt[czs_class(b.nseq)], 1u);   /* the wave's counts per class, in LDS (see czs_cnt) */
             if (with_lits) {
-                czs_ticket(a.scan_ctl + 136, q.lit, q.lit ? czs_class(b.regen) : 0u);
-                czs_ticket(a.scan_ctl + 201, q.copy, 0u);
+                if (q.lit) atomicAdd(&czs_cnt[32u + czs_class(b.regen)], 1u);
+                if (q.copy) atomicAdd(&czs_cnt[64], 1u);
             }
             if (q.chain) { units += 4ull + CZC_MAP_WORDS + b.nseq; seen_seq = 1; }
             if (q.lit && !q.direct) lbytes += 16ull + ((b.regen + 15u) & ~15u);
+        }
+        __syncthreads();
+        for (uint32_t i = (uint32_t)LANE; i < CZS_WAVE_WORDS; i += 64u) {   /* one global atomic per class the wave met, and the wave's counts for pass 1 */
+            const uint32_t v = czs_cnt[i];
+            a.scan_wave[(uint64_t)blockIdx.x * CZS_WAVE_WORDS + i] = v;
+            if (v) atomicAdd(&a.scan_ctl[i < 32u ? i : (i < 64u ? 136u + (i - 32u) : 201u)], v);
         }
         if (valid) {                                                    /* between the passes: arena units / literal bytes the frame needs */
             a.frame_first[f] = w.ok ? units : 0;
@@ -672,13 +712,13 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
             if (known && kout + out > ocap) { w.active = 0; w.ok = 0; q.chain = q.lit = q.copy = 0; }
             else if (b.type == 2 && b.nseq) known = 0; else if (known) { kout += out; pre_blocks++; }
         }
-        /* every lane of the wave takes the same tickets as in pass 0, placed or not: the class bases depend on it */
+        /* every lane takes a place for everything it counted in pass 0, placed in the arenas or not: the wave's shares depend on it */
         const uint32_t cls = q.chain ? czs_class(b.nseq) : 0u;
-        const uint32_t ticket = czs_ticket(a.scan_ctl + 32, q.chain, cls);
+        const uint32_t ticket = q.chain ? czs_base[cls] + atomicAdd(&czs_cnt[cls], 1u) : 0u;
         uint32_t lticket = 0, cticket = 0; const uint32_t lcls = q.lit ? czs_class(b.regen) : 0u;
         if (with_lits) {
-            lticket = czs_ticket(a.scan_ctl + 168, q.lit, lcls);
-            cticket = czs_ticket(a.scan_ctl + 202, q.copy, 0u);
+            if (q.lit) lticket = czs_base[32u + lcls] + atomicAdd(&czs_cnt[32u + lcls], 1u);
+            if (q.copy) cticket = czs_base[64] + atomicAdd(&czs_cnt[64], 1u);
         }
         if (q.chain) {
             uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == cls) bb = base[c];
@@ -736,7 +776,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
             if (good && known && !a.verify_checksum && (!w.has_checksum || w.len - w.end >= 4)) {
                 pre |= CZ_PRE_DONE;
                 uint32_t ck = 0, fl = CZ_RESULT_FINISHED; uint64_t pos = w.end;
-                if (w.has_checksum) { const uint8_t* p = w.src + pos; ck = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); fl |= CZ_RESULT_HAS_CHECKSUM; pos += 4; }
+                if (w.has_checksum) { ck = (uint32_t)czs_ld8(w.src, w.len, pos); fl |= CZ_RESULT_HAS_CHECKSUM; pos += 4; }
                 cz_frame_result r; r.status = 0; r.blocks_decoded = pre_blocks; r.bytes_consumed = pos; r.bytes_produced = kout; r.checksum_from_data = ck; r.flags = fl;
                 r.detail[0] = pre_blocks; r.detail[1] = pos; r.calculated_checksum = 0; r.reserved = 0;
                 a.results[f] = r;

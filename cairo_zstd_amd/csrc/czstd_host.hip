@@ -68,6 +68,7 @@ struct cz_context {
     uint64_t* frame_first = nullptr; size_t frame_first_cap = 0;
     cz_blk_desc* blk_desc = nullptr; uint32_t blk_capacity = 0; uint32_t* scan_ctl = nullptr;   /* block list of the pre-pass */
     uint32_t* frame_order = nullptr;                                    /* n entries, allocated with frame_first */
+    uint32_t* scan_wave = nullptr;                                      /* 72 words per wave of cz_scan_kernel, allocated with frame_first */
     int chain_grid = 0; uint32_t chain_min_nseq = 0;
     /* optional: block-parallel huff0 and tile kernels next to / behind the chain kernel, on streams of their own */
     uint8_t* lit_arena = nullptr; uint64_t lit_capacity = 0; unsigned long long* lit_top = nullptr;
@@ -154,6 +155,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->blk_desc) (void)hipFree(c->blk_desc);
     if (c->scan_ctl) (void)hipFree(c->scan_ctl);
     if (c->frame_order) (void)hipFree(c->frame_order);
+    if (c->scan_wave) (void)hipFree(c->scan_wave);
     if (c->fallback_list) (void)hipFree(c->fallback_list);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -346,6 +348,9 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (c->frame_order) (void)hipFree(c->frame_order);
             c->frame_order = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->frame_order, n * 4));
+            if (c->scan_wave) (void)hipFree(c->scan_wave);
+            c->scan_wave = nullptr;
+            CZ_HIP(c, hipMalloc((void**)&c->scan_wave, ((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS) * 72 * 4));
             if (c->fallback_list) (void)hipFree(c->fallback_list);
             c->fallback_list = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->fallback_list, n * 4));
@@ -368,7 +373,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             a.lit_segs = c->lit_segs; a.lit_seg_capacity = c->seg_capacity; a.copy_segs = c->copy_segs; a.copy_seg_capacity = c->seg_capacity; a.frame_pre = c->frame_pre;
         }
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
-        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order;
+        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
         CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
         a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);

@@ -111,6 +111,7 @@ typedef struct cz_batch_args {
     uint64_t* chain_arena; uint64_t chain_capacity; unsigned long long* chain_top; uint64_t* frame_first;
     uint32_t* chain_counter; uint32_t chain_min_nseq; uint32_t chain_grid;   /* chain_grid: workgroups of the cz_chain_kernel launch */
     cz_blk_desc* blk_desc; uint32_t blk_capacity; uint32_t* scan_ctl; uint32_t scan_pass;   /* block list of the pre-pass (cz_scan_kernel) */
+    uint32_t* scan_wave;                      /* 72 words per wave of cz_scan_kernel: what it counted per class in pass 0 */
     uint32_t* frame_order;                    /* NULL, or the order in which the decode kernels take the frames: largest compressed size first (cz_scan_kernel) */
     uint32_t* exec_counter;                   /* work counter of cz_execute_frames_kernel */
     uint32_t* fallback_list; uint32_t* fallback_count;   /* frames cz_execute_frames_kernel leaves to cz_decode_frames_kernel (NULL: that kernel takes all n frames) */

@@ -116,11 +116,12 @@ int main(int argc, char** argv) {
     /* passes: [chain pre-pass, [literals pass, [cz_execute_frames_kernel (EMU_EXEC=1),]]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
     const int with_exec = arena && lit_bytes && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
     uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
-    std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order;
+    std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order, scan_wave;
     if (arena) {
         blk_desc.resize(a.chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
         a.blk_desc = blk_desc.data(); a.blk_capacity = (uint32_t)blk_desc.size(); a.scan_ctl = scan_ctl.data();
         frame_order.resize(n ? n : 1); a.frame_order = frame_order.data();
+        scan_wave.assign(((n + 63) / 64 + 1) * 72, 0); a.scan_wave = scan_wave.data();
     }
     /* EMU_DICT=<file>: parse the dictionary with cz_dict_setup_kernel (one workgroup) and start every frame from it, as
        cz_context_set_dictionary does; a dictionary that does not parse ends the run with exit code 3 and its status on stderr */

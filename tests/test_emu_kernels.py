@@ -95,6 +95,18 @@ def test_emu_chain_prepass():
     _run_and_compare(frames[:10], caps[:10], chain_bytes=4096, lit_bytes=6000)
 
 
+def test_emu_scan_lists_over_several_waves():
+    """cz_scan_kernel counts per class in LDS and shares the class ranges out per WAVE (scan_wave): a batch of more than two
+    waves of frames — corpus frames of several blocks, Raw / RLE / Compressed, repeated in a shuffled order — through the whole
+    pre-pass pipeline."""
+    small = [(z, len(orig) + 16) for name, z, orig in corpus_pairs(max_orig=500)]
+    rng = np.random.default_rng(77)
+    pick = rng.integers(0, len(small), 132)
+    frames = [small[int(i)][0] for i in pick]
+    caps = [small[int(i)][1] for i in pick]
+    _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+
+
 def test_emu_execute_frames_kernel():
     """cz_execute_frames_kernel (czstd_kernels.hip compiled without its decoders: the frames the pre-pass finished) under
     ASan/UBSan, followed by cz_decode_frames_kernel on the frames it left: corpus frames, synthetic frames, malformed
