@@ -16,10 +16,21 @@ from cairo_zstd_amd import synth
 
 def main():
     total_bad = 0
-    for kind, n, first in (("mix", 6000, 100000), ("mix", 6000, 300000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000)):
+    for kind, n, first in (("mix", 6000, 100000), ("mix", 6000, 300000), ("mix!", 6000, 500000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000),
+                           ("raw_rle", 300, 11000)):
+        damaged = kind.endswith("!")                                     # every third frame gets one flipped bit or loses its tail
+        kind = kind.rstrip("!")
         b = synth.generate(kind, n, first_index=first, nthreads=16)
+        if damaged:
+            rng = np.random.default_rng(first)
+            for i in range(0, n, 3):
+                o, ln = int(b.off[i]), int(b.length[i])
+                if rng.integers(0, 4) == 0:
+                    b.length[i] = max(1, ln - int(rng.integers(1, min(ln, 4000))))
+                else:
+                    b.base[o + int(rng.integers(4, ln))] ^= np.uint8(1 << int(rng.integers(0, 8)))
         frames = [b.frame(i) for i in range(n)]
-        caps = [int(r) + 8 for r in b.regen]
+        caps = [int(r) for r in b.regen]                                 # the capacities the oracle gets below (out_layout)
         o_off, o_cap, o_total = b.out_layout(64)
         _, olen, ost = oracle.decode_batch(b.base, b.off, b.length, o_off, o_cap, int(o_total) + 256, nthreads=32)
         ref_out = _
@@ -35,7 +46,9 @@ def main():
             for i, (r, out) in enumerate(got):
                 if int(r["status"]) != int(ost[i]) or (int(ost[i]) == 0 and out != ref_out[int(o_off[i]): int(o_off[i]) + int(olen[i])].tobytes()):
                     bad += 1
-            print(f"{kind:14s} n={n} prepass={prepass} bad={bad} chain_ms={c.last_chain_ms():.2f} ({time.time() - t:.1f} s)", flush=True)
+                    if bad <= 3:
+                        print(f"   frame {i}: gpu {cz.status.name(r['status'])} oracle {cz.status.name(int(ost[i]))}", flush=True)
+            print(f"{kind + ('!' if damaged else ''):14s} n={n} prepass={prepass} bad={bad} chain_ms={c.last_chain_ms():.2f} ({time.time() - t:.1f} s)", flush=True)
             total_bad += bad
             c.close()
     print("TOTAL BAD", total_bad)

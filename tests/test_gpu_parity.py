@@ -139,16 +139,28 @@ def _mutations(z: bytes, seed: int):
     return out
 
 
-def test_malformed_inputs_status_parity(cz, ctx):
+@pytest.mark.parametrize("pipeline", ["single_kernel", "prepass"])
+def test_malformed_inputs_status_parity(cz, ctx, pipeline):
     """Truncated / bit-flipped frames: same status as the oracle, never a fault, and a failing
-    frame leaves its neighbours intact."""
+    frame leaves its neighbours intact — through the one complete kernel, and through the pre-pass kernels (scan, chain,
+    huff0, tile, execute), which must hand every irregular frame to the complete kernel for the reference's status."""
     pairs = corpus_pairs(max_orig=20000)
     frames, caps = [], []
     for idx, (name, z, orig) in enumerate(pairs):
         for m in _mutations(z, idx):
             frames.append(m)
             caps.append(len(orig) * 2 + 4096)
-    got = cz.decode_batch_host(frames, caps, ctx)
+    if pipeline == "prepass":
+        c2 = cz.Context(0)
+        c2.set_chain_arena(128 << 20, min_sequences=0)
+        c2.set_literal_arena(64 << 20)
+        try:
+            got = cz.decode_batch_host(frames, caps, c2)
+            assert c2.last_chain_ms() > 0.0
+        finally:
+            c2.close()
+    else:
+        got = cz.decode_batch_host(frames, caps, ctx)
     mismatch = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -825,3 +837,35 @@ def test_decode_batch_multi_deals_frames_over_contexts(cz):
     finally:
         c0.close()
         c1.close()
+
+
+@pytest.mark.parametrize("pipeline", ["single_kernel", "prepass"])
+def test_damaged_synthetic_frames_status_and_output_parity(cz, pipeline):
+    """1 800 corpus-like multi-block frames, every third with one flipped bit or a cut tail: status for status and byte for byte
+    what the oracle says, with the capacities the oracle gets — through the complete kernel and through the pre-pass kernels."""
+    from cairo_zstd_amd import synth
+    n = 1800
+    b = synth.generate("mix", n, first_index=500000, nthreads=8)
+    rng = np.random.default_rng(500000)
+    for i in range(0, n, 3):
+        o, ln = int(b.off[i]), int(b.length[i])
+        if rng.integers(0, 4) == 0:
+            b.length[i] = max(1, ln - int(rng.integers(1, min(ln, 4000))))
+        else:
+            b.base[o + int(rng.integers(4, ln))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    frames = [b.frame(i) for i in range(n)]
+    caps = [int(r) for r in b.regen]
+    o_off, o_cap, o_total = b.out_layout(64)
+    ref_out, olen, ost = oracle.decode_batch(b.base, b.off, b.length, o_off, o_cap, int(o_total) + 256, nthreads=8)
+    c = cz.Context(0)
+    try:
+        if pipeline == "prepass":
+            c.set_chain_arena(int(b.length.sum()) * 8 + (64 << 20), min_sequences=0)
+            c.set_literal_arena(int(b.regen.sum()) + (16 << 20))
+        got = cz.decode_batch_host(frames, caps, c)
+    finally:
+        c.close()
+    assert int((np.asarray(ost) != 0).sum()) > n // 12                   # the damage is seen (a flipped literal or raw byte changes bytes, not the status)
+    bad = [(i, cz.status.name(r["status"]), cz.status.name(int(ost[i]))) for i, (r, out) in enumerate(got)
+           if int(r["status"]) != int(ost[i]) or (int(ost[i]) == 0 and out != ref_out[int(o_off[i]): int(o_off[i]) + int(olen[i])].tobytes())]
+    assert not bad, f"{len(bad)} of {n}: {bad[:10]}"
