@@ -5,9 +5,10 @@
 
 A "step" is one pass of the hot path (one cz_decode_batch_device call) over one batch of synthetic
 frames that already sits in HBM.  The call launches
-    cz_scan_kernel x2  ->  cz_chain_kernel || cz_huf_kernel || cz_tile_kernel   (three streams: FSE chains, Huffman literals
+    cz_scan_kernel x2  ->  cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel  (three streams: FSE chains, Huffman literals
                                                                                   and Raw / RLE runs, unit of work = a block)
-                       ->  cz_execute_frames_kernel (frames the pre-pass finished)  ->  cz_decode_frames_kernel (the rest)
+                       ->  cz_huf_kernel (the literals cz_huf1_kernel did not get to beside the chain kernel)
+                       ->  cz_execute_frames_kernel (frames the pre-pass prepared)  ->  cz_decode_frames_kernel (the rest)
 (--no-chain-prepass: the one persistent-grid cz_decode_frames_kernel of round 1).
 Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full compressed
 128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
@@ -120,7 +121,7 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra per-config measurements (N=1)")
     ap.add_argument("--no-verify-all", action="store_true", help="check only a sample of the frames against the oracle (default: every frame, by XXH64)")
     ap.add_argument("--no-chain-prepass", action="store_true", help="diagnostic: everything inside cz_decode_frames_kernel (single launch, as in round 1)")
-    ap.add_argument("--no-literals-pass", action="store_true", help="diagnostic: no cz_huf_kernel / cz_tile_kernel; literals and Raw / RLE blocks inside the decode kernel")
+    ap.add_argument("--no-literals-pass", action="store_true", help="diagnostic: no cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel; literals and Raw / RLE blocks inside the decode kernel")
     ap.add_argument("--no-exec-kernel", dest="exec_kernel", action="store_false", help="diagnostic: pre-passed frames on cz_decode_frames_kernel too, not on cz_execute_frames_kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
@@ -192,7 +193,7 @@ def main():
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
     ctx = cz.Context(local_dev, stream.cuda_stream)
-    # the block-parallel pre-pass (cz_scan_kernel + cz_chain_kernel || cz_huf_kernel || cz_tile_kernel) for every workload
+    # the block-parallel pre-pass (cz_scan_kernel + cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel + cz_huf_kernel) for every workload
     chain_prepass = not args.no_chain_prepass
     arena_bytes = int(batch.length.sum()) * 8 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
     lit_bytes = regen_bytes + (16 << 20)                               # decoded literal bytes never exceed the decoded size
@@ -230,7 +231,7 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
         chain_ms.append(ctx.last_chain_ms())                              # scans + cz_chain_kernel
         exec_ms.append(ctx.last_exec_ms())                                # cz_execute_frames_kernel
-        tail_ms.append(ctx.last_literals_tail_ms())                       # how long cz_huf_kernel / cz_tile_kernel ran on after cz_chain_kernel
+        tail_ms.append(ctx.last_literals_tail_ms())                       # how long cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel ran on after cz_chain_kernel
     torch.cuda.synchronize()
 
     # ---- decode + gather (config 5's exchange step), timed separately
@@ -391,7 +392,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         lit_pass = chain_prepass and not args.no_literals_pass
-        launches = (("cz_scan_kernel x2 + (cz_chain_kernel || cz_huf_kernel || cz_tile_kernel) + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
+        launches = (("cz_scan_kernel x2 + (cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel) + cz_huf_kernel + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
                     + ("cz_execute_frames_kernel + " if args.exec_kernel and lit_pass else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",

@@ -336,7 +336,9 @@ extern "C" __global__ void __launch_bounds__(CZH_THREADS, CZH_WAVES == 2 ? 6 : 8
                cz_execute_frames_kernel, so it is listed here */
             a.lit_first[f] = 0;
             const uint32_t old = atomicExch(&a.frame_pre[f], 0u);
+            /* (a frame is listed once however many of its sections fail: the mark stays, or cz_execute_frames_kernel would list it again) */
             if ((old & CZ_PRE_DONE) && a.fallback_list) { a.frame_pre[f] = CZ_PRE_PUSHED; a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
+            else if (old == CZ_PRE_PUSHED) a.frame_pre[f] = CZ_PRE_PUSHED;
         }
     }
 }
@@ -398,7 +400,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_huf1_kernel(cz
         if (bad && LANE == 0) {
             a.lit_first[f] = 0;
             const uint32_t old = atomicExch(&a.frame_pre[f], 0u);
+            /* (a frame is listed once however many of its sections fail: the mark stays, or cz_execute_frames_kernel would list it again) */
             if ((old & CZ_PRE_DONE) && a.fallback_list) { a.frame_pre[f] = CZ_PRE_PUSHED; a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
+            else if (old == CZ_PRE_PUSHED) a.frame_pre[f] = CZ_PRE_PUSHED;
         }
     }
 }

@@ -74,14 +74,14 @@ def test_emu_chain_prepass():
     leave them to the decoder, which reports the reference's status), an arena that is far too small, and the
     literals pass (a literals-only launch of the decode kernel) feeding the decode kernel, with room and without."""
     frames, caps = [], []
-    for name, z, orig in corpus_pairs(max_orig=1400):
+    for name, z, orig in corpus_pairs(max_orig=1000):
         frames.append(z)
         caps.append(len(orig) + 16)
     b = synth.generate("mix", 24, first_index=4242, nthreads=2)
     keep = [i for i in range(b.n) if b.regen[i] < 30000][:2]
     frames += [b.frame(i) for i in keep]
     caps += [int(b.regen[i]) + 8 for i in keep]
-    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=500)):
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=350)):
         rng = np.random.default_rng(100 + idx)
         a = bytearray(z)
         a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
@@ -97,13 +97,18 @@ def test_emu_chain_prepass():
 
 def test_emu_scan_lists_over_several_waves():
     """cz_scan_kernel counts per class in LDS and shares the class ranges out per WAVE (scan_wave): a batch of more than two
-    waves of frames — corpus frames of several blocks, Raw / RLE / Compressed, repeated in a shuffled order — through the whole
-    pre-pass pipeline."""
-    small = [(z, len(orig) + 16) for name, z, orig in corpus_pairs(max_orig=500)]
+    waves of frames — tiny Raw frames with small corpus frames (several blocks, Huffman literals, sequences) spread over the
+    waves — through the whole pre-pass pipeline."""
+    small = [(z, len(orig) + 16) for name, z, orig in corpus_pairs(max_orig=400)][:10]
     rng = np.random.default_rng(77)
-    pick = rng.integers(0, len(small), 132)
-    frames = [small[int(i)][0] for i in pick]
-    caps = [small[int(i)][1] for i in pick]
+    frames, caps = [], []
+    for i in range(134):
+        if i % 13 == 5:
+            z, cap = small[(i // 13) % len(small)]
+            frames.append(z); caps.append(cap)
+        else:
+            n = int(rng.integers(1, 40))
+            frames.append(raw_frame_with_checksum(rng.integers(0, 256, n, dtype=np.uint8).tobytes())); caps.append(n + 8)
     _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
 
 
@@ -183,6 +188,10 @@ def test_emu_prepass_kernels_and_divergence_vectors():
         assert int(emu_runner.run.last_stderr.split("EMU_LIT: ")[1].split()[0]) == len(frames)   # its stream decoder redoes an uneven split itself: D5 stays
     finally:
         del os.environ["EMU_HUF1"]
+    # frames whose TWO literals sections both go back (the D5 block twice): each is listed for the decode kernel once
+    z5 = frames[1]
+    two = z5[:5] + (2 * 288 - 256).to_bytes(2, "little") + bytes([z5[7] & 0xFE]) + z5[8:] + z5[7:]
+    _run_and_compare([two] * 5, [2 * 288 + 16] * 5, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
     os.environ["EMU_SEGS"] = "3"                                            # lists far too short: most frames are not pre-passed at all
     try:
         _run_and_compare(frames[:6], caps[:6], chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)

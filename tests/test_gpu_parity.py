@@ -869,3 +869,24 @@ def test_damaged_synthetic_frames_status_and_output_parity(cz, pipeline):
     bad = [(i, cz.status.name(r["status"]), cz.status.name(int(ost[i]))) for i, (r, out) in enumerate(got)
            if int(r["status"]) != int(ost[i]) or (int(ost[i]) == 0 and out != ref_out[int(o_off[i]): int(o_off[i]) + int(olen[i])].tobytes())]
     assert not bad, f"{len(bad)} of {n}: {bad[:10]}"
+
+
+def test_frame_whose_sections_go_back_twice_is_listed_once(cz):
+    """A frame of two blocks that cz_huf_kernel both hands back (the D5 block twice: uneven 4-stream splits): the frame is listed
+    for cz_decode_frames_kernel once, however many of its sections fail — a batch of nothing but such frames would otherwise
+    overrun the list."""
+    d = os.path.join(GOLDEN, "vectors")
+    z5 = open(os.path.join(d, "d5_uneven_4stream_split.zst"), "rb").read()
+    orig = open(os.path.join(d, "d5_uneven_4stream_split.orig"), "rb").read()
+    assert len(orig) == 288 and z5[4] == 0x60                           # single segment, 2-byte content size
+    two = z5[:5] + (2 * 288 - 256).to_bytes(2, "little") + bytes([z5[7] & 0xFE]) + z5[8:] + z5[7:]
+    st, ref, info = oracle.decode_frame(two, cap=1024)
+    assert st == 0 and ref == orig * 2 and info["blocks"] == 2
+    c = cz.Context(0)
+    try:
+        c.set_chain_arena(16 << 20, min_sequences=0)
+        c.set_literal_arena(16 << 20)
+        got = cz.decode_batch_host([two] * 300, [600] * 300, c)
+        assert all(int(r["status"]) == 0 and out == ref and int(r["blocks_decoded"]) == 2 for r, out in got)
+    finally:
+        c.close()
