@@ -412,7 +412,11 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             /* next to the chain kernel, on streams of their own: cz_huf1_kernel (one wave per literals section: what fits beside the
                chain kernel's LDS) and cz_tile_kernel; behind the chain kernel, with the whole chip: cz_huf_kernel for what is left */
             CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-            hipLaunchKernelGGL(cz_huf1_kernel, dim3(c->huf1_grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
+            int h1grid = c->huf1_grid;
+#ifdef CZ_EXPERIMENT
+            if (const char* e = getenv("CZ_HUF1_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0) h1grid = g; }
+#endif
+            hipLaunchKernelGGL(cz_huf1_kernel, dim3(h1grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
             CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
