@@ -12,7 +12,7 @@
  *     the total come from four quad_perm DPP operations; the cursor advances with one v_dot4c;
  *     tables of a refilled slot are built by the whole wave (czc_fse_build_wave).
  *   - CZC_SLOTS (10) quads per wave, four waves per CU: 40 chains per CU (LDS: 16-bit
- *     decoding tables 2.5 KB + a 512-byte bit ring per chain; 48 would fit, 40 leave 25 KB per CU to the literals pass that
+ *     decoding tables 2.5 KB + a 512-byte bit ring per chain; 48 would fit, 40 leave 25 KB per CU to the huff0 waves (cz_huf1_kernel) that
  *     runs next to this kernel).
  *   - the 32 steps of a group are one hand-scheduled inline-asm block (czc_group_asm): the ring words
  *     of step i+1 are requested before the state bits of step i are extracted, the next table entry is
@@ -31,7 +31,7 @@
  * reference's status codes in the reference's order.  Nothing here reports errors.
  */
 #ifndef CZC_SLOTS
-#define CZC_SLOTS 10        /* 40 chains per CU = 10 240 on the chip; 12 also fit the LDS, but leave no room for the literals pass next to this kernel */
+#define CZC_SLOTS 10        /* 40 chains per CU = 10 240 on the chip; 12 also fit the LDS, but leave no room for cz_huf1_kernel next to this kernel */
 #endif
 #define CZC_LPS 4           /* lanes per slot: the quad */
 static_assert(CZC_SLOTS * CZC_LPS <= 64, "quads of one wave");

@@ -30,7 +30,7 @@
 
 #include "czstd_types.h"
 
-#define LANE ((int)(threadIdx.x & 63u))   /* lane of the wavefront (cz_exec_frames_kernel has workgroups of several waves) */
+#define LANE ((int)(threadIdx.x & 63u))   /* lane of the wavefront (cz_huf_kernel, which shares this file's helpers, has workgroups of several waves) */
 #define CZ_NOINLINE __attribute__((noinline))
 /* Pointers to global memory say so in their type.  A generic pointer that crosses a function that is
  * not inlined (or sits in a struct) makes the compiler emit flat_* instructions, which count against
@@ -719,7 +719,7 @@ __device__ static __attribute__((noinline)) int cz_parse_sections(cz_gcptr blk, 
 #ifdef CZ_EXEC_ONLY
     if (type >= 2 && !have_literals) return CZX_FALLBACK;
 #else
-    if (type >= 2 && !have_literals) {                                  /* literals_section_decoder.cairo:64-117 (skipped when the literals pass
+    if (type >= 2 && !have_literals) {                                  /* literals_section_decoder.cairo:64-117 (skipped when the huff0 kernels
                                                                            already decoded this block's literals, tree included) */
         uint32_t off = need, left = comp;
         if (type == 2) {

@@ -59,7 +59,7 @@ def main():
     xv = [buf[40 + i] for i in range(9)]
     if sum(xv):
         xt = sum(xv)
-        print(f"cz_exec_frames_kernel thread-0 time shares (s_memtime ticks; {ctx.last_exec_ms():.3f} ms of the launch):")
+        print(f"cz_execute_frames_kernel thread-0 time shares (s_memtime ticks; {ctx.last_exec_ms():.3f} ms of the launch):")
         for name, v in zip(["headers+parse", "huffman table", "huffman streams", "maps", "pass 1", "pass 2", "pass 3", "flush", "raw/rle/tail"], xv):
             print(f"  {name:15s} {100.0 * v / xt:5.1f} %   {v / n:10.0f} ticks/frame")
 

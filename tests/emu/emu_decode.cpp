@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
         lit_segs.resize(cap); copy_segs.resize(cap);
         a.lit_segs = lit_segs.data(); a.lit_seg_capacity = (uint32_t)cap; a.copy_segs = copy_segs.data(); a.copy_seg_capacity = (uint32_t)cap; a.frame_pre = frame_pre.data();
     }
-    /* passes: [chain pre-pass, [literals pass, [cz_execute_frames_kernel (EMU_EXEC=1),]]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
+    /* launches: [scan, huff0 and tile kernels, chain pre-pass, [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
     const int with_exec = arena && lit_bytes && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
     uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
     std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order, scan_wave;
@@ -146,7 +146,7 @@ int main(int argc, char** argv) {
         if (dict_res[0]) return 3;
         a.dict_state = dict_state; a.dict = dict_exact + dict_res[1]; a.dict_len = dict_raw.size() - dict_res[1];
     }
-    /* passes: [block scan (count, place), chain pre-pass, [literals pass (EMU_LIT),] [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel */
+    /* launches: [block scan (count, place), [cz_huf_kernel / cz_huf1_kernel, cz_tile_kernel (EMU_LIT),] chain pre-pass, [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel */
     if (with_exec) { a.fallback_list = fallback_list.data(); a.fallback_count = &fallback_count; }   /* as the host library: set before cz_huf_kernel, which may list frames too */
     /* EMU_HUF1=1: cz_huf1_kernel (the one-wave form that runs beside the chain kernel on the device) never sees the chain kernel
        "done" and takes every literals section; default: it sees it done at once and cz_huf_kernel takes them all */

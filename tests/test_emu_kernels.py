@@ -72,7 +72,7 @@ def test_emu_chain_prepass():
     """cz_chain_kernel + the record-driven path of cz_decode_frames_kernel under ASan/UBSan: corpus frames
     (multi-block, Repeat/RLE/predefined tables), synthetic frames, malformed frames (the pre-pass must
     leave them to the decoder, which reports the reference's status), an arena that is far too small, and the
-    literals pass (a literals-only launch of the decode kernel) feeding the decode kernel, with room and without."""
+    huff0 / tile kernels feeding the decode kernel, with room in the literal arena and without."""
     frames, caps = [], []
     for name, z, orig in corpus_pairs(max_orig=1000):
         frames.append(z)

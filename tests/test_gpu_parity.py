@@ -277,7 +277,7 @@ def test_chain_prepass_matches_oracle(cz, arena_mb, lit_mb):
     from cairo_zstd_amd import synth
     c = cz.Context(0)
     c.set_chain_arena(int(arena_mb * (1 << 20)), min_sequences=0)      # pre-pass every frame, however short its chains
-    c.set_literal_arena(int(lit_mb * (1 << 20)))                       # literals pass next to it (0 = off; 0.05 MB: most frames do not fit)
+    c.set_literal_arena(int(lit_mb * (1 << 20)))                       # huff0 / tile kernels and the execute kernel with it (0 = off; 0.05 MB: most frames do not fit)
     try:
         frames, caps = [], []
         for kind, n in (("full_4a", 12), ("full_4b", 4), ("mix", 800), ("huf_literals", 4), ("raw_rle", 4)):
