@@ -890,3 +890,73 @@ def test_frame_whose_sections_go_back_twice_is_listed_once(cz):
         assert all(int(r["status"]) == 0 and out == ref and int(r["blocks_decoded"]) == 2 for r, out in got)
     finally:
         c.close()
+
+
+def _libzstd():
+    import ctypes
+    try:
+        L = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    L.ZSTD_compress.restype = ctypes.c_size_t
+    L.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    L.ZSTD_isError.restype = ctypes.c_uint
+    L.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    L.ZSTD_compressBound.restype = ctypes.c_size_t
+    L.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    return L
+
+
+@pytest.mark.parametrize("pipeline", ["single_kernel", "prepass"])
+def test_frames_made_by_libzstd_at_run_time(cz, pipeline):
+    """Real encoder output, made on the spot by the box's libzstd (skipped without one): text, structured records, noise with
+    long repeats and runs, 1 KB .. 1.5 MB (up to a dozen blocks: Repeat / Treeless modes, predefined and RLE tables, long
+    matches, repeat offsets), levels 1 / 3 / 9 / 19 — the originals must come back byte for byte, and the oracle must agree."""
+    import ctypes
+    L = _libzstd()
+    if L is None:
+        pytest.skip("no libzstd.so.1 on this box")
+    rng = np.random.default_rng(2024)
+    text = b"".join(orig for name, z, orig in corpus_pairs(max_orig=20000))
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(300)]
+    datas = []
+    for size in (1000, 20000, 131072, 400000, 1500000):
+        datas.append((text * (size // len(text) + 1))[:size])
+        datas.append(b" ".join(words[int(i)] for i in rng.integers(0, len(words), size // 5))[:size])
+        rec = bytearray()
+        while len(rec) < size:
+            rec += b"id=%08d;val=%05d;flag=%d\n" % (len(rec), int(rng.integers(0, 99999)), int(rng.integers(0, 2)))
+        datas.append(bytes(rec[:size]))
+        noise = bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+        pos = 0
+        while pos + 3000 < size:                                         # long repeats at random distances, runs of one byte
+            ln, dist = int(rng.integers(4, 2500)), int(rng.integers(1, max(2, min(pos, 200000))))
+            if pos > dist:
+                for k in range(ln):
+                    noise[pos + k] = noise[pos + k - dist]
+            pos += ln + int(rng.integers(0, 700))
+            if rng.integers(0, 5) == 0:
+                run = int(rng.integers(10, 900)); noise[pos:pos + run] = bytes([int(rng.integers(0, 256))]) * run; pos += run
+        datas.append(bytes(noise[:size]))
+    frames, origs = [], []
+    for i, d in enumerate(datas):
+        for lvl in ((1, 3, 9, 19) if len(d) <= 400000 else (1, 9)):
+            cap = L.ZSTD_compressBound(len(d))
+            dst = ctypes.create_string_buffer(cap)
+            n = L.ZSTD_compress(dst, cap, d, len(d), lvl)
+            assert not L.ZSTD_isError(n)
+            frames.append(dst.raw[:n]); origs.append(d)
+    caps = [len(o) for o in origs]
+    c = cz.Context(0)
+    try:
+        if pipeline == "prepass":
+            c.set_chain_arena(sum(len(f) for f in frames) * 8 + (64 << 20), min_sequences=0)
+            c.set_literal_arena(sum(caps) + (16 << 20))
+        got = cz.decode_batch_host(frames, caps, c)
+    finally:
+        c.close()
+    bad = [(i, cz.status.name(r["status"]), len(out), len(o)) for i, ((r, out), o) in enumerate(zip(got, origs)) if int(r["status"]) != 0 or out != o]
+    assert not bad, bad[:10]
+    for fr, o in list(zip(frames, origs))[::7]:                          # and the oracle sees the same
+        st, ref, info = oracle.decode_frame(fr, cap=len(o))
+        assert st == 0 and ref == o
