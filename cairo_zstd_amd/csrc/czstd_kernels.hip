@@ -1177,6 +1177,14 @@ __device__ static inline CzPlan cz_chunk_plan(const CzExecCtx& x, uint64_t produ
     else if (__ballot(dictm)) p.err = -1;                               /* not an error: cz_chunk_copy takes the dictionary path */
     return p;
 }
+/* up to 16 bytes into the chunk buffer (LDS) at any alignment */
+__device__ static inline __attribute__((always_inline)) void cz_lds_store_upto16(uint8_t* d, uint4 v, uint32_t m) {
+    if (m >= 16u) { __builtin_memcpy(d, &v, 16); return; }
+    if (m & 8u) { const uint64_t t = ((uint64_t)v.y << 32) | v.x; __builtin_memcpy(d, &t, 8); d += 8; v.x = v.z; v.y = v.w; }
+    if (m & 4u) { __builtin_memcpy(d, &v.x, 4); d += 4; v.x = v.y; }
+    if (m & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(d, &h, 2); d += 2; v.x >>= 16; }
+    if (m & 1u) *d = (uint8_t)v.x;
+}
 /* First NL literal bytes and first NMB match bytes (plain far matches) of every lane into the chunk
  * buffer: all global loads first, then byte writes whose address is the lane's dump byte when the
  * lane has fewer bytes (an address select is cheaper than masking the lane off). */
@@ -1240,9 +1248,26 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         else if (!big) cz_copy_group0<4, 8>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
         else {
             cz_copy_group0<8, 16>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
-            /* the rest of long runs (rare in a chunk this small) */
-            for (uint32_t k = 8; k < ll; k++) ob[orel + k] = lit.rle ? lit.byte : ls[k];
-            if (far_plain) for (uint32_t k = 16; k < ml; k++) ob[drel + k] = ms[k];
+            /* the rest of longer runs (up to CZ_OBUF_MAXLEN), sixteen bytes per step and every lane's load of a step issued before
+               the wait: a byte loop here pays one memory round trip per byte of the longest run, which on real encoder output
+               (text: runs of 10..40 bytes in most chunks) was most of this path's time.  A 16-byte load may read beyond its run
+               where that stays inside the literal buffer / the frame's output buffer; only the run's bytes are written. */
+            for (uint32_t k = 8; __ballot(k < ll); k += 16) {
+                if (k < ll) {
+                    const uint32_t m = ll - k < 16u ? ll - k : 16u;
+                    uint4 v;
+                    if (lit.rle) { const uint32_t w = 0x01010101u * lit.byte; v = uint4{w, w, w, w}; }
+                    else v = cz_load_upto16((cz_gcptr)ls + k, m, (uint64_t)lit_start + k + 16u <= lit.len);
+                    (cz_lds_store_upto16)(ob + orel + k, v, m);
+                }
+            }
+            for (uint32_t k = 16; __ballot(far_plain && k < ml); k += 16) {
+                if (far_plain && k < ml) {
+                    const uint32_t m = ml - k < 16u ? ml - k : 16u;
+                    const uint4 v = cz_load_upto16((cz_gcptr)ms + k, m, dst - off + k + 16u <= x.cap);
+                    (cz_lds_store_upto16)(ob + drel + k, v, m);
+                }
+            }
         }
         if (__ballot(far_period)) {                                     /* period-off pattern (decode_buffer.cairo:101-120) */
             uint8_t mt[8]; uint32_t idx = 0;
