@@ -129,7 +129,9 @@ class Context:
 
     def decode_batch_device(self, in_base: int, in_off: int, in_len: int, n: int, out_base: int, out_off: int,
                             out_cap: int, results: int):
-        """All arguments are raw DEVICE pointers (tensor.data_ptr()).  Asynchronous."""
+        """All arguments are raw DEVICE pointers (tensor.data_ptr()).  Asynchronous on the context's stream — which is a stream of
+        the context's own when it was created with handle 0 (torch's default stream): synchronise between torch's writes to these
+        buffers and this call, and before reading the results."""
         st = lib().cz_decode_batch_device(self._h, in_base, in_off, in_len, n, out_base, out_off, out_cap, results)
         if st:
             raise CzError(st, f"hip error {lib().cz_context_last_hip_error(self._h)}")

@@ -61,7 +61,11 @@ typedef struct cz_context cz_context;
 
 int  cz_abi_version(void);
 /* Creates a decoder context on HIP device `device` (ordinal).  `stream` may be NULL (the
- * context then owns a stream) or a hipStream_t cast to void*. */
+ * context then owns a NON-BLOCKING stream) or a hipStream_t cast to void*.  NULL is also the handle of the legacy default
+ * stream: a caller whose other work runs there (PyTorch's torch.cuda.current_stream().cuda_stream is 0 unless a stream
+ * context is active) gets a context that is NOT ordered with that work — it must synchronise (or record / wait on events)
+ * between filling the buffers a batch call reads or writes and the call, and again before it reads the results, or pass a
+ * stream of its own making. */
 int  cz_context_create(cz_context** out, int device, void* stream);
 void cz_context_destroy(cz_context* ctx);
 int  cz_context_synchronize(cz_context* ctx);
