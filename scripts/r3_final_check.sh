@@ -9,5 +9,5 @@ python3 - <<'PY'
 import json
 d = json.loads(open("gpurun_out/r3/bench_default.json").read().strip().splitlines()[-1])
 print({k: d[k] for k in ("value", "ms_per_step", "bit_exact", "kernel_source_hash")}, d["roofline"]["frac"], d["roofline"]["traffic"])
-for o in d.get("other_workloads", []): print("  ", o["workload"] if "workload" in o else o.get("name"), o.get("ms_per_step"), o.get("roofline_frac"), o.get("bit_exact"))
+for k, o in (d.get("other_workloads") or {}).items(): print("  ", k, o.get("kernel_ms_mean"), o.get("roofline_frac"), o.get("bit_exact"))
 PY
