@@ -8,7 +8,10 @@ frames that already sits in HBM.  The call launches
     cz_scan_kernel x2  ->  cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel  (three streams: FSE chains, Huffman literals
                                                                                   and Raw / RLE runs, unit of work = a block)
                        ->  cz_huf_kernel (the literals cz_huf1_kernel did not get to beside the chain kernel)
-                       ->  cz_execute_frames_kernel (frames the pre-pass prepared)  ->  cz_decode_frames_kernel (the rest)
+                       ->  cz_execute_frames_kernel || cz_wexec_kernel (the frames the pre-pass prepared: a wave per frame with
+                           match sources from HBM, side by side with a workgroup per frame with the block in an LDS window — on
+                           batches whose far offsets outweigh the near ones, decided on the device)
+                       ->  cz_decode_frames_kernel (the rest)
 (--no-chain-prepass: the one persistent-grid cz_decode_frames_kernel of round 1).
 Default workload = BASELINE config 4a: 10 000 single-block frames per GPU, each a full compressed
 128 KiB block (Huffman 4-stream literals + 32 768 FSE-coded sequences + match copy).
@@ -25,7 +28,8 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task description)
                 the library, on the streams the kernels run on), against the 8 TB/s HBM peak;
                 chain_latency_floor = how long cz_chain_kernel's slots need for this batch at the
                 measured minimum step latency (a property of its slot count, not of zstd);
-                traffic = PMC bytes from profiles/r3 when that file was measured on
+                frac_dominant_kernel = the same bytes / the longest stage of the step (chain kernel or execute stage);
+                traffic = PMC bytes from profiles/r4 when that file was measured on
                 these very kernel sources (kernel_source_hash), else null
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on all host cores over the whole
                 batch, on one thread over a bounded sample, and libzstd on one thread and on all
@@ -85,7 +89,7 @@ def _kernel_source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cairo_zstd_amd", "csrc")
-    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_pre.hip", "czstd_host.hip", "czstd_types.h"):
+    for name in ("czstd_kernels.hip", "czstd_chain.hip", "czstd_pre.hip", "czstd_wexec.hip", "czstd_host.hip", "czstd_types.h"):
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
@@ -107,6 +111,49 @@ def _libzstd():
     return None
 
 
+def _real_frames(n: int, level: int = 3, distinct: int = 384):
+    """n frames of 128 KiB as a real encoder leaves them: text-like, log-like and mixed binary / text data compressed by the box's
+    libzstd at `level`.  `distinct` different inputs are made (Python builds them: the bound), the batch repeats them.
+    Returns (frames, originals) or None without a libzstd."""
+    import ctypes
+    try:
+        Z = ctypes.CDLL("libzstd.so.1")
+    except OSError:
+        return None
+    Z.ZSTD_compress.restype = ctypes.c_size_t
+    Z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rng = np.random.default_rng(7)
+    SZ = 131072
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(3000)]
+    blob = bytes(rng.integers(0, 256, 4096, dtype=np.uint8))
+    dst = ctypes.create_string_buffer(2 * SZ)
+    frames, origs = [], []
+    for i in range(min(n, distinct)):
+        kind = i % 3
+        if kind == 0:                                                   # running text: words by a skewed distribution
+            idx = np.minimum(rng.integers(0, len(words), SZ // 4), rng.integers(0, len(words), SZ // 4))
+            d = b" ".join(words[int(j)] for j in idx)[:SZ]
+        elif kind == 1:                                                 # log-like records
+            rec = bytearray()
+            t = int(rng.integers(0, 10 ** 9))
+            while len(rec) < SZ:
+                t += int(rng.integers(1, 50))
+                rec += b"%010d host%02d GET /api/v1/item/%06d status=%d bytes=%d\n" % (t, int(rng.integers(0, 40)), int(rng.integers(0, 50000)), (200, 200, 200, 404, 500)[int(rng.integers(0, 5))], int(rng.integers(100, 90000)))
+            d = bytes(rec[:SZ])
+        else:                                                           # records of text fields and binary fields
+            rec = bytearray()
+            while len(rec) < SZ:
+                o = int(rng.integers(0, 4000))
+                rec += b"{\"id\": %d, \"name\": \"%s\", \"blob\": \"" % (int(rng.integers(0, 10 ** 6)), words[int(rng.integers(0, len(words)))]) + blob[o:o + int(rng.integers(8, 64))].hex().encode() + b"\"}\n"
+            d = bytes(rec[:SZ])
+        d = d.ljust(SZ, b".")
+        m = Z.ZSTD_compress(dst, 2 * SZ, d, len(d), level)
+        frames.append(dst.raw[:m])
+        origs.append(d)
+    k = len(frames)
+    return [frames[i % k] for i in range(n)], [origs[i % k] for i in range(n)], k
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +170,8 @@ def main():
     ap.add_argument("--no-chain-prepass", action="store_true", help="diagnostic: everything inside cz_decode_frames_kernel (single launch, as in round 1)")
     ap.add_argument("--no-literals-pass", action="store_true", help="diagnostic: no cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel; literals and Raw / RLE blocks inside the decode kernel")
     ap.add_argument("--no-exec-kernel", dest="exec_kernel", action="store_false", help="diagnostic: pre-passed frames on cz_decode_frames_kernel too, not on cz_execute_frames_kernel")
+    ap.add_argument("--no-wexec-kernel", dest="wexec_kernel", action="store_false", help="diagnostic: cz_execute_frames_kernel alone, never side by side with cz_wexec_kernel")
+    ap.add_argument("--real-frames", type=int, default=16000, help="frames of the real_libzstd_l3 entry of other_workloads (made by the box's libzstd at run time; 0: skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real runs); gloo only to rehearse the N>1 code path on a box with fewer GPUs than ranks")
     args = ap.parse_args()
@@ -191,7 +240,9 @@ def main():
     t_ocap = torch.from_numpy(out_cap.astype(np.int64)).to(dev)
     t_out = torch.empty(out_total, dtype=torch.uint8, device=dev)
     t_res = torch.zeros(F * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    # the context gets a stream of torch's making (handle 0 would mean a stream of the context's own, not ordered with torch's work):
+    # everything this script does between launches synchronises the device, and the gather leg below waits for this stream
+    stream = torch.cuda.Stream(device=dev)
     ctx = cz.Context(local_dev, stream.cuda_stream)
     # the block-parallel pre-pass (cz_scan_kernel + cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel + cz_huf_kernel) for every workload
     chain_prepass = not args.no_chain_prepass
@@ -200,7 +251,9 @@ def main():
     if chain_prepass:
         ctx.set_chain_arena(arena_bytes)
         ctx.set_exec_kernel(args.exec_kernel)
+        ctx.set_wexec_kernel(args.wexec_kernel)
         ctx.set_literal_arena(0 if args.no_literals_pass else lit_bytes)
+    torch.cuda.synchronize()
 
     def decode():
         ctx.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_out.data_ptr(),
@@ -225,14 +278,16 @@ def main():
     # Per-launch kernel durations for the roofline: K more launches of the same step, each read
     # from the hipEvent pair the library records around the kernel on the stream it runs on
     # (reading a pair needs a sync, which must stay out of the timed region above).
-    kernel_ms, chain_ms, exec_ms, tail_ms = [], [], [], []
+    kernel_ms, chain_ms, exec_ms, tail_ms, wexec_ms = [], [], [], [], []
     for _ in range(args.steps):
         decode()
         kernel_ms.append(ctx.last_kernel_ms())
         chain_ms.append(ctx.last_chain_ms())                              # scans + cz_chain_kernel
-        exec_ms.append(ctx.last_exec_ms())                                # cz_execute_frames_kernel
+        exec_ms.append(ctx.last_exec_ms())                                # the execute stage: cz_execute_frames_kernel and, side by side with it, cz_wexec_kernel
+        wexec_ms.append(ctx.last_wexec_ms())                              # how long cz_wexec_kernel ran of that
         tail_ms.append(ctx.last_literals_tail_ms())                       # how long cz_huf_kernel / cz_huf1_kernel / cz_tile_kernel ran on after cz_chain_kernel
     torch.cuda.synchronize()
+    wexec_counts = ctx.last_wexec_counts()
 
     # ---- decode + gather (config 5's exchange step), timed separately
     gather_leg = None
@@ -242,6 +297,7 @@ def main():
 
         def decode_and_gather():
             decode()
+            torch.cuda.current_stream().wait_stream(stream)              # the gather runs on torch's (and RCCL's) streams: behind this step's decode
             czdist.gather_to_root(t_out if args.dist_backend == "nccl" else t_out.cpu(), gather_bufs, 0)
 
         g_elapsed = czdist.max_over_ranks(timed(decode_and_gather), cdev)
@@ -354,6 +410,44 @@ def main():
                           "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "all_frames_ok": okw, "bit_exact": exact, "frames_verified_vs_oracle": nver}
             del ti, td, to, tr
+        # real encoder output (not a BASELINE config: what a user of the library decodes): frames made here by the box's libzstd,
+        # every decoded frame compared with its original, the distinct frames also with the oracle
+        real = _real_frames(args.real_frames) if args.real_frames > 0 and not args.no_chain_prepass else None
+        if real is not None:
+            rf, ro, distinct = real
+            nf = len(rf)
+            lens = np.array([len(f) for f in rf], dtype=np.int64)
+            roff = np.zeros(nf, dtype=np.int64); roff[1:] = np.cumsum(lens[:-1])
+            rbase = np.frombuffer(b"".join(rf) + b"\0" * 64, dtype=np.uint8)
+            SZ = len(ro[0])
+            o_off = np.arange(nf, dtype=np.int64) * SZ
+            ctx.set_chain_arena(int(lens.sum()) * 8 + (64 << 20))
+            ctx.set_literal_arena(nf * SZ + (16 << 20) if not args.no_literals_pass else 0)
+            ti = torch.from_numpy(rbase.copy()).to(dev)
+            td = [torch.from_numpy(x).to(dev) for x in (roff, lens, o_off, np.full(nf, SZ, dtype=np.int64))]
+            to = torch.empty(nf * SZ, dtype=torch.uint8, device=dev)
+            tr = torch.zeros(nf * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            ms, cms, ems = [], [], []
+            for it in range(4):
+                if it == 3:
+                    to.fill_(0xA5); tr.zero_(); torch.cuda.synchronize()
+                ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, to.data_ptr(), td[2].data_ptr(), td[3].data_ptr(), tr.data_ptr())
+                ms.append(ctx.last_kernel_ms()); cms.append(ctx.last_chain_ms()); ems.append(ctx.last_exec_ms())
+            torch.cuda.synchronize()
+            r2 = tr.cpu().numpy().view(cz.RESULT_DTYPE)
+            oh = to.cpu().numpy()
+            okw = bool((r2["status"] == 0).all() and (r2["bytes_produced"] == SZ).all())
+            exact = okw and all(oh[i * SZ:(i + 1) * SZ].tobytes() == ro[i] for i in range(nf))
+            exact = exact and all(oracle.decode_frame(rf[i], cap=SZ + 16)[1] == ro[i] for i in range(distinct))
+            ab = int(lens.sum()) + nf * SZ
+            k = float(np.mean(ms[1:3]))
+            others["real_libzstd_l3"] = {"frames": nf, "distinct_frames": distinct, "what": "128 KiB frames of text-like, log-like and record-like data compressed by the box's libzstd at level 3 (made at run time)",
+                                         "compression_ratio": nf * SZ / float(lens.sum()), "decompressed_MBps": nf * SZ / (k * 1e-3) / 1e6, "kernel_ms": k,
+                                         "chain_kernel_ms": float(np.mean(cms[1:3])), "exec_stage_ms": float(np.mean(ems[1:3])),
+                                         "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "all_frames_ok": okw, "bit_exact": bool(exact), "frames_verified_vs_originals": nf if exact else 0}
+            del ti, td, to, tr, oh
         ctx.set_chain_arena(arena_bytes if chain_prepass else 0)
         ctx.set_literal_arena(lit_bytes if chain_prepass and not args.no_literals_pass else 0)
 
@@ -393,7 +487,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         lit_pass = chain_prepass and not args.no_literals_pass
         launches = (("cz_scan_kernel x2 + (cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel) + cz_huf_kernel + " if lit_pass else "cz_scan_kernel x2 + cz_chain_kernel + ")
-                    + ("cz_execute_frames_kernel + " if args.exec_kernel and lit_pass else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
+                    + (("(cz_execute_frames_kernel || cz_wexec_kernel) + " if args.wexec_kernel and wexec_counts[1] else "cz_execute_frames_kernel + ") if args.exec_kernel and lit_pass else "") + "cz_decode_frames_kernel") if chain_prepass else "cz_decode_frames_kernel"
         line = {
             "metric": "decompressed MB/s (whole node), 128 KiB-block batch",
             "value": regen_all * args.steps / elapsed / 1e6,
@@ -407,7 +501,7 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"
                                       + (", dealt by algorithmic bytes (one untimed all_to_all of compressed bytes)" if balanced else ""),
                        "launches_per_step": launches},
-            "kernel_source_hash": _kernel_source_hash(), "chain_prepass": bool(chain_prepass), "exec_kernel": bool(args.exec_kernel),
+            "kernel_source_hash": _kernel_source_hash(), "chain_prepass": bool(chain_prepass), "exec_kernel": bool(args.exec_kernel), "wexec_kernel": bool(args.wexec_kernel),
             "literals_pass": bool(lit_pass),
             "bit_exact": bool(ok_all), "frames_verified_vs_oracle_rank0": verified,
             "verification": "last launch decoded into a 0xA5-poisoned buffer; every frame compared with the CPU oracle by XXH64" if not args.no_verify_all else "16-frame sample",
@@ -419,6 +513,9 @@ def main():
                          "kernel_ms_all": [round(float(x), 4) for x in kernel_ms],
                          "chain_kernel_ms_mean": float(np.mean(chain_ms)), "prepass_tail_ms_mean": float(np.mean(tail_ms)),
                          "exec_kernel_ms_mean": float(np.mean(exec_ms)),
+                         "exec_stage": "cz_execute_frames_kernel (a wave per frame)" + (f" side by side with cz_wexec_kernel (a workgroup per frame; it ran {float(np.mean(wexec_ms)):.3f} ms of the stage and finished {wexec_counts[1]} of the {F} frames)" if wexec_counts[1] else ""),
+                         "frac_dominant_kernel": alg_bytes / (max(float(np.mean(chain_ms)), float(np.mean(exec_ms)), 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "dominant_kernel": "cz_chain_kernel" if float(np.mean(chain_ms)) >= float(np.mean(exec_ms)) else "execute stage",
                          "decode_kernel_ms_mean": k_ms - float(np.mean(chain_ms)) - float(np.mean(tail_ms)) - float(np.mean(exec_ms)),
                          "slowest_rank_kernel_ms_mean": k_ms_all,
                          **ctx.launch_info()},
@@ -437,14 +534,14 @@ def main():
                                                        "source": "profiles/r2/microbench_chain_step.txt (variant 6: the dependent table chase alone)"}
         # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
         # this same command and committed under profiles/ together with the hash of the kernel sources it was made on
-        pmc = os.path.join(ROOT, "profiles", "r3", f"pmc_hbm_traffic_{args.workload}.json")
+        pmc = os.path.join(ROOT, "profiles", "r4", f"pmc_hbm_traffic_{args.workload}.json")
         if os.path.exists(pmc) and world == 1 and F == 10000:
             t = json.load(open(pmc))
-            if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel):
+            if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel) and bool(t.get("wexec_kernel", True)) == bool(args.wexec_kernel):
                 line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
-                line["roofline"]["traffic_source"] = f"profiles/r3/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
+                line["roofline"]["traffic_source"] = f"profiles/r4/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
             else:
-                line["roofline"]["traffic_source"] = "profiles/r3 PMC file is from other kernel sources or launch options: not quoted"
+                line["roofline"]["traffic_source"] = "profiles/r4 PMC file is from other kernel sources or launch options: not quoted"
         if copy_ceiling is not None:
             line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling
@@ -491,12 +588,15 @@ def main():
                 cpu_leg["libzstd_single_thread"] = {"value": zbytes / zs / 1e6 if zs else None, "unit": "MB/s", "cores": 1, "all_frames_decoded": bool(zok),
                                                     "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} on the first {zdone} frames, {zs:.2f} s"}
                 # all cores: the same libzstd on a pthread pool inside the oracle library (a Python thread per core spends its time on the GIL)
-                t1 = time.perf_counter()
-                good = oracle.libzstd_batch(batch.base, batch.off, batch.length, out_off, out_cap, out_total, batch.regen, nthreads=threads)
-                zall = time.perf_counter() - t1
+                zalls = []
+                for _ in range(2):                                      # the first pass starts the threads and touches the output pages: the second one is quoted
+                    t1 = time.perf_counter()
+                    good = oracle.libzstd_batch(batch.base, batch.off, batch.length, out_off, out_cap, out_total, batch.regen, nthreads=threads)
+                    zalls.append(time.perf_counter() - t1)
+                zall = zalls[-1]
                 if good >= 0:
                     cpu_leg["libzstd_all_cores"] = {"value": regen_bytes / zall / 1e6, "unit": "MB/s", "cores": threads, "all_frames_decoded": bool(good == F),
-                                                    "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} over the whole batch ({F} frames) on {threads} pthreads, one frame per task, {zall:.2f} s wall"}
+                                                    "sample": f"ZSTD_decompress of libzstd {Z.ZSTD_versionNumber()} over the whole batch ({F} frames) on {threads} pthreads, one frame per task: second of two passes, {zall:.2f} s wall (first: {zalls[0]:.2f} s)"}
             line["cpu_baseline"] = cpu_leg
         print(json.dumps(line), flush=True)
     ctx.close()

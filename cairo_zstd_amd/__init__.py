@@ -112,6 +112,29 @@ class Context:
         other frame, on cz_decode_frames_kernel."""
         lib().cz_context_set_exec_kernel(self._h, 1 if on else 0)
 
+    def set_wexec_kernel(self, on: bool = True, cus: int = 0, leave_per_cu: int = 0, force: bool = False):
+        """cz_wexec_kernel (a workgroup per frame, the block in hand in an LDS window) side by side with cz_execute_frames_kernel on
+        batches whose far offsets outweigh the near ones (decided on the device; default on).  cus / leave_per_cu / force: the A/B
+        knobs of cz_context_set_wexec_tuning (force: side by side whatever the offsets look like)."""
+        lib().cz_context_set_wexec_kernel(self._h, 1 if on else 0)
+        st = lib().cz_context_set_wexec_tuning(self._h, int(cus), int(leave_per_cu), 1 if force else 0)
+        if st:
+            raise CzError(st, "cz_context_set_wexec_tuning")
+
+    def last_wexec_counts(self):
+        """(frames listed for cz_wexec_kernel, frames it finished, frames it handed on) in the last launch."""
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        lib().cz_context_last_wexec_counts(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
+    def last_wexec_ms(self) -> float:
+        """Milliseconds of the last launch spent in cz_wexec_kernel (0 when it did not run)."""
+        ms = C.c_float(0)
+        st = lib().cz_context_last_wexec_ms(self._h, C.byref(ms))
+        if st:
+            raise CzError(st, "cz_context_last_wexec_ms")
+        return float(ms.value)
+
     def last_exec_ms(self) -> float:
         """Milliseconds of the last launch spent in cz_execute_frames_kernel (0 when it did not run)."""
         ms = C.c_float(0)

@@ -33,7 +33,7 @@ class BlockHeader(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the library in-tree with hipcc for gfx950 (csrc/Makefile)."""
-    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_types.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("czstd_host.hip", "czstd_kernels.hip", "czstd_chain.hip", "czstd_pre.hip", "czstd_wexec.hip", "czstd_types.h")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("cairo_zstd_amd.h", "cairo_zstd_amd_status.h")]
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -83,6 +83,14 @@ def lib() -> C.CDLL:
     L.cz_context_last_exec_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_set_exec_kernel.restype = C.c_int
     L.cz_context_set_exec_kernel.argtypes = [vp, C.c_int]
+    L.cz_context_set_wexec_kernel.restype = C.c_int
+    L.cz_context_set_wexec_kernel.argtypes = [vp, C.c_int]
+    L.cz_context_set_wexec_tuning.restype = C.c_int
+    L.cz_context_set_wexec_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.cz_context_last_wexec_counts.restype = C.c_int
+    L.cz_context_last_wexec_counts.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.cz_context_last_wexec_ms.restype = C.c_int
+    L.cz_context_last_wexec_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_last_prepass_counts.restype = C.c_int
     L.cz_context_last_prepass_counts.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(sz)]
     L.cz_context_last_literals_tail_ms.restype = C.c_int

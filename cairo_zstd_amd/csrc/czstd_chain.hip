@@ -739,7 +739,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                 }
             }
         }
-        if (q.lit) {
+        if (with_lits && q.lit) {
             uint32_t bb = 0; for (int c = 0; c < 20; c++) if ((uint32_t)c == lcls) bb = lbase[c];
             const uint32_t idx = bb + lticket;
             if (idx >= a.lit_seg_capacity) placed = 0;
@@ -759,11 +759,12 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                 a.lit_segs[idx] = d;
             }
         }
-        if (q.copy) {
+        if (with_lits && q.copy) {
             if (cticket >= a.copy_seg_capacity) placed = 0;
             else { cz_copy_seg d; d.src = ibase + q.copy_src; d.dst = obase + kout_here; d.len = placed ? q.copy_len : 0u; d.fill = q.copy_fill; a.copy_segs[cticket] = d; }
         }
     }
+    int wx = 0;
     if (valid) {
         const int good = placed && w.ok;
         a.frame_first[f] = good ? first_hdr : 0;
@@ -781,7 +782,17 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                 r.detail[0] = pre_blocks; r.detail[1] = pos; r.calculated_checksum = 0; r.reserved = 0;
                 a.results[f] = r;
             }
-            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre;
+            wx = good && !(pre & CZ_PRE_DONE) && first_hdr != 0 && units >= CZ_WX_MIN_UNITS && ocap < 0x80000000ull && !(a.verify_checksum && w.has_checksum) && a.wx_list != nullptr;
+            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre | (wx ? CZ_PRE_WXLIST : 0u);
+        }
+    }
+    if (a.wx_list) {                                                    /* frames for cz_wexec_kernel: everything pre-passed, output fits its LDS window, enough sequences for a workgroup */
+        const unsigned long long wm = __ballot(wx);
+        if (wm) {
+            uint32_t base = 0;
+            if (LANE == __ffsll((long long)wm) - 1) base = atomicAdd(&a.scan_ctl[206], (uint32_t)__popcll(wm));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)wm) - 1);
+            if (wx) a.wx_list[base + (uint32_t)__popcll(wm & ((1ull << LANE) - 1ull))] = f;
         }
     }
     if (with_lits) {                                                    /* frames the decode kernels still have to walk */
@@ -923,6 +934,20 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 if (go) { uint32_t dummy; bad = czc_parse_tables(dblk, dbsize, dsbody, dmodes, 1u << t, sl.stage, 256u, sl.probs, &binfo, rles, &dummy); }
             }
             if (got && bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
+            /* What the batch's offsets look like, for the execute stage (cz_wx_side_by_side): sequences (in units of 64) weighted by
+               the share of their block's offset codes that are near (2..13: offsets below 16 KiB, which a frame's waves in
+               cz_wexec_kernel would have to wait on each other for) and far (14 and up). */
+            if (got && a.wx_list) {
+                const uint32_t info = (binfo >> 10) & 0x3FFu, lg = info >> 6, np = (info & 63u) + 1u, n6 = (o_nseq + 63u) >> 6;
+                uint32_t nearc = 0, farc = 0;
+                if (rles[1] >= 0) { nearc = rles[1] >= 2 && rles[1] <= 13 ? 256u : 0u; farc = rles[1] >= 14 ? 256u : 0u; }
+                else if (lg) {
+                    for (uint32_t sy = 2; sy < np; sy++) { const int32_t pr = sl.probs[1][sy]; const uint32_t cnt = pr > 0 ? (uint32_t)pr : (pr < 0 ? 1u : 0u); if (sy <= 13u) nearc += cnt; else farc += cnt; }
+                    nearc = (nearc << 8) >> lg; farc = (farc << 8) >> lg;
+                }
+                if (nearc) atomicAdd(a.chain_top + 5, (unsigned long long)nearc * n6);
+                if (farc) atomicAdd(a.chain_top + 6, (unsigned long long)farc * n6);
+            }
             CZC_PROF_ACC(10);
             /* build the tables of the refilled slots, each by the whole wave, slot after slot: LL and ML first (the slot's OF
                table, always rewritten for a new block, is their scratch), then OF (scratch: the description bytes, now read) */

@@ -29,6 +29,7 @@
 #include "czstd_kernels.hip"   /* single translation unit: kernels + host side */
 #include "czstd_chain.hip"
 #include "czstd_pre.hip"
+#include "czstd_wexec.hip"
 /* the same kernel source once more, without its decoders: cz_execute_frames_kernel (czstd_kernels.hip, CZ_EXEC_ONLY) */
 #define CZ_EXEC_ONLY 1
 namespace czx {
@@ -54,6 +55,11 @@ struct cz_context {
     uint8_t* lit_scratch = nullptr; int lit_slots = 0; uint32_t* work_counter = nullptr;
     const struct cz_dictionary* batch_dict = nullptr;                   /* cz_context_set_dictionary */
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
+    bool wexec_kernel = true;              /* of those, frames of at most 128 KiB with enough sequences run on cz_wexec_kernel first (a workgroup per frame, window in LDS) */
+    int wexec_cus = 0;                     /* CUs (= workgroups) cz_wexec_kernel runs on; 0: half of them */
+    uint32_t wexec_force = 0;              /* 0: the kernels decide from the batch's offset codes; 1: always side by side (A/B runs) */
+    int wexec_leave_per_cu = 7;           /* frames per workgroup of cz_wexec_kernel that cz_execute_frames_kernel leaves to it at the end of a batch */
+    bool wexec_ready = false; uint32_t* wx_list = nullptr; hipEvent_t ev_wx = nullptr; bool timed_wx = false;
     bool exec_kernel = true;               /* frames the pre-pass finished (chain records + literals) run on cz_execute_frames_kernel; 0: all on cz_decode_frames_kernel */
     int exec_grid = 0;
     uint32_t* fallback_list = nullptr;                                  /* n entries, allocated with frame_first */
@@ -157,6 +163,8 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->frame_order) (void)hipFree(c->frame_order);
     if (c->scan_wave) (void)hipFree(c->scan_wave);
     if (c->fallback_list) (void)hipFree(c->fallback_list);
+    if (c->wx_list) (void)hipFree(c->wx_list);
+    if (c->ev_wx) (void)hipEventDestroy(c->ev_wx);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
@@ -308,6 +316,42 @@ CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 
+/* Frames of at most 128 KiB with enough sequences run on cz_wexec_kernel (default, 1) or, like the other pre-passed frames, on cz_execute_frames_kernel (0). */
+CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->wexec_kernel = on != 0; return CZ_OK; }
+/* A/B knobs of the side-by-side execute stage: CUs cz_wexec_kernel runs on (0: half), frames per CU of it that cz_execute_frames_kernel
+   leaves to it at the end of a batch (0: default), force = 1: side by side whatever the batch's offsets look like. */
+CZ_EXPORT int cz_context_set_wexec_tuning(cz_context* c, int cus, int leave_per_cu, int force) {
+    if (!c || cus < 0 || leave_per_cu < 0) return CZ_E_INVALID_ARG;
+    c->wexec_cus = cus; if (leave_per_cu) c->wexec_leave_per_cu = leave_per_cu; c->wexec_force = force ? 1u : 0u;
+    return CZ_OK;
+}
+/* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it gave up. */
+CZ_EXPORT int cz_context_last_wexec_counts(cz_context* c, size_t* listed, size_t* finished, size_t* given_up) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (listed) *listed = 0;
+    if (finished) *finished = 0;
+    if (given_up) *given_up = 0;
+    if (!c->scan_ctl) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t h[4] = {0, 0, 0, 0};
+    CZ_HIP(c, hipMemcpy(h, c->scan_ctl + 206, sizeof h, hipMemcpyDeviceToHost));
+    if (listed) *listed = h[0];
+    if (given_up) *given_up = h[1];
+    if (finished) *finished = h[3];
+    return CZ_OK;
+}
+/* Part of the last launch spent in cz_wexec_kernel (0 when it did not run). */
+CZ_EXPORT int cz_context_last_wexec_ms(cz_context* c, float* ms) {
+    if (!c || !ms) return CZ_E_INVALID_ARG;
+    *ms = 0.0f;
+    if (!c->timed || !c->timed_wx) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->timed_lit ? c->ev_lit : c->ev_mid, c->ev_wx));
+    return CZ_OK;
+}
+
 /* Part of the last launch spent in cz_execute_frames_kernel (0 when it did not run). */
 CZ_EXPORT int cz_context_last_exec_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
@@ -354,8 +398,11 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (c->fallback_list) (void)hipFree(c->fallback_list);
             c->fallback_list = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->fallback_list, n * 4));
+            if (c->wx_list) (void)hipFree(c->wx_list);
+            c->wx_list = nullptr;
+            CZ_HIP(c, hipMalloc((void**)&c->wx_list, n * 4));
         }
-        CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 32, c->stream));
+        CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 64, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
         a.frame_first = c->frame_first; a.chain_counter = c->chain_counter; a.chain_min_nseq = c->chain_min_nseq;
         const bool lit_pass = c->lit_arena != nullptr;
@@ -373,6 +420,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             a.lit_segs = c->lit_segs; a.lit_seg_capacity = c->seg_capacity; a.copy_segs = c->copy_segs; a.copy_seg_capacity = c->seg_capacity; a.frame_pre = c->frame_pre;
         }
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
+        if (c->exec_kernel && lit_pass && !c->batch_dict && c->wexec_kernel) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
         a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
         CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
@@ -380,6 +428,13 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         const bool use_exec = c->exec_kernel && lit_pass && !c->batch_dict;
+        const bool use_wx = use_exec && c->wexec_kernel;
+        if (use_wx && !c->wexec_ready) {
+            CZ_HIP(c, hipFuncSetAttribute((const void*)cz_wexec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS_BYTES));
+            CZ_HIP(c, hipEventCreate(&c->ev_wx));
+            c->wexec_ready = true;
+        }
+        if (use_wx) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         /* the literal and copy kernels may start when the chain kernel does (not before: they would take the LDS the chain
            kernel's workgroups need and hold them up) */
@@ -431,20 +486,42 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             c->timed_lit = true;
         } else c->timed_lit = false;
         c->timed_chain = true;
-        c->timed_exec = false;
+        c->timed_exec = false; c->timed_wx = false;
         if (use_exec) {
-            /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of
-               its own); it lists every other frame for the launch below */
             int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
 #ifdef CZ_EXPERIMENT
             if (const char* e = getenv("CZ_EXEC_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < egrid) egrid = g; }
 #endif
-            hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
-            CZ_HIP(c, hipGetLastError());
+            a.wx_leave = 0;
+            if (use_wx) {
+                /* Two kernels execute the sequences side by side and share the frames (each claims a frame before it starts on it):
+                   cz_wexec_kernel — a workgroup of 16 waves per frame, the block in hand in an LDS window: bound by instruction
+                   issue — on `wexec_cus` CUs (a workgroup of it fills a CU), and cz_execute_frames_kernel — a wave per frame, match
+                   sources from HBM: bound by the rate of random reads, which does not need every CU — on the others.  The first is
+                   launched on this stream, the second on a stream of its own behind an event: so the first is dispatched first and
+                   gets its CUs.  (If it does not, it finds every frame claimed when it starts: nothing is lost but the overlap.) */
+                int wgrid = c->wexec_cus > 0 ? c->wexec_cus : c->num_cu / 2;
+                if (wgrid > c->num_cu) wgrid = c->num_cu;
+                a.wx_leave = (uint32_t)(wgrid * c->wexec_leave_per_cu); a.wx_force = c->wexec_force;
+                hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
+                CZ_HIP(c, hipGetLastError());
+                CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
+                c->timed_wx = true;
+                CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_lit, 0));
+                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a);
+                CZ_HIP(c, hipGetLastError());
+                CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
+                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            } else {
+                /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of its
+                   own); it lists every frame it cannot do for cz_decode_frames_kernel */
+                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
+                CZ_HIP(c, hipGetLastError());
+            }
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
             c->timed_exec = true;
         }
-    } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; }
+    } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; c->timed_wx = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_MAIN_DYN_LDS, c->stream, a);

@@ -51,6 +51,14 @@ typedef CZ_GLOBAL uint16_t* cz_gptr16;
 __device__ static inline uint32_t cz_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ static inline int32_t cz_unii(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_uni((uint32_t)(v >> 32)) << 32) | cz_uni((uint32_t)v); }
+/* Do cz_wexec_kernel and cz_execute_frames_kernel share this batch's frames?  Only when far offsets outweigh near ones (what
+   cz_chain_kernel summed from the blocks' offset-code tables): a workgroup per frame pays when its waves seldom wait for each
+   other's bytes; on near-offset data it is no faster than one wave and holds a whole CU. */
+#ifndef CZ_EXEC_ONLY
+__device__ static inline int cz_wx_side_by_side(const cz_batch_args& a) {
+    return a.wx_list != nullptr && (a.wx_force ? a.wx_force == 1u : a.chain_top[6] > a.chain_top[5]);
+}
+#endif
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
  * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
  * frame.  No stamp executes in the product build. */
@@ -2362,20 +2370,35 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_ex
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
 #endif
     if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
+    const uint32_t total = a.n;
+    const int wx_on = ::cz_wx_side_by_side(a);
     cz_init_llml();
     for (;;) {
         __syncthreads();
         if (LANE == 0) sh.frame_idx = atomicAdd(a.exec_counter, 1u);
         __syncthreads();
         const uint32_t fi = cz_uni(sh.frame_idx);
-        if (fi >= a.n) break;
+        if (fi >= total) break;
         const uint32_t f = a.frame_order ? cz_uni(a.frame_order[fi]) : fi;
         int err = CZX_FALLBACK;
         /* regular to its last block, everything listed, and cz_huf_kernel met nothing irregular; a frame whose chains
            cz_chain_kernel gave up on (first == 0 with sequences in it) comes back from cz_run_frame */
         const uint64_t first = cz_uni64(a.frame_first[f]), lfirst = cz_uni64(a.lit_first[f]);
         const uint32_t pre = cz_uni(a.frame_pre[f]);
-        if (((pre & CZ_PRE_DONE) && lfirst != 0) || pre == CZ_PRE_PUSHED) continue;   /* all of it done by the pre-pass kernels, result record written by the scan (or taken back and listed by cz_huf_kernel) */
+        if (((pre & CZ_PRE_DONE) && lfirst != 0) || pre == CZ_PRE_PUSHED || (pre & (CZ_PRE_WXDONE | CZ_PRE_CLAIMED))) continue;
+        if (wx_on && (pre & CZ_PRE_WXLIST)) {
+            /* cz_wexec_kernel, which runs beside this kernel, may take this frame: whoever claims it first does it.  The last
+               wx_leave listed frames are left to that kernel: a frame started here now would still be running on its one wave
+               long after the other kernel has run out of frames. */
+            __syncthreads();
+            if (LANE == 0) {
+                uint32_t got = CZ_PRE_CLAIMED;
+                if (a.scan_ctl[206] - *(volatile uint32_t*)&a.scan_ctl[208] > a.wx_leave) { got = atomicOr(&a.frame_pre[f], CZ_PRE_CLAIMED); if (!(got & CZ_PRE_CLAIMED)) atomicAdd(&a.scan_ctl[208], 1u); }
+                sh.frame_idx = got;
+            }
+            __syncthreads();
+            if (cz_uni(sh.frame_idx) & CZ_PRE_CLAIMED) continue;
+        }   /* all of it done by the pre-pass kernels, result record written by the scan (or taken back and listed by cz_huf_kernel) */
         if ((pre & CZ_PRE_REGULAR) && lfirst != 0) {
             CzFrameIO io;
             io.src = (cz_gcptr)(a.in_base + a.in_off[f]); io.src_len = a.in_len[f]; io.dst = (cz_gptr)(a.out_base + a.out_off[f]); io.dst_cap = a.out_cap[f];

@@ -70,7 +70,15 @@ typedef struct cz_blk_desc {
                                   [136..167] Huffman literal sections per size class (bit length of the regenerated size), [168..199] fill counters,
                                   [200] work counter of cz_huf_kernel, [201] copy segments counted, [202] placed, [203] work counter of cz_tile_kernel,
                                   [204] frames that are not CZ_PRE_DONE (cz_execute_frames_kernel has nothing to do when there are none),
-                                  [205] waves of cz_chain_kernel that have finished (cz_huf1_kernel stops when all have) */
+                                  [205] waves of cz_chain_kernel that have finished (cz_huf1_kernel stops when all have),
+                                  [206] frames listed for cz_wexec_kernel (wx_list), [207] of those, frames it did not finish,
+                                  [208] listed frames claimed so far (by either execute kernel), [209] frames cz_wexec_kernel finished */
+/* cz_wexec_kernel (czstd_wexec.hip): a workgroup per frame, the frame's window in LDS */
+#define CZ_WX_RING_LOG 17u
+#define CZ_WX_RING (1u << CZ_WX_RING_LOG)   /* frames of at most this many decoded bytes (out_cap) */
+#ifndef CZ_WX_MIN_UNITS
+#define CZ_WX_MIN_UNITS 512u                /* chain-arena units (~ sequences) a frame must have to be worth a workgroup */
+#endif
 /* One Huffman-coded literals section, as cz_scan_kernel lists it for cz_huf_kernel. */
 typedef struct cz_lit_seg {
     uint32_t frame;           /* batch entry */
@@ -92,8 +100,13 @@ typedef struct cz_copy_seg {
 #define CZ_PRE_REGULAR 0x80000000u   /* frame_pre[f]: the scan walked the frame to its end and listed all of it; low bits: leading blocks done by the pre-pass kernels */
 #define CZ_PRE_DONE    0x40000000u   /* ... and ALL its blocks are done by them: the scan also wrote the frame's result record (no content checksum to verify) */
 #define CZ_PRE_PUSHED  0x20000000u   /* (without CZ_PRE_REGULAR) cz_huf_kernel took a CZ_PRE_DONE frame back and listed it for cz_decode_frames_kernel itself */
-#define CZ_PRE_COUNT   0x1FFFFFFFu
+#define CZ_PRE_WXDONE  0x10000000u   /* cz_wexec_kernel finished the frame (result record written): cz_execute_frames_kernel skips it */
+#define CZ_PRE_WXLIST  0x08000000u   /* cz_scan_kernel listed the frame for cz_wexec_kernel */
+#define CZ_PRE_CLAIMED 0x04000000u   /* cz_wexec_kernel and cz_execute_frames_kernel run side by side and share the frames: whichever sets this bit first does the frame */
+#define CZ_PRE_COUNT   0x03FFFFFFu
 
+/* chain_top (8 x u64, zeroed per launch): [0] arena units taken; bytes 16.. the work counters of the kernels; [5] / [6] sequences (units of 64, x 256) with
+   near / far offset codes, summed by cz_chain_kernel (see cz_wx_side_by_side) */
 typedef struct cz_batch_args {
     const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
     uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
@@ -125,6 +138,9 @@ typedef struct cz_batch_args {
     uint8_t* lit_arena; uint64_t lit_capacity; unsigned long long* lit_top; uint64_t* lit_first;
     cz_lit_seg* lit_segs; uint32_t lit_seg_capacity; cz_copy_seg* copy_segs; uint32_t copy_seg_capacity; uint32_t* frame_pre;
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
+    uint32_t* wx_list; uint32_t* wx_counter;  /* frames cz_scan_kernel lists for cz_wexec_kernel (NULL: none), and that kernel's work counter */
+    uint32_t wx_force;                        /* 0: cz_wx_side_by_side decides from the batch's offset codes; 1: on; 2: off (A/B runs) */
+    uint32_t wx_leave;                        /* cz_execute_frames_kernel leaves the last wx_leave listed frames to cz_wexec_kernel (a frame takes one wave of the former far longer than a workgroup of the latter) */
 } cz_batch_args;
 
 #endif

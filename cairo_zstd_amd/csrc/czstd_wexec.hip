@@ -1,0 +1,739 @@
+/*
+ * czstd_wexec.hip — cz_wexec_kernel: sequence execution with SEVERAL waves per frame and the frame's window in LDS.
+ *
+ * cz_execute_frames_kernel gives a frame to one wave and reads match sources from the frame's output in HBM: with 4 096 frames in
+ * flight that is a 512 MB footprint of random 32-byte reads.  Here a frame is the work of one WORKGROUP of up to 16
+ * waves, one workgroup per CU, and the frame's output is assembled in a 128 KiB window in LDS: match sources never leave the CU,
+ * and the output goes to HBM once, with aligned 16-byte stores, when a block is finished.
+ *
+ * What the reference carries from one sequence to the next (sequence_execution.cairo:12-129, scratch.cairo:11-19) is the output
+ * position, the literal cursor and the three-entry offset history.  All three compose associatively, so a block's records are cut
+ * into CHUNKS of 64 sequences that different waves work on at once (chunk c belongs to wave c mod W):
+ *   1  records -> (ll, ml, offset_value) per lane; prefix sums of ll and ll + ml; the chunk's history transform by a DPP scan over
+ *      packed transforms (cz_history's, with SYMBOLIC results: "what slot j held when the chunk began, plus delta");
+ *   2  the chunk waits for the state BEFORE it — published by chunk c - 1 in an LDS slot —, adds its own sums, resolves its
+ *      summary against the incoming history and publishes the state before chunk c + 1.  Nothing else is serial: the chain of
+ *      publications runs ahead of the data movement;
+ *   3  literals go from the literal buffer (HBM, read once) to their place in the window;
+ *   4  matches copy window -> window.  A match may go once every byte of its source is final: below the position up to which ALL
+ *      earlier chunks are done (the minimum over the waves of "start of the chunk I have not finished"), or inside the lane's own
+ *      chunk below the first match of the chunk that is not done yet (the in-chunk rounds of cz_sequences_rec_fast).  The oldest
+ *      chunk in flight never waits for another one, so the pipeline cannot lock up.
+ * Per block: barrier, tail literals (sequence_execution.cairo:72-78), the block's bytes window -> HBM.
+ *
+ * The kernel is a pure accelerator, like cz_chain_kernel: it takes the frames cz_scan_kernel listed for it (regular to the last
+ * block, everything pre-passed, output <= 128 KiB, enough sequences to be worth a workgroup) and marks those it finished
+ * (frame_pre[f] |= CZ_PRE_WXDONE, result record written).  On ANY irregularity — a check of execute_sequences that fails, a
+ * frame the pre-pass kernels took back — it leaves the frame as it was; cz_execute_frames_kernel, which runs behind it and skips
+ * the marked frames, then does that frame in the reference's order of detection.  Nothing here reports errors.
+ */
+#define WX_WAVES 16u
+#define WX_THREADS (64u * WX_WAVES)
+#define WX_RING CZ_WX_RING                   /* the window: frames of at most this many decoded bytes */
+#define WX_NS 64u                            /* look-back entries, one per chunk in flight and the 48 before (an entry is not reused before its readers are done with it) */
+#define WX_F_AGG 1u                          /* entry flags: the chunk's sums are there / its outgoing history / the state BEHIND the chunk */
+#define WX_F_HOK 2u
+#define WX_F_INCL 4u
+#define WX_INF 0xFFFFFFFFu
+#define WX_REL 0x80000000u                   /* symbolic history value: bits 30:29 = incoming slot, bits 15:0 = 0x8000 + delta */
+#define WX_COOP_LEN 96u                      /* literal runs / matches longer than this are copied by the whole wave */
+
+/* LDS words another wave writes: volatile accesses, and fences that keep the compiler from moving the window accesses across them.
+ * On the device the LDS executes one wave's instructions in order, so a flag written after the data is seen after the data; the
+ * CPU emulator (tests/emu) runs lanes as threads and needs real fences. */
+#ifdef CZ_EMU
+#define WX_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define WX_PAUSE() sched_yield()
+#include <stdio.h>
+#define WX_SPIN_GUARD(cnt, ...) do { if (++(cnt) == 20000u) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+#define WX_DBG(...) do { if (getenv("EMU_WX_DBG")) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+#else
+#define WX_FENCE() asm volatile("" ::: "memory")
+#define WX_PAUSE() __builtin_amdgcn_s_sleep(1)
+#define WX_SPIN_GUARD(cnt, ...) do { } while (0)
+#define WX_DBG(...) do { } while (0)
+#endif
+
+/* diagnostic build only (-DCZ_PROFILE): per-wave s_memtime sums per phase, added to args.prof[40..49] when the kernel ends */
+#ifdef CZ_PROFILE
+#define WX_PROF_T0() do { wxt_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define WX_PROF_ACC(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); wxp[i] += n_ - wxt_; wxt_ = n_; } while (0)
+#define WX_PROF_CNT(i) do { wxp[i] += 1; } while (0)
+#else
+#define WX_PROF_T0() do { } while (0)
+#ifdef WX_ASM_MARKS
+#define WX_PROF_ACC(i) asm volatile("; WX_MARK " #i)
+#else
+#define WX_PROF_ACC(i) do { } while (0)
+#endif
+#define WX_PROF_CNT(i) do { } while (0)
+#endif
+struct WxCtl {
+    uint32_t llml[96];                                         /* [0..35] LL base | bits << 24, [40..92] ML */
+    __attribute__((aligned(16))) uint8_t maps[CZ_CHAIN_MAP_BYTES];   /* state -> code: LL 512, ML 512, OF 256 (kept over Repeat-mode blocks) */
+    __attribute__((aligned(16))) uint32_t slot[WX_NS][8];      /* chunk c at [c % WX_NS]: (c + 1) << 3 | flags, its sum of ll + ml, of ll, position behind it | literal cursor behind it, history behind it */
+    uint32_t fin[WX_RING / 32u + 4u];                          /* one bit per byte of the window: final (set by the sequence that wrote it) */
+    uint32_t err;                                              /* some wave met something irregular: the frame is left to cz_execute_frames_kernel */
+    uint32_t reset_at;                                         /* first chunk of the block whose output does not fit the window any more (WX_INF: none) */
+    /* written by thread 0 between barriers */
+    uint32_t fidx;
+    uint32_t go;                                               /* 0 end of frame (ok), 1 block follows, 2 give the frame up */
+    uint32_t btype, bsize, blt, bregen, bnseq, bpredone, mapflags, lit_rle, lit_byte, lit_len;
+    uint32_t P, blocks, hist[3];
+    uint32_t src_lo, src_hi, lit_lo, lit_hi, rec_lo, rec_hi, maps_lo, maps_hi, bits_lo, bits_hi;
+    uint8_t dump[64 * WX_WAVES + 16];                          /* where a lane's byte goes when it has none to write */
+};
+#define WX_LDS_BYTES (WX_RING + (uint32_t)sizeof(WxCtl))
+
+/* (the pointers are cast to the LDS address space by hand: the compiler does not infer it for volatile accesses and would emit
+   flat_* instructions, whose waits also cover every global load in flight) */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WX_LDS __attribute__((address_space(3)))
+#else
+#define WX_LDS
+#endif
+__device__ static inline uint32_t wx_ld(const uint32_t* p) { return *(const volatile WX_LDS uint32_t*)p; }
+__device__ static inline void wx_st(uint32_t* p, uint32_t v) { *(volatile WX_LDS uint32_t*)p = v; }
+__device__ static inline uint64_t wx_ptr(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+/* a look-back entry: the word with the flags is read first (device: it is in the first of two 16-byte LDS reads, which execute in order) */
+__device__ static inline void wx_read_entry(const uint32_t* e, uint32_t* w) {
+#ifdef CZ_EMU
+    w[0] = wx_ld(&e[0]); WX_FENCE();
+    for (int k = 1; k < 8; k++) w[k] = wx_ld(&e[k]);
+#else
+    typedef uint32_t wx_v4 __attribute__((ext_vector_type(4)));
+    const wx_v4 a = *(const volatile WX_LDS wx_v4*)e; const wx_v4 b = *(const volatile WX_LDS wx_v4*)(e + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+#endif
+}
+
+/* unaligned window accesses (gfx950 LDS takes them; the compiler emits ds_read_b32 / b64 for these) */
+__device__ static inline uint32_t wx_r32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static inline uint64_t wx_r64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ static inline void wx_w16(uint8_t* p, uint32_t v) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); }
+__device__ static inline void wx_w32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ static inline void wx_w64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+/* exactly n <= 8 bytes of v */
+__device__ static inline void wx_wn(uint8_t* p, uint64_t v, uint32_t n) {
+    if (n >= 8u) { wx_w64(p, v); return; }
+    if (n & 4u) { wx_w32(p, (uint32_t)v); p += 4; v >>= 32; }
+    if (n & 2u) { wx_w16(p, (uint32_t)v); p += 2; v >>= 16; }
+    if (n & 1u) *p = (uint8_t)v;
+}
+/* up to 8 bytes from global memory: one load when it stays inside the buffer (`whole`), else byte by byte */
+__device__ static inline uint64_t wx_g64(cz_gcptr s, uint32_t n, int whole) {
+    if (whole) return cz_ldu64(s);
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < 8; b++) if (b < n) v |= (uint64_t)s[b] << (8 * b);
+    return v;
+}
+
+/* ---- copies by the whole workgroup (blocks without sequences, tails, the flush) */
+/* global -> window */
+__device__ static inline void wx_wg_g2w(uint8_t* ring, uint32_t at, cz_gcptr src, uint32_t n, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = 16u * tid; i < n; i += 16u * nthreads) {
+        if (i + 16u <= n) { const uint4 v = cz_ldu128(src + i); __builtin_memcpy(ring + at + i, &v, 16); }
+        else for (uint32_t j = i; j < n; j++) ring[at + j] = src[j];
+    }
+}
+__device__ static inline void wx_wg_fill(uint8_t* ring, uint32_t at, uint32_t byte, uint32_t n, uint32_t tid, uint32_t nthreads) {
+    const uint32_t w = 0x01010101u * byte; const uint4 v = uint4{w, w, w, w};
+    for (uint32_t i = 16u * tid; i < n; i += 16u * nthreads) {
+        if (i + 16u <= n) __builtin_memcpy(ring + at + i, &v, 16);
+        else for (uint32_t j = i; j < n; j++) ring[at + j] = (uint8_t)byte;
+    }
+}
+/* window -> global, aligned 16-byte stores once the destination is aligned */
+__device__ static inline void wx_wg_flush(const uint8_t* ring, uint32_t at, cz_gptr dst, uint32_t n, uint32_t tid, uint32_t nthreads) {
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head > n) head = n;
+    if (tid < head) dst[tid] = ring[at + tid];
+    const uint32_t body = (n - head) >> 4;
+    for (uint32_t i = tid; i < body; i += nthreads) { uint4 v; __builtin_memcpy(&v, ring + at + head + 16u * i, 16); *(cz_gptr4)(dst + head + 16u * i) = v; }
+    const uint32_t done = head + 16u * body;
+    if (tid < n - done) dst[done + tid] = ring[at + done + tid];
+}
+
+/* ---- copies by one wave (long literal runs and long matches of a chunk) */
+__device__ static inline void wx_wave_g2w(uint8_t* ring, uint32_t at, cz_gcptr src, uint32_t n) {
+    for (uint32_t i = 8u * (uint32_t)LANE; i < n; i += 512u) {
+        const uint32_t m = n - i < 8u ? n - i : 8u;
+        wx_wn(ring + at + i, wx_g64(src + i, m, m == 8u), m);
+    }
+}
+__device__ static inline void wx_wave_fill(uint8_t* ring, uint32_t at, uint32_t byte, uint32_t n) {
+    const uint64_t v = 0x0101010101010101ull * byte;
+    for (uint32_t i = 8u * (uint32_t)LANE; i < n; i += 512u) wx_wn(ring + at + i, v, n - i < 8u ? n - i : 8u);
+}
+/* window -> window, n bytes to d from d - off: the forward byte copy of decode_buffer.cairo:95-127.  With off < n the output is
+   periodic from d - off on, so any earlier multiple of off is as good a distance: the distance doubles until it covers a step. */
+__device__ static inline void wx_wave_w2w(uint8_t* ring, uint32_t d, uint32_t off, uint32_t n) {
+    uint32_t copied = 0, dist = off;
+    while (copied < n) {
+        while (dist < 512u && 2u * dist <= off + copied) dist += dist;
+        uint32_t step = n - copied < dist ? n - copied : dist;
+        if (step > 512u) step = 512u;
+        const uint32_t i = 8u * (uint32_t)LANE;
+        uint64_t v = 0; uint32_t m = 0;
+        if (i < step) { m = step - i < 8u ? step - i : 8u; v = wx_r64(ring + d + copied - dist + i); }   /* (reads at most 7 bytes beyond the source; only m are used) */
+        cz_wave_sync();                                                 /* every lane has read before any lane writes */
+        if (m) wx_wn(ring + d + copied + i, v, m);
+        cz_wave_sync();
+        copied += step;
+    }
+}
+
+/* ---- one lane: n bytes to d from d - off, any n (the per-lane loop behind the short forms) */
+__device__ static inline void wx_lane_w2w(uint8_t* ring, uint32_t d, uint32_t off, uint32_t n) {
+    uint32_t copied = 0, dist = off;
+    while (copied < n) {
+        while (dist < 8u && 2u * dist <= off + copied) dist += dist;
+        uint32_t step = n - copied < dist ? n - copied : dist;
+        if (step > 8u) step = 8u;
+        wx_wn(ring + d + copied, wx_r64(ring + d + copied - dist), step);
+        copied += step;
+    }
+}
+
+/* ---- the `final` bitmap: bit p = byte p of the window has its final value */
+#ifdef CZ_EMU
+#define WX_OR(p, v) ((void)__atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST))
+static inline void wx_emu_min(uint32_t* p, uint32_t v) { uint32_t o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < o && !__atomic_compare_exchange_n(p, &o, v, 0, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) { } }
+#define WX_MIN(p, v) wx_emu_min((p), (v))
+#else
+#define WX_OR(p, v) ((void)__hip_atomic_fetch_or((WX_LDS uint32_t*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define WX_MIN(p, v) ((void)__hip_atomic_fetch_min((WX_LDS uint32_t*)(p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#endif
+/* the bits of [p, p + n) that lie in 32-bit word `word` of the bitmap */
+__device__ static inline uint32_t wx_word_mask(uint32_t p, uint32_t n, uint32_t word) {
+    const uint32_t lo = word << 5, hi = lo + 32u, a = p > lo ? p : lo, e = p + n < hi ? p + n : hi;
+    if (a >= e) return 0u;
+    const uint32_t len = e - a;
+    return (len >= 32u ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (a & 31u);
+}
+/* n <= 32: two words at most */
+__device__ static inline void wx_mark32(uint32_t* fin, uint32_t p, uint32_t n) {
+    const uint64_t m = ((1ull << n) - 1ull) << (p & 31u);
+    WX_OR(&fin[p >> 5], (uint32_t)m); WX_OR(&fin[(p >> 5) + 1u], (uint32_t)(m >> 32));
+}
+__device__ static inline int wx_final32(const uint32_t* fin, uint32_t p, uint32_t n) {
+    const uint64_t m = ((1ull << n) - 1ull) << (p & 31u);
+    const uint32_t w0 = wx_ld(&fin[p >> 5]), w1 = wx_ld(&fin[(p >> 5) + 1u]);
+    return (((uint32_t)m & ~w0) | ((uint32_t)(m >> 32) & ~w1)) == 0u;
+}
+/* any n, one lane */
+__device__ static inline void wx_mark(uint32_t* fin, uint32_t p, uint32_t n) {
+    for (uint32_t w = p >> 5; (w << 5) < p + n; w++) WX_OR(&fin[w], wx_word_mask(p, n, w));
+}
+__device__ static inline int wx_final(const uint32_t* fin, uint32_t p, uint32_t n) {
+    for (uint32_t w = p >> 5; (w << 5) < p + n; w++) { const uint32_t m = wx_word_mask(p, n, w); if (m & ~wx_ld(&fin[w])) return 0; }
+    return 1;
+}
+/* any n, the whole wave */
+__device__ static inline void wx_wave_mark(uint32_t* fin, uint32_t p, uint32_t n) {
+    for (uint32_t w = (p >> 5) + (uint32_t)LANE; (w << 5) < p + n; w += 64u) WX_OR(&fin[w], wx_word_mask(p, n, w));
+}
+
+/* records -> values (cz_rec_values with this kernel's tables).  WIDE = 0: no record of the chunk has more than 32 extra bits */
+template <int WIDE>
+__device__ static inline uint32_t wx_rec_values(const WxCtl& ctl, uint64_t r, cz_gcptr bits, uint32_t& ll, uint32_t& ml) {
+    const uint8_t* mapll = ctl.maps; const uint8_t* mapml = mapll + 512; const uint8_t* mapof = mapll + 1024;
+    const uint32_t xt = (uint32_t)r, st = (uint32_t)(r >> 32);
+    const uint32_t oc = mapof[(st >> 18) & 255];
+    const uint32_t tl = ctl.llml[mapll[st & 511]], tm = ctl.llml[40 + mapml[(st >> 9) & 511]];
+    const uint32_t mx = tm >> 24, lx = tl >> 24;
+    uint32_t ov;
+    if (!WIDE || !(st & CZC_REC_WIDE)) {                                /* <= 32 extra bits: the top of the record's low word */
+        ov = (1u << oc) + __builtin_amdgcn_ubfe(xt, 32 - oc, oc);       /* sequence_section_decoder.cairo:243 */
+        ml = (tm & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx, mx);     /* :249-256 */
+        ll = (tl & 0xFFFFFFu) + __builtin_amdgcn_ubfe(xt, 32 - oc - mx - lx, lx);
+    } else {                                                            /* the low word says where the extra bits are in the bitstream */
+        const uint64_t W = cz_stream_window64(bits, xt);
+        ov = (1u << oc) + cz_field(W, 0, oc);
+        ml = (tm & 0xFFFFFFu) + cz_field(W, oc, mx);
+        ll = (tl & 0xFFFFFFu) + cz_field(W, oc + mx, lx);
+    }
+    return ov;
+}
+
+/* symbolic value of what a history slot holds, from a transform byte: pushed by a lane of this chunk, or an incoming slot */
+__device__ static inline uint32_t wx_resolve(uint32_t s, uint32_t h0, uint32_t h1, uint32_t h2) {
+    const uint32_t base = cz_pick3((s >> 29) & 3u, h0, h1, h2);
+    return (s & WX_REL) ? base + (s & 0xFFFFu) - 0x8000u : s;
+}
+
+/* Matches of one chunk (step 4), in rounds: a match goes once every byte of its source is final.  Below `horizon` — the end of the
+ * chunk this wave worked on two turns ago — everything is: a chunk passes its look-back only when all chunks before it have
+ * published their sums, i.e. when their waves have finished the data phase two chunks before those.  Above it the `final` bitmap
+ * says so byte by byte (a sequence sets the bits of its literals and its match when the match is written), which also orders the
+ * matches of the chunk itself.  first = 1: one round, returns the lanes that have to wait; first = 0: rounds until `todo` is done. */
+struct WxData { uint32_t ll, ml, opos, off; uint64_t lw; uint32_t lpos; int active; };   /* a chunk ready for its data phase, per lane */
+__device__ static inline unsigned long long wx_match_rounds(WxCtl& ctl, uint8_t* rw, cz_gcptr out, uint32_t rbase, uint32_t cap, const WxData& x, uint32_t horizon, uint8_t* dump, const int first,
+                                                            unsigned long long* wxp, unsigned long long todo = 0) {
+    const uint32_t lane = (uint32_t)LANE;
+    const uint32_t ll = x.ll, ml = x.ml, opos = x.opos, off = x.off, d = opos + ll, tot = ll + ml;
+    /* A source that begins before the block (position < rbase) is in the frame's output in HBM: the first n1 bytes of the match
+       come from there (final since the barrier behind the earlier block), the rest, if any, from the start of the window on.
+       The bytes to wait for: the window part of the source from `horizon` on (below it everything is final), clipped to the start of
+       the sequence's own literals (they are in place). */
+    const uint32_t src = d - off, n1 = src < rbase ? (rbase - src < ml ? rbase - src : ml) : 0u;
+    const uint32_t send_ = off < ml ? d : src + ml, wend = send_ < opos ? send_ : opos, wsrc = src > horizon ? src : horizon,
+                   slen = wsrc >= wend ? 0u : wend - wsrc;
+    int undone = first ? x.active : (int)((todo >> lane) & 1ull);
+    const int smallseq = !__ballot(tot > 32u);
+    const int small4 = !__ballot(ml > 4u || n1 != 0u);
+    const unsigned long long longm = __ballot(undone && ml > WX_COOP_LEN), hugem = __ballot(undone && tot > 512u);
+    uint32_t spins = 0; (void)spins;
+    for (;;) {
+        if (!__ballot(undone)) break;
+        WX_PROF_CNT(7);
+        int ready = undone && slen == 0u;
+        if (__ballot(undone && !ready)) {
+            if (undone && !ready) ready = smallseq ? wx_final32(ctl.fin, wsrc - rbase, slen) : wx_final(ctl.fin, wsrc - rbase, slen);
+            WX_FENCE();
+        }
+        const unsigned long long rm = __ballot(ready);
+        if (!rm) {                                                      /* every match left waits for another wave (or the frame has been given up) */
+            if (first || cz_uni(wx_ld(&ctl.err))) break;
+            WX_PAUSE(); WX_PROF_CNT(8);
+            WX_SPIN_GUARD(spins, "WX SPIN match: lane %u undone %d opos %u ll %u ml %u off %u src %u slen %u horizon %u rbase %u\n", lane, undone, opos, ll, ml, off, src, slen, horizon, rbase);
+            continue;
+        }
+        if (small4) {
+            if (ready) {
+                uint32_t w = wx_r32(rw + src);
+                if (off < 4u) w = off == 1u ? (w & 0xFFu) * 0x01010101u : (off == 2u ? (w & 0xFFFFu) * 0x00010001u : ((w & 0xFFFFFFu) | (w << 24)));
+                wx_w16(rw + d, w); rw[d + 2u] = (uint8_t)(w >> 16);
+                uint8_t* q = ml > 3u ? rw + d + 3u : dump; *q = (uint8_t)(w >> 24);
+            }
+        } else {
+            if (ready && ml <= WX_COOP_LEN) {
+                for (uint32_t k = 0; k < n1; k += 8) { const uint32_t m = n1 - k < 8u ? n1 - k : 8u; wx_wn(rw + d + k, wx_g64(out + src + k, m, src + k + 8u <= cap), m); }
+                if (ml > n1) wx_lane_w2w(rw, d + n1, off, ml - n1);
+            }
+            for (unsigned long long lm = rm & longm; lm; lm &= lm - 1) {
+                const int j = cz_unii(__ffsll((long long)lm) - 1);
+                const uint32_t dj = cz_readlane(d, j), oj = cz_readlane(off, j), mj = cz_readlane(ml, j), nj = cz_readlane(n1, j);
+                cz_wave_sync();
+                if (nj) { wx_wave_g2w(rw, dj, out + (dj - oj), nj); cz_wave_sync(); }
+                if (mj > nj) wx_wave_w2w(rw, dj + nj, oj, mj - nj);
+            }
+        }
+        WX_FENCE();
+        if (smallseq) { if (ready) wx_mark32(ctl.fin, opos - rbase, tot); }
+        else {
+            if (ready && tot <= 512u) wx_mark(ctl.fin, opos - rbase, tot);
+            for (unsigned long long lm = rm & hugem; lm; lm &= lm - 1) {
+                const int j = cz_unii(__ffsll((long long)lm) - 1);
+                wx_wave_mark(ctl.fin, cz_readlane(opos, j) - rbase, cz_readlane(tot, j));
+            }
+        }
+        if (ready) undone = 0;
+        cz_wave_sync();
+        if (first) break;
+    }
+    return __ballot(undone);
+}
+
+/* Chunks of one block's records (sequence_execution.cairo:12-83), all waves.  The entry of "chunk -1" holds the state before chunk 0.
+ * A wave works on two chunks at a time, 16 apart: per turn it runs step 1 of the NEXT chunk y and publishes its sums, then moves
+ * the data of the CURRENT chunk x (steps 3 and 4), then does the look-back of y (step 2) and issues y's literal loads.  So the
+ * sums of a chunk are out a whole data phase before anybody's look-back asks for them, and literal bytes have a whole step 1 to
+ * arrive. */
+__device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr out, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, cz_gcptr lbase, uint32_t lit_len,
+                                          int lit_rle, uint32_t rle_byte, uint32_t cap, uint32_t wave, uint32_t nwaves, uint32_t pstart, uint32_t c0, unsigned long long* wxp) {
+    /* The window holds the block's output from position `pstart` on: byte `pos` of the frame at rw[pos].  Chunks from c0 on (c0 > 0:
+       the pass before this one filled the window; its bytes are in HBM now and the window starts again at the position before chunk
+       c0).  The first chunk whose output would pass the end of the window sets ctl.reset_at; chunks from there on are left for
+       the next pass. */
+    uint8_t* const rw = ring - pstart;
+    const uint32_t rbase = pstart, wlimit = cap;
+#ifdef CZ_PROFILE
+    unsigned long long wxt_ = 0;
+#endif
+    const uint32_t nch = (nseq + 63u) >> 6, lane = (uint32_t)LANE;
+    const uint32_t yfirst = c0 + ((wave + nwaves - (c0 & (nwaves - 1u))) & (nwaves - 1u));   /* this wave's chunks: those equal to its number mod the waves */
+    if (yfirst >= nch) return;
+    auto load_rec = [&](uint32_t ch) -> uint64_t { const uint32_t i = 64u * ch + lane; return rec[i < nseq ? i : nseq - 1u]; };   /* coalesced 8-byte loads */
+    uint64_t r1 = load_rec(yfirst), r2 = load_rec(yfirst + nwaves), r3 = load_rec(yfirst + 2u * nwaves);
+    uint8_t* const dump = ctl.dump + 64u * wave + lane;
+    /* step 1 results of chunk y, kept over the data phase of chunk x */
+    uint32_t a_ll = 0, a_ml = 0, a_orel = 0, a_lrel = 0, a_asym = 0; int a_active = 0, a_bad = 0;
+    uint32_t a_sum_ll = 0, a_sum_tot = 0, a_o0 = 0, a_o1 = 0, a_o2 = 0; int a_habs = 0;
+    WxData x; x.ll = x.ml = x.opos = x.off = x.lpos = 0; x.lw = 0; x.active = 0;
+    int x_ok = 0;                                                       /* chunk x passed its checks (else nothing of it is written: the frame is given up) */
+    uint32_t out1 = pstart, out2 = pstart, out3 = pstart;               /* positions behind the chunk in hand (x), behind this wave's previous chunk (x - 16) and behind the one before (x - 32) */
+    uint32_t y = yfirst; int have_x = 0;
+    unsigned long long m_undone = 0;                                    /* matches of chunk x that are not written yet */
+    for (;;) {
+        const int have_y = y < nch && y < cz_uni(wx_ld(&ctl.reset_at));
+        if (have_y) {
+            /* 1: values, sums, the chunk's history transform */
+            const uint64_t r = r1;
+            r1 = r2; r2 = r3; r3 = load_rec(y + 3u * nwaves);
+            WX_PROF_T0(); WX_PROF_CNT(9);
+            const uint32_t cnt = nseq - 64u * y < 64u ? nseq - 64u * y : 64u;
+            const int active = lane < cnt;
+            uint32_t ll = 0, ml = 0, ov = 4;
+            if (!__ballot((uint32_t)(r >> 32) & CZC_REC_WIDE)) { const uint32_t v = wx_rec_values<0>(ctl, r, bits, ll, ml); if (active) ov = v; else { ll = 0; ml = 0; } }
+            else if (active) ov = wx_rec_values<1>(ctl, r, bits, ll, ml);
+            a_bad = active && ov >= 0x40000000u;                        /* (also keeps pushed values clear of WX_REL) */
+            const uint32_t tot = ll + ml;
+            if (!__ballot((ll | ml) >= 512u)) {                         /* both prefix sums in one scan */
+                const uint32_t pk = ll | (tot << 16), incl = cz_wave_incl_scan(pk), sums = cz_readlane(incl, 63), excl = incl - pk;
+                a_sum_ll = sums & 0xFFFFu; a_sum_tot = sums >> 16; a_lrel = excl & 0xFFFFu; a_orel = excl >> 16;
+            } else {
+                const uint32_t il = cz_wave_incl_scan(ll), it = cz_wave_incl_scan(tot);
+                a_sum_ll = cz_readlane(il, 63); a_sum_tot = cz_readlane(it, 63); a_lrel = il - ll; a_orel = it - tot;
+            }
+            /* history (sequence_execution.cairo:85-129): cz_history's packed transforms; pushed values stay symbolic where they are
+               "offset_value 3 with no literals" = what slot 0 held before the lane, minus one */
+            uint32_t T, M;
+            const int dec = active && ov == 3 && ll == 0;
+            {
+                const uint32_t kind = !active ? 0u : (ov > 3 ? 3u : ov - (ll > 0 ? 1u : 0u));
+                const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? (0x00010080u | lane) : 0x00010002u;
+                T = (kind & 2u) ? t23 : t01;
+                M = kind == 3u ? 0xFFu : 0u;
+            }
+#define WX_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pM = cz_dpp<CTRL, RM>(0u, M); \
+            const uint32_t R = __builtin_amdgcn_perm(T, pT, T); const uint32_t Mn = __builtin_amdgcn_perm(M, pM, T); \
+            T = (T & M) | (R & ~M); M = Mn; } while (0)
+            WX_HT_STEP(CZ_DPP_SHR1, 0xF); WX_HT_STEP(CZ_DPP_SHR2, 0xF); WX_HT_STEP(CZ_DPP_SHR4, 0xF); WX_HT_STEP(CZ_DPP_SHR8, 0xF);
+            WX_HT_STEP(CZ_DPP_BCAST15, 0xA); WX_HT_STEP(CZ_DPP_BCAST31, 0xC);
+#undef WX_HT_STEP
+            uint32_t pv = ov - 3u;
+            const unsigned long long dm = __ballot(dec);
+            if (dm) {
+                const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T);  /* transform of everything before the lane */
+                for (unsigned long long m = dm; m; m &= m - 1) {
+                    const int j = cz_unii(__ffsll((long long)m) - 1);
+                    const uint32_t bT = cz_readlane(eT, j) & 0xFFu;
+                    const uint32_t before = (bT & 0x80u) ? cz_readlane(pv, cz_unii((int)(bT & 63u))) : (WX_REL | ((bT & 3u) << 29) | 0x8000u);
+                    if ((int)lane == j) pv = before - 1u;
+                }
+            }
+            const uint32_t pushed = __shfl(pv, (int)(T & 63u));         /* every lane takes part */
+            a_asym = (T & 0x80u) ? pushed : (WX_REL | ((T & 3u) << 29) | 0x8000u);
+            const uint32_t fT = cz_readlane(T, 63);
+            uint32_t osym[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t tk = (fT >> (8 * k)) & 0xFFu;
+                const uint32_t pk_ = cz_readlane(pv, cz_unii((int)(tk & 63u)));
+                osym[k] = (tk & 0x80u) ? pk_ : (WX_REL | ((tk & 3u) << 29) | 0x8000u);
+            }
+            a_ll = ll; a_ml = ml; a_active = active;
+            a_o0 = cz_uni(osym[0]); a_o1 = cz_uni(osym[1]); a_o2 = cz_uni(osym[2]);
+            a_habs = !((a_o0 | a_o1 | a_o2) & WX_REL);
+            /* the chunk's sums — and its outgoing history when that does not depend on the incoming one (three pushes in 64
+               sequences: nearly always) — are published at once */
+            if (lane == 0) {
+                uint32_t* const mine = ctl.slot[y & (WX_NS - 1u)];
+                if (a_habs) { wx_st(&mine[5], a_o0); wx_st(&mine[6], a_o1); wx_st(&mine[7], a_o2); }
+                wx_st(&mine[1], a_sum_tot); wx_st(&mine[2], a_sum_ll);
+                WX_FENCE();
+                wx_st(&mine[0], ((y + 1u) << 3) | WX_F_AGG | (a_habs ? WX_F_HOK : 0u));
+            }
+            WX_PROF_ACC(0);
+        }
+        if (have_x && x_ok) {
+            WX_PROF_T0();
+            const uint32_t ll = x.ll, opos = x.opos;
+            /* 3: literals: from the literal buffer (asked for at the end of the chunk's look-back) to their place in the window */
+            {
+                const unsigned long long l8 = __ballot(ll > 8u);
+                if (__ballot(ll > 0u)) {
+                    if (!__ballot(ll > 2u)) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 2; j++) { uint8_t* q = j < ll ? rw + opos + j : dump; *q = (uint8_t)(x.lw >> (8 * j)); }
+                    } else wx_wn(rw + opos, x.lw, ll < 8u ? ll : 8u);
+                }
+                if (l8) {
+                    /* the rest of longer runs: by the lane up to WX_COOP_LEN, by the wave beyond */
+                    const uint32_t lpos = x.lpos;
+                    if (ll > 8u && ll <= WX_COOP_LEN) {
+                        for (uint32_t k = 8; k < ll; k += 8) {
+                            const uint32_t m = ll - k < 8u ? ll - k : 8u;
+                            const uint64_t v = lit_rle ? 0x0101010101010101ull * rle_byte : wx_g64(lbase + lpos + k, m, lpos + k + 8u <= lit_len);
+                            wx_wn(rw + opos + k, v, m);
+                        }
+                    }
+                    for (unsigned long long lm = __ballot(ll > WX_COOP_LEN); lm; lm &= lm - 1) {
+                        const int j = cz_unii(__ffsll((long long)lm) - 1);
+                        const uint32_t n = cz_readlane(ll, j) - 8u, at = cz_readlane(opos, j) + 8u, from = cz_readlane(lpos, j) + 8u;
+                        if (lit_rle) wx_wave_fill(rw, at, rle_byte, n); else wx_wave_g2w(rw, at, lbase + from, n);
+                    }
+                }
+            }
+            cz_wave_sync();
+            WX_PROF_ACC(2);
+            /* 4: matches: the first round here, what it leaves after the look-back of the next chunk (wx_match_rounds) */
+            m_undone = wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 1, wxp);
+            WX_PROF_ACC(3);
+        }
+        if (!have_y) {
+            if (m_undone) { WX_PROF_T0(); wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 0, wxp, m_undone); WX_PROF_ACC(3); }
+            break;
+        }
+        /* 2: the state before chunk y, by a decoupled look-back: the entries of the 16 chunks before it — the nearest one whose own
+           state is known, plus the sums of those between.  The serial chain has one link per ROUND of chunks, not one per chunk; a
+           history that is not absolute chains through its chunk only. */
+        WX_PROF_T0();
+        uint32_t P_in = 0, L_in = 0, h0 = 0, h1 = 0, h2 = 0; int stop = 0;
+        {
+            /* wait (one word per entry): the nearest chunk before y whose own state is known (chunk y - 16, this wave's previous
+               one, at the latest), the sums of those between, and the history behind chunk y - 1 */
+            const uint32_t* const ent = ctl.slot[(y - 1u - (lane & 15u)) & (WX_NS - 1u)];
+            uint32_t k = 0, lbspins = 0; (void)lbspins;
+            for (;;) {
+                const uint32_t w0 = wx_ld(&ent[0]);
+                const uint32_t f = lane < 16u && (w0 >> 3) == y - lane ? (w0 & 7u) : 0u;   /* (an entry may still be that of a chunk 64 earlier) */
+                const unsigned long long inclm = __ballot(f & WX_F_INCL), aggm = __ballot(f & WX_F_AGG);
+                if (inclm) {
+                    k = (uint32_t)cz_unii(__ffsll((long long)inclm) - 1);
+                    const unsigned long long below = (1ull << k) - 1ull;
+                    if ((aggm & below) == below && (cz_readlane(f, 0) & WX_F_HOK)) break;
+                }
+                if (cz_uni(wx_ld(&ctl.reset_at)) <= y) { stop = 1; break; }   /* a chunk before this one did not fit the window: the next pass */
+                WX_PAUSE(); WX_PROF_CNT(6);
+                WX_SPIN_GUARD(lbspins, "WX SPIN look-back: y %u lane %u w0 %08x\n", y, lane, w0);
+            }
+            WX_FENCE();
+            uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (lane < 16u && !stop) wx_read_entry(ent, e);
+            uint32_t sp = lane < k ? e[1] : (lane == k ? e[3] : 0u), sl = lane < k ? e[2] : (lane == k ? e[4] : 0u);
+#define WX_ROW_ADD(CTRL) do { sp += cz_dpp<CTRL, 0xF>(0u, sp); sl += cz_dpp<CTRL, 0xF>(0u, sl); } while (0)
+            WX_ROW_ADD(CZ_DPP_SHR1); WX_ROW_ADD(CZ_DPP_SHR2); WX_ROW_ADD(CZ_DPP_SHR4); WX_ROW_ADD(CZ_DPP_SHR8);
+#undef WX_ROW_ADD
+            P_in = cz_readlane(sp, 15); L_in = cz_readlane(sl, 15);
+            h0 = cz_readlane(e[5], 0); h1 = cz_readlane(e[6], 0); h2 = cz_readlane(e[7], 0);
+        }
+        /* (a position that has left the buffer stays where it is: no wrap-around can bring it back inside) */
+        const uint32_t P_out = P_in > wlimit ? P_in : P_in + a_sum_tot, L_out = L_in > lit_len ? L_in : L_in + a_sum_ll;
+        if (!stop && P_out <= wlimit && P_out - rbase > WX_RING) {
+            /* the chunk does not fit the window any more: the next pass starts with it (a chunk that would not fit an empty window
+               is given up below: its entry gets the state behind it, and later chunks, which cannot fit either, follow it there) */
+            if (P_out - P_in <= WX_RING) { if (lane == 0) WX_MIN(&ctl.reset_at, y); stop = 1; }
+        }
+        if (stop) {
+            if (m_undone) { wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 0, wxp, m_undone); m_undone = 0; }
+            break;
+        }
+        if (lane == 0) {
+            uint32_t* const mine = ctl.slot[y & (WX_NS - 1u)];
+            if (!a_habs) { wx_st(&mine[5], wx_resolve(a_o0, h0, h1, h2)); wx_st(&mine[6], wx_resolve(a_o1, h0, h1, h2)); wx_st(&mine[7], wx_resolve(a_o2, h0, h1, h2)); }
+            wx_st(&mine[4], L_out); wx_st(&mine[3], P_out);
+            WX_FENCE();
+            wx_st(&mine[0], ((y + 1u) << 3) | WX_F_AGG | WX_F_HOK | WX_F_INCL);
+        }
+        /* every check of execute_sequences (sequence_execution.cairo:28-36 literals, :47 zero offset; decode_buffer.cairo:65 offset
+           beyond the output so far — no dictionary here) and the capacity of the caller's buffer */
+        WxData nx;
+        nx.ll = a_ll; nx.ml = a_ml; nx.active = a_active;
+        nx.off = wx_resolve(a_asym, h0, h1, h2);
+        nx.opos = P_in + a_orel; nx.lpos = L_in + a_lrel;
+        const int bad = a_bad | (a_active && (nx.off - 1u >= nx.opos + a_ll));
+        const int nx_ok = !(__ballot(bad) || P_out > wlimit || P_out - rbase > WX_RING || L_out > lit_len);
+        if (!nx_ok && lane == 0) { wx_st(&ctl.err, 1u); WX_DBG("WX give-up: chunk %u P_in %u P_out %u wlimit %u L_out %u lit_len %u badmask %llx\n", y, P_in, P_out, wlimit, L_out, lit_len, (unsigned long long)__builtin_popcountll(0)); }
+        nx.lw = 0x0101010101010101ull * rle_byte;
+        if (nx_ok && !lit_rle && a_ll > 0u) nx.lw = wx_g64(lbase + nx.lpos, a_ll, nx.lpos + 8u <= lit_len);
+        WX_PROF_ACC(1);
+        /* the matches of chunk x that had to wait: the chunks they wait for have had this look-back's time */
+        if (m_undone) { wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 0, wxp, m_undone); m_undone = 0; WX_PROF_ACC(3); }
+        x = nx; x_ok = nx_ok;
+        out3 = out2; out2 = out1; out1 = P_out;
+        have_x = 1; y += nwaves;
+    }
+}
+
+/* One workgroup per frame; frames from the list cz_scan_kernel made (a.wx_list, scan_ctl[206] entries). */
+extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_batch_args a) {
+    uint8_t* const ring = (uint8_t*)cz_dyn_lds;
+    WxCtl& ctl = *(WxCtl*)(ring + WX_RING);
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = cz_uni(tid >> 6);
+    const uint32_t nlist = cz_uni(a.scan_ctl[206]);
+    if (nlist == 0 || !cz_wx_side_by_side(a)) return;
+    unsigned long long wxp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef CZ_PROFILE
+    unsigned long long wxt_ = 0;
+#endif
+    for (uint32_t i = tid; i < 36; i += nthreads) ctl.llml[i] = CZ_LL_BASE[i] | ((uint32_t)CZ_LL_BITS[i] << 24);
+    for (uint32_t i = tid; i < 53; i += nthreads) ctl.llml[40 + i] = CZ_ML_BASE[i] | ((uint32_t)CZ_ML_BITS[i] << 24);
+    CzsWalk w; CzsBlk b;                                                /* thread 0's walk over the frame's headers (the scan's own walker: same decisions) */
+    czs_begin(w, nullptr, 0, 0);
+    b.type = b.blk_off = b.bsize = b.lt = b.regen = b.lit_hdr = b.nseq = b.sbody = b.modes = 0;
+    uint64_t chain_cursor = 0, lit_cursor = 0; uint32_t pre_blocks = 0;
+    for (;;) {
+        __syncthreads();
+        WX_PROF_T0();
+        if (tid == 0) {
+            const uint32_t i = atomicAdd(a.wx_counter, 1u);
+            uint32_t f = i < nlist ? a.wx_list[i] : 0xFFFFFFFFu;
+            ctl.fidx = f; ctl.go = 2; ctl.err = 0;
+            if (f != 0xFFFFFFFFu) {
+                /* still as the scan left it?  (cz_chain_kernel / the huff0 kernels may have taken the frame back) */
+                const uint32_t pre = atomicOr(&a.frame_pre[f], CZ_PRE_CLAIMED);   /* (cz_execute_frames_kernel runs beside this kernel: whoever claims a frame first does it) */
+                chain_cursor = a.frame_first[f]; lit_cursor = a.lit_first[f]; pre_blocks = pre & CZ_PRE_COUNT;
+                if (!(pre & CZ_PRE_CLAIMED)) atomicAdd(&a.scan_ctl[208], 1u);
+                if (pre & CZ_PRE_CLAIMED) ctl.go = 3;
+                else if ((pre & CZ_PRE_REGULAR) && !(pre & CZ_PRE_DONE) && chain_cursor != 0 && lit_cursor != 0 && a.out_cap[f] < 0x80000000ull) {
+                    czs_begin(w, a.in_base + a.in_off[f], a.in_len[f], 1);
+                    if (w.active) { ctl.go = 1; ctl.P = 0; ctl.blocks = 0; ctl.hist[0] = 1; ctl.hist[1] = 4; ctl.hist[2] = 8; }   /* scratch.cairo:35 */
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t f = cz_uni(ctl.fidx);
+        if (f == 0xFFFFFFFFu) break;
+        if (cz_uni(ctl.go) != 1u) {                                     /* taken by the other kernel (3), or not what the scan left (2): cz_decode_frames_kernel does it from scratch */
+            if (tid == 0 && ctl.go == 2u && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
+            continue;
+        }
+        cz_gcptr fsrc = (cz_gcptr)(a.in_base + a.in_off[f]);
+        cz_gptr out = (cz_gptr)(a.out_base + a.out_off[f]);
+        const uint32_t cap = (uint32_t)a.out_cap[f];
+        int ok = 0;
+        for (;;) {
+            /* thread 0: the next block (block_decoder.cairo:237-321 and the section headers behind it) */
+            if (tid == 0) {
+                uint32_t go = 2;
+                const int has = czs_next(w, a.chain_min_nseq, b);
+                if (!has) go = w.ok ? 0u : 2u;
+                else {
+                    const uint32_t P = ctl.P, blocks = ctl.blocks;
+                    const int predone = blocks < pre_blocks;
+                    go = 1; ctl.btype = b.type; ctl.bsize = b.bsize; ctl.blt = b.lt; ctl.bregen = b.regen; ctl.bnseq = b.nseq; ctl.bpredone = (uint32_t)predone;
+                    const uint64_t sp = (uint64_t)(uintptr_t)(fsrc + b.blk_off);
+                    ctl.src_lo = (uint32_t)sp; ctl.src_hi = (uint32_t)(sp >> 32);
+                    uint32_t outlen = b.type != 2 ? b.bsize : (b.nseq ? 0u : b.regen);
+                    if (P + outlen > cap || outlen > WX_RING) go = 2;      /* (a block's output must fit the window; the format's blocks do: block_decoder.cairo:67) */
+                    if (go == 1 && b.type == 2 && !predone) {
+                        /* the block's literals (literals_section_decoder.cairo:32-56): Raw in place, RLE one byte, Huffman-coded in the node the scan laid out */
+                        uint64_t lp = sp + b.lit_hdr; uint32_t rle = 0, byte = 0;
+                        if (b.lt == 1) { rle = 1; byte = fsrc[b.blk_off + b.lit_hdr]; }
+                        else if (b.lt >= 2) {
+                            if (lit_cursor < 64) go = 2;
+                            else {
+                                CZ_GLOBAL const uint64_t* node = (CZ_GLOBAL const uint64_t*)(a.lit_arena + lit_cursor);
+                                const uint64_t nxt = node[0], meta = node[1];
+                                if ((uint32_t)meta != b.regen) go = 2;
+                                lp = (uint64_t)(uintptr_t)(a.lit_arena + lit_cursor + 16); lit_cursor = nxt;
+                            }
+                        }
+                        ctl.lit_lo = (uint32_t)lp; ctl.lit_hi = (uint32_t)(lp >> 32); ctl.lit_rle = rle; ctl.lit_byte = byte; ctl.lit_len = b.regen;
+                        if (go == 1 && b.nseq) {
+                            if (!chain_cursor) go = 2;
+                            else {
+                                /* cz_chain_kernel's header: {nseq << 32 | maps that follow, offset of the bitstream, next header}, maps, records */
+                                cz_gcptr64 arena = (cz_gcptr64)a.chain_arena;
+                                const uint64_t w0 = arena[chain_cursor], w1 = arena[chain_cursor + 1], w2 = arena[chain_cursor + 2];
+                                const uint64_t mp = (uint64_t)(uintptr_t)(a.chain_arena + chain_cursor + 4), rp = mp + 8ull * CZ_CHAIN_MAP_WORDS;
+                                const uint64_t bp = sp + (uint32_t)w1;
+                                chain_cursor = w2;
+                                if ((uint32_t)(w0 >> 32) != b.nseq) go = 2;
+                                ctl.mapflags = (uint32_t)w0; ctl.maps_lo = (uint32_t)mp; ctl.maps_hi = (uint32_t)(mp >> 32);
+                                ctl.rec_lo = (uint32_t)rp; ctl.rec_hi = (uint32_t)(rp >> 32); ctl.bits_lo = (uint32_t)bp; ctl.bits_hi = (uint32_t)(bp >> 32);
+                                /* the state before chunk 0: the entry of "chunk -1" */
+                                for (uint32_t k = 0; k < WX_NS; k++) ctl.slot[k][0] = 0;
+                                uint32_t* s0 = ctl.slot[WX_NS - 1u];
+                                s0[1] = 0; s0[2] = 0; s0[3] = P; s0[4] = 0; s0[5] = ctl.hist[0]; s0[6] = ctl.hist[1]; s0[7] = ctl.hist[2];
+                                s0[0] = WX_F_AGG | WX_F_HOK | WX_F_INCL;
+                            }
+                        }
+                    }
+                }
+                ctl.go = go;
+                if (go == 2) WX_DBG("WX give-up at block %u: type %u size %u nseq %u P %u has %d ok %d chain %llu lit %llu\n", ctl.blocks, b.type, b.bsize, b.nseq, ctl.P, has, w.ok, (unsigned long long)chain_cursor, (unsigned long long)lit_cursor);
+            }
+            __syncthreads();
+            WX_PROF_ACC(4);
+            const uint32_t go = cz_uni(ctl.go);
+            if (go != 1u) { ok = go == 0u; break; }
+            const uint32_t btype = cz_uni(ctl.btype), bsize = cz_uni(ctl.bsize), nseq = cz_uni(ctl.bnseq), regen = cz_uni(ctl.bregen);
+            const uint32_t P = cz_uni(ctl.P);
+            const int predone = (int)cz_uni(ctl.bpredone);
+            cz_gcptr bsrc = (cz_gcptr)(uintptr_t)wx_ptr(cz_uni(ctl.src_lo), cz_uni(ctl.src_hi));
+            uint32_t P_end = P, wbase = P;                              /* the window holds this block's output from wbase on: byte `pos` of the frame at (ring - wbase)[pos] */
+            uint8_t* const rw = ring - P;
+            if (predone) P_end = P + (btype != 2 ? bsize : regen);      /* cz_tile_kernel / cz_huf_kernel put this block's output in place */
+            else if (btype == 0) { wx_wg_g2w(rw, P, bsrc, bsize, tid, nthreads); P_end = P + bsize; }            /* Raw, block_decoder.cairo:97-103 */
+            else if (btype == 1) { wx_wg_fill(rw, P, bsrc[0], bsize, tid, nthreads); P_end = P + bsize; }        /* RLE :104-123 */
+            else {
+                cz_gcptr lbase = (cz_gcptr)(uintptr_t)wx_ptr(cz_uni(ctl.lit_lo), cz_uni(ctl.lit_hi));
+                const int lit_rle = (int)cz_uni(ctl.lit_rle); const uint32_t rle_byte = cz_uni(ctl.lit_byte), lit_len = cz_uni(ctl.lit_len);
+                uint32_t L_end = 0;
+                if (nseq) {
+                    const uint32_t mapflags = cz_uni(ctl.mapflags);
+                    cz_gcptr mp = (cz_gcptr)(uintptr_t)wx_ptr(cz_uni(ctl.maps_lo), cz_uni(ctl.maps_hi));
+                    if (tid < 80u) {                                    /* the maps of the tables this block defined: 80 x 16 bytes */
+                        const uint32_t which = tid < 32u ? 1u : (tid < 64u ? 4u : 2u);
+                        if (mapflags & which) { const uint4 v = cz_ldu128(mp + 16u * tid); *(uint4*)(ctl.maps + 16u * tid) = v; }
+                    }
+                    __syncthreads();
+                    const cz_gcptr64 recp = (cz_gcptr64)(uintptr_t)wx_ptr(cz_uni(ctl.rec_lo), cz_uni(ctl.rec_hi));
+                    const cz_gcptr bitp = (cz_gcptr)(uintptr_t)wx_ptr(cz_uni(ctl.bits_lo), cz_uni(ctl.bits_hi));
+                    const uint32_t nch = (nseq + 63u) >> 6;
+                    uint32_t c0 = 0; int give_up = 0;
+                    for (;;) {
+                        /* one pass = as many chunks as fit the window; nothing of the pass is final yet */
+                        for (uint32_t i = tid; i < WX_RING / 32u + 4u; i += nthreads) ctl.fin[i] = 0;
+                        if (tid == 0) ctl.reset_at = WX_INF;
+                        __syncthreads();
+                        wx_block_sequences(ctl, ring, (cz_gcptr)out, recp, nseq, bitp, lbase, lit_len, lit_rle, rle_byte, cap, wave, nwaves, wbase, c0, wxp);
+                        __syncthreads();
+                        WX_PROF_T0();
+                        const uint32_t cs = cz_uni(ctl.reset_at);
+                        if (cz_uni(wx_ld(&ctl.err)) || (cs != WX_INF && (cs <= c0 || cs >= nch))) { give_up = 1; break; }
+                        if (cs == WX_INF) break;
+                        /* the window is full: its bytes go to HBM, and it starts again at the position before chunk cs (whose entries are
+                           cleared of what the pass published of them: a chunk's sums say its wave has got there) */
+                        const uint32_t pmid = cz_uni(ctl.slot[(cs - 1u) & (WX_NS - 1u)][3]);
+                        wx_wg_flush(ring - wbase, wbase, out + wbase, pmid - wbase, tid, nthreads);
+                        if (tid < WX_NS && (ctl.slot[tid][0] >> 3) > cs) ctl.slot[tid][0] = 0;
+                        wbase = pmid; c0 = cs;
+                        __syncthreads();
+                    }
+                    if (give_up) { ok = 0; break; }
+                    const uint32_t* se = ctl.slot[(nch - 1u) & (WX_NS - 1u)];   /* the last chunk's entry */
+                    P_end = cz_uni(se[3]); L_end = cz_uni(se[4]);
+                    if (P_end > cap || L_end > lit_len) { ok = 0; break; }
+                    if (tid == 0) { ctl.hist[0] = se[5]; ctl.hist[1] = se[6]; ctl.hist[2] = se[7]; }
+                }
+                /* literals behind the last sequence — for a block without sequences, all of them (sequence_execution.cairo:72-78, block_decoder.cairo:229-232) */
+                const uint32_t rest = lit_len - L_end;
+                if (P_end + rest > cap || rest > WX_RING) { ok = 0; break; }
+                if (P_end + rest - wbase > WX_RING) {                   /* no room behind the sequences' output: that goes to HBM first */
+                    wx_wg_flush(ring - wbase, wbase, out + wbase, P_end - wbase, tid, nthreads);
+                    wbase = P_end;
+                    __syncthreads();
+                }
+                if (rest) { if (lit_rle) wx_wg_fill(ring - wbase, P_end, rle_byte, rest, tid, nthreads); else wx_wg_g2w(ring - wbase, P_end, lbase + L_end, rest, tid, nthreads); }
+                P_end += rest;
+            }
+            __syncthreads();
+            if (!predone) wx_wg_flush(ring - wbase, wbase, out + wbase, P_end - wbase, tid, nthreads);
+            /* (later blocks read these bytes from HBM: the barrier at the top of the loop orders the stores before those loads — the
+               waves of a workgroup share their CU's L1, which writes through) */
+            if (tid == 0) { ctl.P = P_end; ctl.blocks += 1; }
+            WX_PROF_ACC(5);
+        }
+        __syncthreads();
+        if (ok && tid == 0) {
+            /* frame_decoder.cairo:189-200: the last block was the frame's last; the stored content checksum follows it */
+            uint32_t ck = 0, fl = CZ_RESULT_FINISHED; uint64_t pos = w.end; int good = 1;
+            if (w.has_checksum) { if (w.len - w.end >= 4) { ck = (uint32_t)czs_ld8(w.src, w.len, pos); fl |= CZ_RESULT_HAS_CHECKSUM; pos += 4; } else good = 0; }
+            if (good) {
+                cz_frame_result r; r.status = 0; r.blocks_decoded = ctl.blocks; r.bytes_consumed = pos; r.bytes_produced = ctl.P; r.checksum_from_data = ck; r.flags = fl;
+                r.detail[0] = ctl.blocks; r.detail[1] = pos; r.calculated_checksum = 0; r.reserved = 0;
+                a.results[f] = r;
+                a.frame_pre[f] |= CZ_PRE_WXDONE;
+                atomicAdd(&a.scan_ctl[209], 1u);
+            } else ok = 0;
+        }
+        if (!ok && tid == 0 && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }   /* cz_decode_frames_kernel does it from scratch and reports what is wrong with it */
+    }
+#ifdef CZ_PROFILE
+    if ((tid & 63u) == 0 && a.prof) for (int i = 0; i < 10; i++) atomicAdd(&a.prof[40 + i], wxp[i]);
+#endif
+}

@@ -162,6 +162,26 @@ int cz_context_last_exec_ms(cz_context* ctx, float* ms);
  * cz_decode_frames_kernel's record path instead (the round-2 arrangement, kept for A/B runs: bench.py --no-exec-kernel).
  * Batches that start from a dictionary (cz_context_set_dictionary) always take cz_decode_frames_kernel. */
 int cz_context_set_exec_kernel(cz_context* ctx, int on);
+/* With both arenas set, the frames that hold enough sequences to be worth a workgroup can also be executed by cz_wexec_kernel:
+ * 16 waves per frame, the output of the block in hand in a 128 KiB LDS window (earlier blocks are read from the output buffer;
+ * a block that regenerates more than the window is done in several passes), the three values the reference carries from sequence
+ * to sequence (output position, literal cursor, offset history: sequence_execution.cairo:12-129, scratch.cairo:11-19) composed
+ * across chunks of 64 sequences by a look-back, match sources ordered byte by byte through a bitmap of final bytes.  It runs SIDE BY
+ * SIDE with cz_execute_frames_kernel, on half of the CUs, and the two share the frames (each claims a frame before it starts on
+ * it): one is bound by instruction issue, the other by the rate of random reads from HBM.  Whether a batch is executed this way is
+ * decided on the device, from the offset-code tables of its blocks (cz_chain_kernel sums them up): only when far offsets outweigh
+ * near ones — with near offsets the waves of a frame wait on each other's bytes and a workgroup is no faster than one wave.
+ * A frame cz_wexec_kernel cannot finish (a check of execute_sequences fails) goes to cz_decode_frames_kernel, which reports the
+ * reference's status.  on = 1, the default; on = 0: cz_execute_frames_kernel alone (A/B runs: bench.py --no-wexec-kernel). */
+int cz_context_set_wexec_kernel(cz_context* ctx, int on);
+/* A/B knobs: CUs cz_wexec_kernel runs on (0: half of them), frames per such CU that cz_execute_frames_kernel leaves to it at the end
+ * of a batch (0: the default, 7), force = 1: side by side whatever the batch's offsets look like (tests use it). */
+int cz_context_set_wexec_tuning(cz_context* ctx, int cus, int leave_per_cu, int force);
+/* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it
+ * handed on to cz_decode_frames_kernel. */
+int cz_context_last_wexec_counts(cz_context* ctx, size_t* listed, size_t* finished, size_t* given_up);
+/* The part of the most recent launch spent in cz_wexec_kernel (0 when it did not run). */
+int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
 
 /* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the
  * per-phase shader-cycle sums accumulated by the kernels; returns the number of phases written

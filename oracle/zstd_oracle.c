@@ -636,6 +636,9 @@ static inline void fse_update_state(const fse_table* t, rbr* br, fse_entry* st) 
 }
 /* sequence_section_decoder.cairo:35-71, :73-195, :197-297 (the RLE and non-RLE loops
    differ only in skipping init/update for RLE'd tables, so they are one loop here). */
+/* diagnostic hook (czo_fse_sync_study): called with the tables of a block set up and the reader at the first bit of its
+   sequence bitstream; never set by the decode entry points */
+static void (*g_seq_hook)(const scratch* s, const seq_header* h, const rbr* br) = NULL;
 static int decode_sequences(scratch* s, const seq_header* h, const uint8_t* src, size_t len) {
     size_t used, off = 0; int e;
     unsigned m = h->modes;                                  /* sequence_section.cairo:47-57 */
@@ -648,6 +651,7 @@ static int decode_sequences(scratch* s, const seq_header* h, const uint8_t* src,
 
     rbr br; rbr_init(&br, src + off, len - off);            /* :42-44 */
     if (rbr_skip_padding(&br)) return CZ_E_SEQ_EXTRA_PADDING; /* :46-64 */
+    if (g_seq_hook) g_seq_hook(s, h, &br);
 
     fse_entry ll = {0,0,0}, ml = {0,0,0}, of = {0,0,0};     /* FSEDecoderTrait::new, fse_decoder.cairo:65-72 */
     if (s->ll.accuracy_log && s->ll.decode) ll = s->ll.decode[0];
@@ -1154,6 +1158,134 @@ CZO_API int czo_decode_single_block(const uint8_t* src, size_t len, uint8_t* dst
     *written = s.buf_len; *consumed = 3 + body;
     s.buf = NULL; scratch_free(&s); return e;
 }
+
+/* ------------------------------------------------------------------ diagnostic: do the three FSE chains resynchronise?
+ * (a feasibility study for segment-speculative chains; test infrastructure, zero GPU time.)
+ * For every block with at least min_nseq sequences: the true trajectory — bit position and the three table states before each
+ * sequence (sequence_section_decoder.cairo:223-286) — then `starts` speculative decoders, each begun at a random bit position with
+ * the states an initialisation AT that position would read (fse_decoder.cairo:78-91), stepped until it stands on a position of
+ * the true trajectory with states that behave the same from there on (same table cell, or a cell with the same symbol, bits and
+ * base line; a table whose every cell has one symbol and no bits is ignored), for at most max_steps steps.
+ * hist[d] += 1 for a start that needed d steps (d <= max_steps), hist[max_steps + 1] for one that did not get there;
+ * sum[0] blocks studied, [1] starts, [2] sequences in those blocks, [3] bits in their streams, [4] steps on which the position was
+ * on the true trajectory but the states were not. */
+typedef struct { uint64_t* hist; uint64_t* sum; uint32_t min_nseq, starts, max_steps; uint64_t rng; } sync_cfg;
+static sync_cfg g_sync;
+static inline uint64_t sync_rand(void) { uint64_t z = (g_sync.rng += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static int sync_degenerate(const fse_table* t, int rle) {
+    if (rle >= 0) return 1;
+    const size_t n = (size_t)1 << t->accuracy_log;
+    for (size_t i = 0; i < n; i++) if (t->decode[i].symbol != t->decode[0].symbol || t->decode[i].num_bits != 0) return 0;
+    return 1;
+}
+static inline int sync_same(const fse_table* t, uint32_t a, uint32_t b) {
+    return a == b || (t->decode[a].symbol == t->decode[b].symbol && t->decode[a].num_bits == t->decode[b].num_bits && t->decode[a].base_line == t->decode[b].base_line);
+}
+/* one step from (br, states): the sequence's extra bits, then the three state updates (LL, ML, OF); 0 ok, 1 invalid code */
+static inline int sync_step(const scratch* s, rbr* br, uint32_t* ill, uint32_t* iml, uint32_t* iof, int dll, int dml, int dof) {
+    const uint8_t lc = s->ll_rle >= 0 ? (uint8_t)s->ll_rle : s->ll.decode[*ill].symbol;
+    const uint8_t mc = s->ml_rle >= 0 ? (uint8_t)s->ml_rle : s->ml.decode[*iml].symbol;
+    const uint8_t oc = s->of_rle >= 0 ? (uint8_t)s->of_rle : s->of.decode[*iof].symbol;
+    uint32_t v; unsigned lnb, mnb; uint64_t t;
+    lookup_ll_code(lc, &v, &lnb); lookup_ml_code(mc, &v, &mnb);
+    if (oc >= 32 || lnb > 56 || mnb > 56) return 1;
+    rbr_get(br, oc, &t); rbr_get(br, mnb, &t); rbr_get(br, lnb, &t);
+    (void)dll; (void)dml; (void)dof;
+    if (s->ll_rle < 0) { rbr_get(br, s->ll.decode[*ill].num_bits, &t); *ill = s->ll.decode[*ill].base_line + (uint32_t)t; }
+    if (s->ml_rle < 0) { rbr_get(br, s->ml.decode[*iml].num_bits, &t); *iml = s->ml.decode[*iml].base_line + (uint32_t)t; }
+    if (s->of_rle < 0) { rbr_get(br, s->of.decode[*iof].num_bits, &t); *iof = s->of.decode[*iof].base_line + (uint32_t)t; }
+    return 0;
+}
+static void sync_hook(const scratch* s, const seq_header* h, const rbr* br0) {
+    const uint32_t n = h->num_sequences;
+    if (n < g_sync.min_nseq || br0->pos <= 0) return;
+    const int64_t nbits = br0->pos;
+    const int dll = sync_degenerate(&s->ll, s->ll_rle), dml = sync_degenerate(&s->ml, s->ml_rle), dof = sync_degenerate(&s->of, s->of_rle);
+    int32_t* seq_at = (int32_t*)malloc(((size_t)nbits + 1) * sizeof(int32_t));
+    uint32_t* st = (uint32_t*)malloc((size_t)n * 3 * sizeof(uint32_t));
+    if (!seq_at || !st) { free(seq_at); free(st); return; }
+    memset(seq_at, 0xFF, ((size_t)nbits + 1) * sizeof(int32_t));
+    /* the true trajectory */
+    rbr br = *br0; uint64_t t; uint32_t ill = 0, iml = 0, iof = 0;
+    if (s->ll_rle < 0) { rbr_get(&br, s->ll.accuracy_log, &t); ill = (uint32_t)t; }
+    if (s->of_rle < 0) { rbr_get(&br, s->of.accuracy_log, &t); iof = (uint32_t)t; }
+    if (s->ml_rle < 0) { rbr_get(&br, s->ml.accuracy_log, &t); iml = (uint32_t)t; }
+    uint32_t good = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (br.pos < 0) break;
+        seq_at[br.pos] = (int32_t)i; st[3 * i] = ill; st[3 * i + 1] = iml; st[3 * i + 2] = iof; good = i + 1;
+        if (sync_step(s, &br, &ill, &iml, &iof, dll, dml, dof)) break;
+    }
+    if (good < n) { free(seq_at); free(st); return; }
+    g_sync.sum[0] += 1; g_sync.sum[2] += n; g_sync.sum[3] += (uint64_t)nbits;
+    for (uint32_t k = 0; k < g_sync.starts; k++) {
+        rbr sb = *br0; sb.pos = 1 + (int64_t)(sync_rand() % (uint64_t)nbits);
+        uint32_t a = 0, b = 0, c = 0;
+        if (s->ll_rle < 0) { rbr_get(&sb, s->ll.accuracy_log, &t); a = (uint32_t)t; }
+        if (s->of_rle < 0) { rbr_get(&sb, s->of.accuracy_log, &t); c = (uint32_t)t; }
+        if (s->ml_rle < 0) { rbr_get(&sb, s->ml.accuracy_log, &t); b = (uint32_t)t; }
+        uint32_t d = 0; int hit = 0;
+        for (; d <= g_sync.max_steps && sb.pos > 0; d++) {
+            const int32_t i = seq_at[sb.pos];
+            if (i >= 0) {
+                if ((dll || sync_same(&s->ll, a, st[3 * i])) && (dml || sync_same(&s->ml, b, st[3 * i + 1])) && (dof || sync_same(&s->of, c, st[3 * i + 2]))) { hit = 1; break; }
+                g_sync.sum[4] += 1;
+            }
+            if (sync_step(s, &sb, &a, &b, &c, dll, dml, dof)) break;
+        }
+        g_sync.sum[1] += 1;
+        g_sync.hist[hit ? d : g_sync.max_steps + 1] += 1;
+    }
+    free(seq_at); free(st);
+}
+CZO_API int czo_fse_sync_study(const uint8_t* src, size_t len, size_t cap, uint32_t min_nseq, uint32_t starts, uint32_t max_steps, uint64_t seed,
+                               uint64_t* hist, uint64_t* sum) {
+    uint8_t* dst = (uint8_t*)malloc(cap ? cap : 1); uint64_t info[8];
+    if (!dst) return CZ_E_INVALID_ARG;
+    g_sync.hist = hist; g_sync.sum = sum; g_sync.min_nseq = min_nseq; g_sync.starts = starts; g_sync.max_steps = max_steps; g_sync.rng = seed;
+    g_seq_hook = sync_hook;
+    const int e = czo_decode_frame(src, len, dst, cap, info);
+    g_seq_hook = NULL;
+    free(dst);
+    return e;
+}
+
+
+/* diagnostic: the sequences of every block of a frame as (ll, ml, offset_value) triples, appended to out[] (cap triples); returns the status, *count = triples written */
+static uint32_t* g_dump_out; static size_t g_dump_cap, g_dump_n;
+static void dump_hook(const scratch* s, const seq_header* h, const rbr* br0) {
+    rbr br = *br0; uint64_t t; uint32_t ill = 0, iml = 0, iof = 0;
+    if (s->ll_rle < 0) { rbr_get(&br, s->ll.accuracy_log, &t); ill = (uint32_t)t; }
+    if (s->of_rle < 0) { rbr_get(&br, s->of.accuracy_log, &t); iof = (uint32_t)t; }
+    if (s->ml_rle < 0) { rbr_get(&br, s->ml.accuracy_log, &t); iml = (uint32_t)t; }
+    for (uint32_t i = 0; i < h->num_sequences; i++) {
+        const uint8_t lc = s->ll_rle >= 0 ? (uint8_t)s->ll_rle : s->ll.decode[ill].symbol;
+        const uint8_t mc = s->ml_rle >= 0 ? (uint8_t)s->ml_rle : s->ml.decode[iml].symbol;
+        const uint8_t oc = s->of_rle >= 0 ? (uint8_t)s->of_rle : s->of.decode[iof].symbol;
+        uint32_t lv, mv; unsigned lnb, mnb; uint64_t ob, mb, lb;
+        lookup_ll_code(lc, &lv, &lnb); lookup_ml_code(mc, &mv, &mnb);
+        if (oc >= 32 || lnb > 56 || mnb > 56) return;
+        rbr_get(&br, oc, &ob); rbr_get(&br, mnb, &mb); rbr_get(&br, lnb, &lb);
+        if (g_dump_n < g_dump_cap) { g_dump_out[3 * g_dump_n] = lv + (uint32_t)lb; g_dump_out[3 * g_dump_n + 1] = mv + (uint32_t)mb; g_dump_out[3 * g_dump_n + 2] = (uint32_t)ob + (1u << oc); }
+        g_dump_n++;
+        if (i + 1 < h->num_sequences) {
+            if (s->ll_rle < 0) { rbr_get(&br, s->ll.decode[ill].num_bits, &t); ill = s->ll.decode[ill].base_line + (uint32_t)t; }
+            if (s->ml_rle < 0) { rbr_get(&br, s->ml.decode[iml].num_bits, &t); iml = s->ml.decode[iml].base_line + (uint32_t)t; }
+            if (s->of_rle < 0) { rbr_get(&br, s->of.decode[iof].num_bits, &t); iof = s->of.decode[iof].base_line + (uint32_t)t; }
+        }
+    }
+}
+CZO_API int czo_dump_sequences(const uint8_t* src, size_t len, size_t cap, uint32_t* out, size_t out_cap, size_t* count) {
+    uint8_t* dst = (uint8_t*)malloc(cap ? cap : 1); uint64_t info[8];
+    if (!dst) return CZ_E_INVALID_ARG;
+    g_dump_out = out; g_dump_cap = out_cap; g_dump_n = 0;
+    g_seq_hook = dump_hook;
+    const int e = czo_decode_frame(src, len, dst, cap, info);
+    g_seq_hook = NULL; free(dst);
+    *count = g_dump_n;
+    return e;
+}
+
 CZO_API int czo_abi_version(void) { return 1; }
 
 /* ------------------------------------------------------------------ bench.py's second CPU baseline

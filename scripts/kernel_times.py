@@ -30,17 +30,31 @@ def child(kind, n):
         if os.environ.get("CZ_LITPASS", "1") == "1":
             ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
         ctx.set_exec_kernel(os.environ.get("CZ_EXEC", "1") == "1")
-    tot, ch, ex, lt = [], [], [], []
+        wxe = os.environ.get("CZ_WEXEC", "1").split(",")               # on[,cus[,leave_per_cu[,force]]]
+        ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=len(wxe) > 3 and wxe[3] == "1")
+    tot, ch, ex, lt, wx = [], [], [], [], []
     for it in range(5):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
         tot.append(ctx.last_kernel_ms())
         ch.append(ctx.last_chain_ms())
         ex.append(ctx.last_exec_ms())
+        wx.append(ctx.last_wexec_ms())
         lt.append(ctx.last_literals_tail_ms())
     res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
     ok = bool((res["status"] == 0).all() and (res["bytes_produced"] == b.regen).all())
+    if os.environ.get("CZ_CHECK", "0") == "1":                          # every frame against the CPU oracle
+        import oracle
+        got = t_out.cpu().numpy()
+        nbad = 0
+        for i in range(n):
+            st, ref, _ = oracle.decode_frame(b.frame(i), cap=int(out_cap[i]))
+            o = int(out_off[i])
+            if st != 0 or bytes(got[o:o + len(ref)]) != ref:
+                nbad += 1
+        ok = ok and nbad == 0
+        print(f"oracle check: {nbad} of {n} frames differ", flush=True)
     print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
-          f"lit tail {np.mean(lt[2:]):6.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  main {np.mean(tot[2:]) - np.mean(ch[2:]) - np.mean(ex[2:]):8.3f} ms  ok={ok}", flush=True)
+          f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  ok={ok}", flush=True)
     ctx.close()
 
 

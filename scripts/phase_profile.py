@@ -56,12 +56,14 @@ def main():
     rv = [buf[50 + i] for i in range(6)]
     if sum(rv[:4]):
         print(f"  refill events {rv[5]}: pull+stage {rv[0] / max(rv[5], 1):.0f}, own tables {rv[1] / max(rv[5], 1):.0f}, repeat rounds {rv[2] / max(rv[5], 1):.0f}, build {rv[3] / max(rv[5], 1):.0f} ticks each")
-    xv = [buf[40 + i] for i in range(9)]
-    if sum(xv):
-        xt = sum(xv)
-        print(f"cz_execute_frames_kernel thread-0 time shares (s_memtime ticks; {ctx.last_exec_ms():.3f} ms of the launch):")
-        for name, v in zip(["headers+parse", "huffman table", "huffman streams", "maps", "pass 1", "pass 2", "pass 3", "flush", "raw/rle/tail"], xv):
-            print(f"  {name:15s} {100.0 * v / xt:5.1f} %   {v / n:10.0f} ticks/frame")
+    xv = [buf[40 + i] for i in range(10)]
+    if sum(xv[:6]):
+        xt = sum(xv[:4]) or 1
+        print(f"cz_wexec_kernel wave-time shares (s_memtime ticks summed over waves; {ctx.last_wexec_ms():.3f} ms of the launch; {xv[9]} chunks):")
+        for name, v in zip(["values+scans", "look-back", "checks+literals", "matches"], xv[:4]):
+            print(f"  {name:15s} {100.0 * v / xt:5.1f} %   {v / max(xv[9], 1):10.0f} ticks/chunk")
+        print(f"  frame setup+headers {xv[4] / 64 / n:.0f} ticks/frame/wave, flush+tail {xv[5] / 64 / n:.0f} (per wave of 16)")
+        print(f"  look-back retries {xv[6]}, match rounds {xv[7]} ({xv[7] / max(xv[9], 1):.2f} per chunk), waits for earlier chunks {xv[8]} ({xv[8] / max(xv[9], 1):.2f} per chunk)")
 
 
 if __name__ == "__main__":

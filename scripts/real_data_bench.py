@@ -63,16 +63,18 @@ t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
 ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
 ctx.set_chain_arena(comp * 8 + (64 << 20))
 ctx.set_literal_arena(n * SZ + (16 << 20))
-ms, ch, ex = [], [], []
+ctx.set_wexec_kernel(os.environ.get("CZ_WEXEC", "1") != "0", force=os.environ.get("CZ_WEXEC", "1") == "force")
+torch.cuda.synchronize()                                                # (the context runs on a stream of its own)
+ms, ch, ex, wx = [], [], [], []
 for it in range(5):
     ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
-    ms.append(ctx.last_kernel_ms()); ch.append(ctx.last_chain_ms()); ex.append(ctx.last_exec_ms())
+    ms.append(ctx.last_kernel_ms()); ch.append(ctx.last_chain_ms()); ex.append(ctx.last_exec_ms()); wx.append(ctx.last_wexec_ms())
 res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
 out = t_out.cpu().numpy()
-ok = bool((res["status"] == 0).all()) and all(out[i * SZ:(i + 1) * SZ].tobytes() == origs[i] for i in range(0, n, 17))
+ok = bool((res["status"] == 0).all()) and all(out[i * SZ:(i + 1) * SZ].tobytes() == origs[i] for i in range(0, n, int(os.environ.get("CZ_CHECK_EVERY", "17"))))
 k = float(np.mean(ms[2:]))
 print(f"{n} frames of {SZ} B, libzstd level {level}: ratio {n * SZ / comp:.2f}, all decoded and checked: {ok}")
-print(f"  GPU step {k:.3f} ms (chain {np.mean(ch[2:]):.3f}, execute {np.mean(ex[2:]):.3f}) = {n * SZ / k / 1e6:.1f} GB/s decoded, {(n * SZ + comp) / k / 1e6:.1f} GB/s algorithmic ({(n * SZ + comp) / k / 1e6 / 8000:.3f} of 8 TB/s)")
+print(f"  GPU step {k:.3f} ms (chain {np.mean(ch[2:]):.3f}, wexec {np.mean(wx[2:]):.3f}, execute {np.mean(ex[2:]):.3f}) = {n * SZ / k / 1e6:.1f} GB/s decoded, {(n * SZ + comp) / k / 1e6:.1f} GB/s algorithmic ({(n * SZ + comp) / k / 1e6 / 8000:.3f} of 8 TB/s)")
 t0 = time.time()
 good = oracle.libzstd_batch(base, in_off, lens, out_off, out_cap, n * SZ + 64, out_cap, nthreads=os.cpu_count() or 8)
 dt = time.time() - t0

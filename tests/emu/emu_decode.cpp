@@ -13,6 +13,7 @@
 thread_local emu_dim3 threadIdx;
 thread_local emu_dim3 blockIdx;
 emu_dim3 gridDim;
+emu_dim3 blockDim;
 pthread_barrier_t emu_barrier;
 pthread_barrier_t emu_wbar[EMU_MAX_WAVES];
 volatile uint64_t emu_xchg_all[EMU_MAX_WAVES][64];
@@ -42,6 +43,7 @@ static void* emu_watchdog(void*) {
 #include "czstd_kernels.hip"
 #include "czstd_chain.hip"
 #include "czstd_pre.hip"
+#include "czstd_wexec.hip"
 #define CZ_EXEC_ONLY 1
 namespace czx {
 #include "czstd_kernels.hip"
@@ -53,11 +55,12 @@ static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2) czx::cz_execute_frames_kernel(la->a);
+    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2 || la->which == 11) czx::cz_execute_frames_kernel(la->a);
     else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
     else if (la->which == 7) cz_huf_kernel(la->a);
     else if (la->which == 9) cz_huf1_kernel(la->a);
     else if (la->which == 8) cz_tile_kernel(la->a);
+    else if (la->which == 10) cz_wexec_kernel(la->a);
     else if (la->which >= 4) cz_scan_kernel(la->a);                     /* 4, 5: the two passes of the block scan */
     else cz_decode_frames_kernel(la->a);
     emu_lane_done[la->lane] = 1;
@@ -88,10 +91,10 @@ int main(int argc, char** argv) {
     a.in_base = in_exact; a.in_off = in_off.data(); a.in_len = in_len.data();
     a.out_base = out; a.out_off = out_off.data(); a.out_cap = out_cap.data();
     a.results = res.data(); a.tasks = nullptr; a.n = (uint32_t)n; a.work_counter = &counter;
-    a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES; a.verify_checksum = 1;
+    a.lit_scratch = lit; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES; a.verify_checksum = getenv("EMU_VERIFY") ? (uint32_t)atoi(getenv("EMU_VERIFY")) : 1u;
     /* EMU_CHAIN=<bytes>: run the FSE-chain pre-pass first, with an arena of that many bytes */
     const char* ce = getenv("EMU_CHAIN");
-    unsigned long long chain_top[4] = {0, 0, 0, 0}; uint32_t chain_counter = 0;
+    unsigned long long chain_top[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t chain_counter = 0;
     std::vector<uint64_t> frame_first(n ? n : 1, 0);
     uint64_t* arena = nullptr;
     if (ce && atoll(ce) > 0) {
@@ -115,6 +118,10 @@ int main(int argc, char** argv) {
     }
     /* launches: [scan, huff0 and tile kernels, chain pre-pass, [cz_execute_frames_kernel (EMU_EXEC=1),]] main kernel (behind cz_execute_frames_kernel: the frames it left) */
     const int with_exec = arena && lit_bytes && getenv("EMU_EXEC") && atoi(getenv("EMU_EXEC")) > 0;
+    /* EMU_WEXEC=<waves>: cz_wexec_kernel (that many waves per workgroup) ahead of cz_execute_frames_kernel */
+    const int wx_waves = with_exec && getenv("EMU_WEXEC") ? atoi(getenv("EMU_WEXEC")) : 0;
+    std::vector<uint32_t> wx_list(n ? n : 1, 0); uint32_t wx_counter = 0;
+    if (wx_waves > 0) { a.wx_list = wx_list.data(); a.wx_counter = &wx_counter; a.wx_force = getenv("EMU_WX_AUTO") ? 0u : 1u; a.wx_leave = 0; }   /* forced on unless EMU_WX_AUTO: the batch's offset codes decide, as on the device */
     uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
     std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order, scan_wave;
     if (arena) {
@@ -152,14 +159,17 @@ int main(int argc, char** argv) {
        "done" and takes every literals section; default: it sees it done at once and cz_huf_kernel takes them all */
     const int huf1_all = getenv("EMU_HUF1") && atoi(getenv("EMU_HUF1")) > 0;
     a.chain_grid = (uint32_t)grid;
-    const int order[8] = {4, 5, 0, 9, 7, 8, 2, 1};
-    for (int pi = arena ? 0 : 7; pi < 8; pi++) {
+    const int order[10] = {4, 5, 0, 9, 7, 8, 10, 2, 11, 1};            /* 2 / 11: cz_execute_frames_kernel beside / behind cz_wexec_kernel (10) */
+    for (int pi = arena ? 0 : 9; pi < 10; pi++) {
         const int which = order[pi];
-        if (which == 2 && !with_exec) continue;
+        if ((which == 2 || which == 11) && !with_exec) continue;
+        if (which == 10 && wx_waves <= 0) continue;
+        if (which == 11) continue;
         if ((which == 7 || which == 8 || which == 9) && !lit_bytes) continue;
-        const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : 64);
+        const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : (which == 10 ? 64 * wx_waves : 64));
+        blockDim.x = (unsigned)nthreads;
 
-        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 || which == 9 ? 1 : grid);
+        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 || which == 9 || which == 10 ? 1 : grid);
         emu_nthreads = nthreads; gridDim.x = (unsigned)nblocks;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
         for (int b = 0; b < nblocks; b++) {
@@ -181,6 +191,7 @@ int main(int argc, char** argv) {
         free(lit_arena);
     }
     if (with_exec) fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_execute_frames_kernel\n", (unsigned long long)(n - fallback_count));
+    if (wx_waves > 0) { unsigned long long nd = 0; for (uint64_t i = 0; i < n; i++) nd += (frame_pre[i] & CZ_PRE_WXDONE) != 0; fprintf(stderr, "EMU_WEXEC: %u frames listed, %llu finished by cz_wexec_kernel\n", scan_ctl[206], nd); }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {
         fwrite(&res[i], sizeof(cz_frame_result), 1, g);

@@ -24,6 +24,7 @@ struct emu_dim3 { unsigned x, y, z; };
 extern thread_local emu_dim3 threadIdx;
 extern thread_local emu_dim3 blockIdx;
 extern emu_dim3 gridDim;                  /* blocks of the launch in flight (set by the harness) */
+extern emu_dim3 blockDim;                 /* threads per block of the launch in flight */
 struct uint4 { uint32_t x, y, z, w; };
 
 /* A workgroup is EMU_MAX_WAVES waves at most: emu_barrier joins all its threads (__syncthreads), emu_wbar[w]
@@ -109,4 +110,5 @@ static inline int __ffsll(long long v) { return v ? __builtin_ctzll((unsigned lo
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline uint32_t atomicExch(uint32_t* p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }

@@ -19,7 +19,7 @@ def build(target="emu_decode"):
     return os.path.join(EMU_DIR, target)
 
 
-def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None):
+def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None, wexec_waves=0, verify=True):
     exe = build(target)
     with tempfile.TemporaryDirectory() as td:
         inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
@@ -31,6 +31,9 @@ def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kern
         env = dict(os.environ, EMU_CHAIN=str(int(chain_bytes)), EMU_EXEC="1" if exec_kernel else "0", EMU_LIT=str(int(lit_bytes)), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
         if dict_path:
             env["EMU_DICT"] = dict_path
+        if wexec_waves:
+            env["EMU_WEXEC"] = str(int(wexec_waves))
+        env["EMU_VERIFY"] = "1" if verify else "0"
         p = subprocess.run([exe, inp, outp], capture_output=True, timeout=timeout, env=env)
         run.last_stderr = p.stderr.decode()[-2000:]
         if p.returncode != 0:

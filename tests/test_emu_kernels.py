@@ -13,8 +13,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0):
-    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes)
+def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0, wexec_waves=0, verify=True):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes, wexec_waves=wexec_waves, verify=verify)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -22,7 +22,7 @@ def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0
             bad.append((i, status.name(r["status"]), status.name(st)))
         elif st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"]):
             bad.append((i, "DATA"))
-        elif st == 0 and info["has_checksum"]:
+        elif st == 0 and info["has_checksum"] and verify:
             # the emulator runs with content-checksum verification on
             want = oracle.xxh64(ref) & 0xFFFFFFFF
             if not (r["flags"] & 4) or int(r["calculated_checksum"]) != want or bool(r["flags"] & 8) != (want == info["checksum"]):
@@ -135,6 +135,30 @@ def test_emu_execute_frames_kernel():
     assert "frames finished by cz_execute_frames_kernel" in err
     done = int(err.split("EMU_EXEC: ")[1].split()[0])
     assert 0 < done < len(frames), (done, len(frames))                  # some frames took it, the malformed ones did not
+
+def test_emu_wexec_kernel():
+    """cz_wexec_kernel (czstd_wexec.hip: several waves per frame, LDS window, look-back over chunk entries, bitmap of final bytes)
+    under ASan/UBSan with 4 waves per workgroup, ahead of cz_execute_frames_kernel and cz_decode_frames_kernel: corpus frames,
+    corpus-like frames (several blocks, sources in earlier blocks, long matches and literal runs, repeat offsets of every kind), a
+    frame whose second block regenerates more than the window holds, and damaged frames, which it hands on."""
+    frames, caps = [], []
+    for name, z, orig in corpus_pairs(max_orig=2500):
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    b = synth.generate("mix", 30, first_index=0, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:6] + [13]     # 13: 200 KB, a block above 128 KiB
+    frames += [b.frame(i) for i in keep]
+    caps += [int(b.regen[i]) + 8 for i in keep]
+    for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=700)):
+        rng = np.random.default_rng(900 + idx)
+        a = bytearray(z)
+        a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+        frames.append(bytes(a))
+        caps.append(len(orig) * 2 + 4096)
+    _run_and_compare(frames, caps, chain_bytes=16 << 20, lit_bytes=8 << 20, exec_kernel=True, wexec_waves=4, verify=False)
+    err = emu_runner.run.last_stderr
+    listed, done = int(err.split("EMU_WEXEC: ")[1].split()[0]), int(err.split("frames listed, ")[1].split()[0])
+    assert listed > 20 and 10 < done <= listed, (listed, done)
 
 
 def test_emu_d2_weight_log_10_unsupported():

@@ -571,6 +571,53 @@ def test_execute_frames_kernel_matches_oracle(cz):
     finally:
         c.close()
 
+@pytest.mark.parametrize("auto", [False, True])
+def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
+    """cz_wexec_kernel (a workgroup of 16 waves per frame, the block in hand in an LDS window, chunks of 64 sequences composed by a
+    look-back) side by side with cz_execute_frames_kernel, the two claiming frames from one batch: same results as the oracle.
+    Forced on (auto = False) every listed frame may go to either kernel — config 4a, config 4b (a block of 224 KiB: the window is
+    filled more than once), corpus-like multi-block frames (blocks above the format's 128 KiB, matches into earlier blocks, long
+    matches, `offset_value 3 with no literals`), the whole reference corpus (windows up to 3.5 MiB) and damaged frames, which it
+    must hand on.  auto = True: the device decides from the batch's offset codes, and takes the far-offset batch only."""
+    from cairo_zstd_amd import synth
+    c = cz.Context(0)
+    c.set_chain_arena(512 << 20, min_sequences=0)
+    c.set_literal_arena(256 << 20)
+    c.set_wexec_kernel(True, force=not auto)
+    try:
+        def run(frames, caps):
+            got = cz.decode_batch_host(frames, caps, c)
+            bad = []
+            for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, got)):
+                st, ref, info = oracle.decode_frame(fr, cap=cap)
+                if st != int(r["status"]) or (st == 0 and (out != ref or int(r["bytes_consumed"]) != info["consumed"] or int(r["blocks_decoded"]) != info["blocks"]
+                                                           or bool(r["flags"] & 2) != info["has_checksum"] or (info["has_checksum"] and int(r["checksum_from_data"]) != info["checksum"]))):
+                    bad.append((i, cz.status.name(r["status"]), cz.status.name(st)))
+            assert not bad, bad[:10]
+            return c.last_wexec_counts()
+        b = synth.generate("full_4a", 300, first_index=77)
+        listed, finished, handed = run([b.frame(i) for i in range(b.n)], [int(r) for r in b.regen])
+        assert listed == b.n and finished > 0 and handed == 0, (listed, finished, handed)   # far offsets: side by side in both modes
+        frames, caps = [], []
+        for kind, n in (("full_4b", 12), ("mix", 700)):
+            bb = synth.generate(kind, n, first_index=4711)
+            frames += [bb.frame(i) for i in range(n)]
+            caps += [int(r) + 16 for r in bb.regen]
+        for name, z, orig in corpus_pairs():
+            frames.append(z)
+            caps.append(len(orig) + 32)
+        for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=20000)):
+            for m in _mutations(z, idx)[:6]:
+                frames.append(m)
+                caps.append(len(orig) * 2 + 4096)
+        listed, finished, handed = run(frames, caps)
+        if auto:
+            assert finished == 0, (listed, finished, handed)            # near offsets: cz_execute_frames_kernel alone
+        else:
+            assert listed > 100 and finished > 50 and handed > 0, (listed, finished, handed)
+    finally:
+        c.close()
+
 
 def test_more_frames_than_resident_workgroups_with_prepass(cz):
     """Grid-size regression: both launches of the two-pass pipeline index per-workgroup scratch."""
