@@ -121,6 +121,12 @@ class Context:
         if st:
             raise CzError(st, "cz_context_set_wexec_tuning")
 
+    def last_sequence_stats(self):
+        """(near-offset, far-offset, long-run) sequence sums of the last launch (x 4), as cz_chain_kernel took them from the code tables."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().cz_context_last_sequence_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
+
     def last_wexec_counts(self):
         """(frames listed for cz_wexec_kernel, frames it finished, frames it handed on) in the last launch."""
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -937,7 +937,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             /* What the batch's offsets look like, for the execute stage (cz_wx_side_by_side): sequences (in units of 64) weighted by
                the share of their block's offset codes that are near (2..13: offsets below 16 KiB, which a frame's waves in
                cz_wexec_kernel would have to wait on each other for) and far (14 and up). */
-            if (got && a.wx_list) {
+            if (got && a.exec_counter) {
                 const uint32_t info = (binfo >> 10) & 0x3FFu, lg = info >> 6, np = (info & 63u) + 1u, n6 = (o_nseq + 63u) >> 6;
                 uint32_t nearc = 0, farc = 0;
                 if (rles[1] >= 0) { nearc = rles[1] >= 2 && rles[1] <= 13 ? 256u : 0u; farc = rles[1] >= 14 ? 256u : 0u; }
@@ -947,6 +947,19 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
                 if (nearc) atomicAdd(a.chain_top + 5, (unsigned long long)nearc * n6);
                 if (farc) atomicAdd(a.chain_top + 6, (unsigned long long)farc * n6);
+                /* ... and the share of sequences the execute kernel's fast loop does not take: a literal run above 8 bytes (LL code > 8)
+                   or a match above 16 (ML code > 13); the two shares are added (an upper bound) */
+                uint32_t longc = 0;
+                for (int t = 0; t < 3; t += 2) {
+                    const uint32_t inf = (binfo >> (10 * t)) & 0x3FFu, lgt = inf >> 6, npt = (inf & 63u) + 1u, lim = t == 0 ? 8u : 13u;
+                    if (rles[t] >= 0) longc += (uint32_t)rles[t] > lim ? 256u : 0u;
+                    else if (lgt) {
+                        uint32_t cl = 0;
+                        for (uint32_t sy = lim + 1u; sy < npt; sy++) { const int32_t pr = sl.probs[t][sy]; cl += pr > 0 ? (uint32_t)pr : 0u; }   /* ("less than one" symbols: rare by definition, and encoders list symbols they never use that way) */
+                        longc += (cl << 8) >> lgt;
+                    }
+                }
+                if (longc) atomicAdd(a.chain_top + 7, (unsigned long long)longc * n6);
             }
             CZC_PROF_ACC(10);
             /* build the tables of the refilled slots, each by the whole wave, slot after slot: LL and ML first (the slot's OF

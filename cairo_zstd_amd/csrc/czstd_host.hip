@@ -35,6 +35,19 @@
 namespace czx {
 #include "czstd_kernels.hip"
 }
+#undef CZ_EXEC_KERNEL
+/* ... and a third time with a register budget of 8 waves per SIMD: frames of short sequences with near offsets (config 4b), where
+   the execute kernel waits on its own recent stores rather than on HBM, run a quarter faster with twice the waves; long sequences
+   (the general loop) would spill at 64 registers.  Which of the two builds runs a batch is decided on the device (cz_exec_variant). */
+#undef CZ_EXEC_WAVES
+#define CZ_EXEC_WAVES 8
+#define CZ_EXEC_KERNEL cz_execute_frames8_kernel
+namespace czx8 {
+#include "czstd_kernels.hip"
+}
+#undef CZ_EXEC_KERNEL
+#undef CZ_EXEC_WAVES
+#define CZ_EXEC_WAVES 4
 #undef CZ_EXEC_ONLY
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
@@ -57,11 +70,12 @@ struct cz_context {
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
     bool wexec_kernel = true;              /* of those, frames of at most 128 KiB with enough sequences run on cz_wexec_kernel first (a workgroup per frame, window in LDS) */
     int wexec_cus = 0;                     /* CUs (= workgroups) cz_wexec_kernel runs on; 0: half of them */
+    uint32_t exec_variant_force = 0;       /* 0: cz_exec_variant decides; 4 / 8: that variant of cz_execute_frames_kernel (A/B runs) */
     uint32_t wexec_force = 0;              /* 0: the kernels decide from the batch's offset codes; 1: always side by side (A/B runs) */
     int wexec_leave_per_cu = 7;           /* frames per workgroup of cz_wexec_kernel that cz_execute_frames_kernel leaves to it at the end of a batch */
     bool wexec_ready = false; uint32_t* wx_list = nullptr; hipEvent_t ev_wx = nullptr; bool timed_wx = false;
     bool exec_kernel = true;               /* frames the pre-pass finished (chain records + literals) run on cz_execute_frames_kernel; 0: all on cz_decode_frames_kernel */
-    int exec_grid = 0;
+    int exec_grid = 0, exec8_grid = 0;
     uint32_t* fallback_list = nullptr;                                  /* n entries, allocated with frame_first */
     int last_grid = 0;
     int last_hip_error = 0;
@@ -220,6 +234,8 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, czx::cz_execute_frames_kernel, CZ_WG_THREADS, CZ_EXEC_DYN_LDS) != hipSuccess || occ <= 0) occ = 4;
         c->exec_grid = c->num_cu * occ;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, czx8::cz_execute_frames8_kernel, CZ_WG_THREADS, CZ_EXEC_DYN_LDS) != hipSuccess || occ <= 0) occ = 8;
+        c->exec8_grid = c->num_cu * occ;
     }
     CZ_HIP(c, hipMalloc((void**)&c->chain_arena, (bytes + 7) & ~(size_t)7));
     c->chain_capacity = bytes / 8;
@@ -277,7 +293,7 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
 }
 
 /* Frames the pre-pass finished run on cz_execute_frames_kernel (default, 1) or, like every other frame, on cz_decode_frames_kernel (0). */
-CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; return CZ_OK; }
+CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; c->exec_variant_force = on == 4 || on == 8 ? (uint32_t)on : 0u; return CZ_OK; }
 
 CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
 
@@ -323,6 +339,22 @@ CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) retur
 CZ_EXPORT int cz_context_set_wexec_tuning(cz_context* c, int cus, int leave_per_cu, int force) {
     if (!c || cus < 0 || leave_per_cu < 0) return CZ_E_INVALID_ARG;
     c->wexec_cus = cus; if (leave_per_cu) c->wexec_leave_per_cu = leave_per_cu; c->wexec_force = force ? 1u : 0u;
+    return CZ_OK;
+}
+/* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' code tables, in sequences
+   x 4 — with near offset codes (2..13), with far ones (14 and up), with a literal run above 8 or a match above 16 bytes: what
+   cz_wx_side_by_side and cz_exec_variant decide from. */
+CZ_EXPORT int cz_context_last_sequence_stats(cz_context* c, uint64_t* near_offsets, uint64_t* far_offsets, uint64_t* long_runs) {
+    if (!c) return CZ_E_INVALID_ARG;
+    uint64_t h[3] = {0, 0, 0};
+    if (c->chain_top) {
+        CZ_HIP(c, hipSetDevice(c->device));
+        CZ_HIP(c, hipStreamSynchronize(c->stream));
+        CZ_HIP(c, hipMemcpy(h, c->chain_top + 5, sizeof h, hipMemcpyDeviceToHost));
+    }
+    if (near_offsets) *near_offsets = h[0];
+    if (far_offsets) *far_offsets = h[1];
+    if (long_runs) *long_runs = h[2];
     return CZ_OK;
 }
 /* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it gave up. */
@@ -492,7 +524,8 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
 #ifdef CZ_EXPERIMENT
             if (const char* e = getenv("CZ_EXEC_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < egrid) egrid = g; }
 #endif
-            a.wx_leave = 0;
+            const int egrid8 = (int)(n < (size_t)c->exec8_grid ? n : (size_t)c->exec8_grid);
+            a.wx_leave = 0; a.exec_variant_force = c->exec_variant_force;
             if (use_wx) {
                 /* Two kernels execute the sequences side by side and share the frames (each claims a frame before it starts on it):
                    cz_wexec_kernel — a workgroup of 16 waves per frame, the block in hand in an LDS window: bound by instruction
@@ -509,6 +542,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 c->timed_wx = true;
                 CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_lit, 0));
                 hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a);
+                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
                 CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
                 CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -516,6 +550,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of its
                    own); it lists every frame it cannot do for cz_decode_frames_kernel */
                 hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
+                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
             }
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));

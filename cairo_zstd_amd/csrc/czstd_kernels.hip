@@ -58,6 +58,17 @@ __device__ static inline uint64_t cz_uni64(uint64_t v) { return ((uint64_t)cz_un
 __device__ static inline int cz_wx_side_by_side(const cz_batch_args& a) {
     return a.wx_list != nullptr && (a.wx_force ? a.wx_force == 1u : a.chain_top[6] > a.chain_top[5]);
 }
+/* Which build of cz_execute_frames_kernel runs this batch: 8 waves per SIMD (64 registers) when its offsets are near — then the
+   kernel waits on its own recent stores rather than on random reads from HBM, and twice the waves hide twice as much of that —
+   AND its code tables give next to no weight (under 1 sequence in 256) to literal runs above 8 or matches above 16 bytes, which
+   the fast loop does not take (the general loop spills at 64 registers); else 4 waves per SIMD.  Both builds are launched; the
+   other one returns at once. */
+__device__ static inline uint32_t cz_exec_variant(const cz_batch_args& a) {
+    if (a.exec_variant_force) return a.exec_variant_force;
+    if (!a.chain_top) return 4u;
+    const unsigned long long nearq = a.chain_top[5], farq = a.chain_top[6], longq = a.chain_top[7];
+    return nearq > farq && longq * 256ull < nearq + farq ? 8u : 4u;
+}
 #endif
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
  * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
@@ -2365,11 +2376,15 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_dict_setup_kernel
  * Same source as cz_decode_frames_kernel minus every decoder (no Huffman table, no FSE tables, no bit ring in LDS: 3 KB per
  * wave instead of 10.5 KB, and a register budget of its own).  Any other frame — and any frame that turns out to need a
  * decoder after all — is appended to args.fallback_list for cz_decode_frames_kernel. */
-extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) cz_execute_frames_kernel(cz_batch_args a) {
+#ifndef CZ_EXEC_KERNEL
+#define CZ_EXEC_KERNEL cz_execute_frames_kernel
+#endif
+extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EXEC_KERNEL(cz_batch_args a) {
 #ifdef CZ_PROFILE
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
 #endif
     if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
+    if (::cz_exec_variant(a) != CZ_EXEC_WAVES) return;                  /* the build with the other register budget runs this batch */
     const uint32_t total = a.n;
     const int wx_on = ::cz_wx_side_by_side(a);
     cz_init_llml();

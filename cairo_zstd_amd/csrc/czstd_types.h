@@ -106,7 +106,7 @@ typedef struct cz_copy_seg {
 #define CZ_PRE_COUNT   0x03FFFFFFu
 
 /* chain_top (8 x u64, zeroed per launch): [0] arena units taken; bytes 16.. the work counters of the kernels; [5] / [6] sequences (units of 64, x 256) with
-   near / far offset codes, summed by cz_chain_kernel (see cz_wx_side_by_side) */
+   near / far offset codes, [7] with a literal run above 8 or a match above 16 bytes, summed by cz_chain_kernel (see cz_wx_side_by_side, cz_exec_variant) */
 typedef struct cz_batch_args {
     const uint8_t* in_base; const uint64_t* in_off; const uint64_t* in_len;
     uint8_t* out_base; const uint64_t* out_off; const uint64_t* out_cap;
@@ -139,6 +139,7 @@ typedef struct cz_batch_args {
     cz_lit_seg* lit_segs; uint32_t lit_seg_capacity; cz_copy_seg* copy_segs; uint32_t copy_seg_capacity; uint32_t* frame_pre;
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
     uint32_t* wx_list; uint32_t* wx_counter;  /* frames cz_scan_kernel lists for cz_wexec_kernel (NULL: none), and that kernel's work counter */
+    uint32_t exec_variant_force;              /* 0: cz_exec_variant decides between the two register budgets of cz_execute_frames_kernel; 4 / 8: that one */
     uint32_t wx_force;                        /* 0: cz_wx_side_by_side decides from the batch's offset codes; 1: on; 2: off (A/B runs) */
     uint32_t wx_leave;                        /* cz_execute_frames_kernel leaves the last wx_leave listed frames to cz_wexec_kernel (a frame takes one wave of the former far longer than a workgroup of the latter) */
 } cz_batch_args;

@@ -161,7 +161,7 @@ int cz_context_last_exec_ms(cz_context* ctx, float* ms);
  * frame, sequence execution only: no decoders in LDS or registers) — on = 1, the default; on = 0 sends them to
  * cz_decode_frames_kernel's record path instead (the round-2 arrangement, kept for A/B runs: bench.py --no-exec-kernel).
  * Batches that start from a dictionary (cz_context_set_dictionary) always take cz_decode_frames_kernel. */
-int cz_context_set_exec_kernel(cz_context* ctx, int on);
+int cz_context_set_exec_kernel(cz_context* ctx, int on);   /* (on = 4 / 8: that register budget — waves per SIMD — whatever the batch looks like; 1: decided on the device) */
 /* With both arenas set, the frames that hold enough sequences to be worth a workgroup can also be executed by cz_wexec_kernel:
  * 16 waves per frame, the output of the block in hand in a 128 KiB LDS window (earlier blocks are read from the output buffer;
  * a block that regenerates more than the window is done in several passes), the three values the reference carries from sequence
@@ -177,6 +177,11 @@ int cz_context_set_wexec_kernel(cz_context* ctx, int on);
 /* A/B knobs: CUs cz_wexec_kernel runs on (0: half of them), frames per such CU that cz_execute_frames_kernel leaves to it at the end
  * of a batch (0: the default, 7), force = 1: side by side whatever the batch's offsets look like (tests use it). */
 int cz_context_set_wexec_tuning(cz_context* ctx, int cus, int leave_per_cu, int force);
+/* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' LL / OF / ML code
+ * tables, in sequences x 4 — with near offset codes (2..13: offsets below 16 KiB), with far ones, with a literal run above 8 or a
+ * match above 16 bytes.  The execute stage is arranged from these on the device: cz_wexec_kernel beside cz_execute_frames_kernel
+ * when far > near; the 8-waves-per-SIMD build of cz_execute_frames_kernel when near > far and long < (near + far) / 512. */
+int cz_context_last_sequence_stats(cz_context* ctx, uint64_t* near_offsets, uint64_t* far_offsets, uint64_t* long_runs);
 /* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it
  * handed on to cz_decode_frames_kernel. */
 int cz_context_last_wexec_counts(cz_context* ctx, size_t* listed, size_t* finished, size_t* given_up);

@@ -29,7 +29,7 @@ def child(kind, n):
         ctx.set_chain_arena(int(b.length.sum()) * 6 + (64 << 20))
         if os.environ.get("CZ_LITPASS", "1") == "1":
             ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
-        ctx.set_exec_kernel(os.environ.get("CZ_EXEC", "1") == "1")
+        cz.lib().cz_context_set_exec_kernel(ctx._h, int(os.environ.get("CZ_EXEC", "1")))   # 0 off, 1 on, 4 / 8: that register budget whatever the batch looks like
         wxe = os.environ.get("CZ_WEXEC", "1").split(",")               # on[,cus[,leave_per_cu[,force]]]
         ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=len(wxe) > 3 and wxe[3] == "1")
     tot, ch, ex, lt, wx = [], [], [], [], []
@@ -54,7 +54,7 @@ def child(kind, n):
         ok = ok and nbad == 0
         print(f"oracle check: {nbad} of {n} frames differ", flush=True)
     print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
-          f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  ok={ok}", flush=True)
+          f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  near/far/long {ctx.last_sequence_stats()}  ok={ok}", flush=True)
     ctx.close()
 
 
