@@ -17,6 +17,8 @@ import numpy as np
 from . import status
 from ._lib import (RESULT_CHECKSUM_COMPUTED, RESULT_CHECKSUM_MATCH, RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM,
                    BlockHeader, FrameHeader, build, lib)
+
+DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1 = 1, 2     # cz_context_set_debug_flags
 from .status import CzError
 
 __all__ = ["Context", "FrameDecoder", "BlockDecodingStrategy", "decode_batch_host", "read_frame_header",
@@ -120,6 +122,20 @@ class Context:
         st = lib().cz_context_set_wexec_tuning(self._h, int(cus), int(leave_per_cu), 1 if force else 0)
         if st:
             raise CzError(st, "cz_context_set_wexec_tuning")
+
+    def set_debug_flags(self, flags: int):
+        """Test knobs (cz_context_set_debug_flags): DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1."""
+        lib().cz_context_set_debug_flags(self._h, int(flags))
+
+    def debug_read_chain_arena(self, nbytes: int):
+        """(first nbytes of the chain arena as a uint64 array, arena units in use) after the last launch."""
+        import numpy as _np
+        buf = _np.zeros(nbytes // 8, dtype=_np.uint64)
+        used = C.c_uint64(0)
+        st = lib().cz_context_debug_read_chain_arena(self._h, buf.ctypes.data, buf.nbytes, C.byref(used))
+        if st:
+            raise CzError(st, "cz_context_debug_read_chain_arena")
+        return buf, int(used.value)
 
     def last_sequence_stats(self):
         """(near-offset, far-offset, long-run) sequence sums of the last launch (x 4), as cz_chain_kernel took them from the code tables."""

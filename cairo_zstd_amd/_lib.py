@@ -87,6 +87,10 @@ def lib() -> C.CDLL:
     L.cz_context_set_wexec_kernel.argtypes = [vp, C.c_int]
     L.cz_context_set_wexec_tuning.restype = C.c_int
     L.cz_context_set_wexec_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.cz_context_set_debug_flags.restype = C.c_int
+    L.cz_context_set_debug_flags.argtypes = [vp, C.c_uint32]
+    L.cz_context_debug_read_chain_arena.restype = C.c_int
+    L.cz_context_debug_read_chain_arena.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.cz_context_last_sequence_stats.restype = C.c_int
     L.cz_context_last_sequence_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.cz_context_last_wexec_counts.restype = C.c_int

@@ -1077,7 +1077,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             int ran_asm = 0;
             (void)tail; (void)wide;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (!tail) {
+            if (!tail && !(a.debug_flags & CZ_DEBUG_CHAIN_CPP_STEP)) {
                 CZ_GLOBAL uint64_t* rp = chain_live && ql < 3 ? rec + done : (CZ_GLOBAL uint64_t*)(a.chain_arena + 8);
                 if (!__ballot(chain_live && wide)) {
                     const CzcLane sv = c;

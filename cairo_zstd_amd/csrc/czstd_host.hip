@@ -70,6 +70,7 @@ struct cz_context {
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
     bool wexec_kernel = true;              /* of those, frames of at most 128 KiB with enough sequences run on cz_wexec_kernel first (a workgroup per frame, window in LDS) */
     int wexec_cus = 0;                     /* CUs (= workgroups) cz_wexec_kernel runs on; 0: half of them */
+    uint32_t debug_flags = 0;              /* CZ_DEBUG_* */
     uint32_t exec_variant_force = 0;       /* 0: cz_exec_variant decides; 4 / 8: that variant of cz_execute_frames_kernel (A/B runs) */
     uint32_t wexec_force = 0;              /* 0: the kernels decide from the batch's offset codes; 1: always side by side (A/B runs) */
     int wexec_leave_per_cu = 7;           /* frames per workgroup of cz_wexec_kernel that cz_execute_frames_kernel leaves to it at the end of a batch */
@@ -295,6 +296,18 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
 /* Frames the pre-pass finished run on cz_execute_frames_kernel (default, 1) or, like every other frame, on cz_decode_frames_kernel (0). */
 CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; c->exec_variant_force = on == 4 || on == 8 ? (uint32_t)on : 0u; return CZ_OK; }
 
+CZ_EXPORT int cz_context_set_debug_flags(cz_context* c, uint32_t flags) { if (!c) return CZ_E_INVALID_ARG; c->debug_flags = flags; return CZ_OK; }
+CZ_EXPORT int cz_context_debug_read_chain_arena(cz_context* c, void* dst, size_t bytes, uint64_t* units_in_use) {
+    if (!c || (bytes && !dst)) return CZ_E_INVALID_ARG;
+    if (units_in_use) *units_in_use = 0;
+    if (!c->chain_arena) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (bytes > c->chain_capacity * 8) bytes = c->chain_capacity * 8;
+    if (bytes) CZ_HIP(c, hipMemcpy(dst, c->chain_arena, bytes, hipMemcpyDeviceToHost));
+    if (units_in_use) { unsigned long long top = 0; CZ_HIP(c, hipMemcpy(&top, c->chain_top, 8, hipMemcpyDeviceToHost)); *units_in_use = 64ull + top; }
+    return CZ_OK;
+}
 CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
 
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 0: every frame that has
@@ -401,7 +414,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
-    a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum;
+    a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum; a.debug_flags = c->debug_flags;
     if (!a.tasks && c->batch_dict) { a.dict_state = c->batch_dict->d_state; a.dict = c->batch_dict->d_raw + c->batch_dict->content_off; a.dict_len = c->batch_dict->len - c->batch_dict->content_off; }
     int grid = (int)(n < (size_t)c->grid_max ? n : (size_t)c->grid_max);
 #ifdef CZ_EXPERIMENT
@@ -503,7 +516,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
 #ifdef CZ_EXPERIMENT
             if (const char* e = getenv("CZ_HUF1_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0) h1grid = g; }
 #endif
-            hipLaunchKernelGGL(cz_huf1_kernel, dim3(h1grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
+            if (!(c->debug_flags & CZ_DEBUG_NO_HUF1)) hipLaunchKernelGGL(cz_huf1_kernel, dim3(h1grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
             CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));

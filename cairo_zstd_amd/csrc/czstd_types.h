@@ -139,6 +139,7 @@ typedef struct cz_batch_args {
     cz_lit_seg* lit_segs; uint32_t lit_seg_capacity; cz_copy_seg* copy_segs; uint32_t copy_seg_capacity; uint32_t* frame_pre;
     uint32_t verify_checksum;                 /* batch path: XXH64 of every checksummed frame on the device */
     uint32_t* wx_list; uint32_t* wx_counter;  /* frames cz_scan_kernel lists for cz_wexec_kernel (NULL: none), and that kernel's work counter */
+    uint32_t debug_flags;                     /* CZ_DEBUG_* (cz_context_set_debug_flags): test knobs, 0 in normal use */
     uint32_t exec_variant_force;              /* 0: cz_exec_variant decides between the two register budgets of cz_execute_frames_kernel; 4 / 8: that one */
     uint32_t wx_force;                        /* 0: cz_wx_side_by_side decides from the batch's offset codes; 1: on; 2: off (A/B runs) */
     uint32_t wx_leave;                        /* cz_execute_frames_kernel leaves the last wx_leave listed frames to cz_wexec_kernel (a frame takes one wave of the former far longer than a workgroup of the latter) */

@@ -188,6 +188,18 @@ int cz_context_last_wexec_counts(cz_context* ctx, size_t* listed, size_t* finish
 /* The part of the most recent launch spent in cz_wexec_kernel (0 when it did not run). */
 int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
 
+/* Test knobs (0 in normal use).  CZ_DEBUG_CHAIN_CPP_STEP: cz_chain_kernel takes every step of every chain with its plain C++ step
+ * instead of the hand-scheduled inline-asm group — the two must leave the same records (sequence_section_decoder.cairo:223-286).
+ * CZ_DEBUG_NO_HUF1: cz_huf1_kernel (the one-wave huff0 kernel beside the chain kernel) is not launched, so which kernel decodes a
+ * literals section no longer depends on timing (literals_section_decoder.cairo:95-115: cz_huf_kernel hands a frame with an uneven
+ * 4-stream split back, cz_huf1_kernel keeps it). */
+#define CZ_DEBUG_CHAIN_CPP_STEP 1u
+#define CZ_DEBUG_NO_HUF1 2u
+int cz_context_set_debug_flags(cz_context* ctx, uint32_t flags);
+/* Copies the first `bytes` of the chain arena (headers, state -> code maps and per-sequence records of the most recent batch
+ * launch, as cz_chain_kernel left them) to host memory and returns the arena units in use; synchronises.  For tests. */
+int cz_context_debug_read_chain_arena(cz_context* ctx, void* dst, size_t bytes, uint64_t* units_in_use);
+
 /* Diagnostic builds only (libcairo_zstd_amd_prof.so, -DCZ_PROFILE): copies out and clears the
  * per-phase shader-cycle sums accumulated by the kernels; returns the number of phases written
  * (0 in the product library, which executes no stamps). */

@@ -769,18 +769,105 @@ def test_r3_vectors_vs_manifest(cz, prepass):
         if prepass:
             c.set_chain_arena(64 << 20, min_sequences=0)
             c.set_literal_arena(16 << 20)
-        got = cz.decode_batch_host([z for _, z, _ in vec], [e["orig_len"] + 64 for _, _, e in vec], c)
-        for (name, z, e), (r, out) in zip(vec, got):
-            assert int(r["status"]) == 0, (name, cz.status.name(r["status"]))
-            assert len(out) == e["orig_len"] and int(r["bytes_consumed"]) == len(z), name
-            assert hashlib.sha256(out).hexdigest() == e["orig_sha256"] and f"{oracle.xxh64(out):016x}" == e["xxh64"], name
-        if prepass:
-            with_chain, with_lits = c.last_prepass_counts(len(vec))
-            # the D5 frame: cz_huf_kernel hands it back (its streams do not split ceil(regen / 4)); cz_huf1_kernel, when it gets to the
-            # section first, redoes the streams back to back itself and keeps it
-            assert with_lits in (len(vec) - 1, len(vec)), (with_chain, with_lits)
+        for huf1 in ((True, False) if prepass else (True,)):
+            # without cz_huf1_kernel (which takes sections off the same list while the chain kernel runs: who gets the D5 section is
+            # a matter of timing) every section is cz_huf_kernel's, and the hand-back of the D5 frame is deterministic
+            c.set_debug_flags(0 if huf1 else cz.DEBUG_NO_HUF1)
+            got = cz.decode_batch_host([z for _, z, _ in vec], [e["orig_len"] + 64 for _, _, e in vec], c)
+            for (name, z, e), (r, out) in zip(vec, got):
+                assert int(r["status"]) == 0, (name, cz.status.name(r["status"]))
+                assert len(out) == e["orig_len"] and int(r["bytes_consumed"]) == len(z), name
+                assert hashlib.sha256(out).hexdigest() == e["orig_sha256"] and f"{oracle.xxh64(out):016x}" == e["xxh64"], name
+            if prepass:
+                with_chain, with_lits = c.last_prepass_counts(len(vec))
+                # the D5 frame: cz_huf_kernel hands it back (its streams do not split ceil(regen / 4)); cz_huf1_kernel, when it gets to
+                # the section first, redoes the streams back to back itself and keeps it
+                if huf1:
+                    assert with_lits in (len(vec) - 1, len(vec)), (with_chain, with_lits)
+                else:
+                    assert with_lits == len(vec) - 1, (with_chain, with_lits)
     finally:
         c.close()
+
+def test_chain_kernel_asm_group_and_cpp_step_leave_the_same_records(cz):
+    """cz_chain_kernel's hand-scheduled inline-asm group (czc_group_asm, and its wide variant) against the plain C++ step
+    (czc_step), which the CPU emulator runs: the same blocks through both, and the chain arenas — headers, state -> code maps and
+    the 8-byte record of every sequence (sequence_section_decoder.cairo:223-286) — compared word for word."""
+    from cairo_zstd_amd import synth
+    frames, caps = [], []
+    for kind, n in (("full_4a", 6), ("full_4b", 2), ("mix", 300)):
+        b = synth.generate(kind, n, first_index=901)
+        frames += [b.frame(i) for i in range(n)]
+        caps += [int(r) + 16 for r in b.regen]
+    for name, z, orig in corpus_pairs():
+        frames.append(z)
+        caps.append(len(orig) + 32)
+    arenas = []
+    for flags in (0, cz.DEBUG_CHAIN_CPP_STEP):
+        c = cz.Context(0)
+        try:
+            c.set_chain_arena(512 << 20, min_sequences=0)
+            c.set_literal_arena(256 << 20)
+            c.set_debug_flags(flags | cz.DEBUG_NO_HUF1)
+            got = cz.decode_batch_host(frames, caps, c)
+            assert all(int(r["status"]) == 0 for r, _ in got)
+            with_chain, _ = c.last_prepass_counts(len(frames))
+            arena, used = c.debug_read_chain_arena(512 << 20)
+            arenas.append((arena[:used].copy(), used, with_chain, [out for _, out in got]))
+        finally:
+            c.close()
+    (a0, u0, w0, o0), (a1, u1, w1, o1) = arenas
+    assert u0 == u1 and w0 == w1 and w0 > 200, (u0, u1, w0, w1)
+    assert o0 == o1
+    # blocks are placed in the arena by atomics whose order differs from run to run: compare block by block, found through the
+    # headers {nseq << 32 | maps, bitstream offset, next header of the frame, 0}, keyed by what does not depend on the placement
+    def blocks(a, used):
+        out, at = {}, 64
+        while at < used:
+            nseq = int(a[at] >> 32)
+            size = 4 + 160 + nseq
+            key = (nseq, int(a[at + 1]), int(a[at] & 0xFFFFFFFF), a[at + 4:at + 4 + 160].tobytes()[:64])
+            out.setdefault(key, []).append(a[at + 4:at + size].tobytes())
+            at += size
+        return out
+    b0, b1 = blocks(a0, u0), blocks(a1, u1)
+    assert set(b0) == set(b1)
+    for k in b0:
+        assert sorted(b0[k]) == sorted(b1[k]), k[:3]
+
+
+def test_truncated_sequence_section_status_parity(cz):
+    """A sequences section that ends before its last sequences are read: the reference unwraps a negative bits_remaining
+    (sequence_section_decoder.cairo:279) and panics before it could return NotEnoughBytesForNumSequences (:281); oracle and
+    device both report CZ_E_SEQ_NOT_ENOUGH_BYTES (DESIGN.md divergences), through the complete kernel and through the pre-pass
+    kernels."""
+    from cairo_zstd_amd import synth
+    b = synth.generate("full_4a", 4, first_index=31)
+    frames, caps = [], []
+    for i in range(b.n):
+        fr = bytearray(b.frame(i))
+        # the single block's size field: cut bytes off the END of the block (= the start of the reversed sequence bitstream is kept,
+        # its tail goes), keeping the header consistent
+        hdr = 10
+        h = fr[hdr] | (fr[hdr + 1] << 8) | (fr[hdr + 2] << 16)
+        size = h >> 3
+        for cut in (1, 7, 300):
+            g = bytearray(fr[:hdr + 3 + size - cut])
+            nh = (h & 7) | ((size - cut) << 3)
+            g[hdr:hdr + 3] = bytes((nh & 0xFF, (nh >> 8) & 0xFF, (nh >> 16) & 0xFF))
+            frames.append(bytes(g)); caps.append(int(b.regen[i]) + 64)
+    want = [oracle.decode_frame(fr, cap=cap)[0] for fr, cap in zip(frames, caps)]
+    assert any(w == cz.status.CZ_E_SEQ_NOT_ENOUGH_BYTES for w in want), [cz.status.name(w) for w in want]
+    for prepass in (False, True):
+        c = cz.Context(0)
+        try:
+            if prepass:
+                c.set_chain_arena(64 << 20, min_sequences=0)
+                c.set_literal_arena(16 << 20)
+            got = cz.decode_batch_host(frames, caps, c)
+            assert [int(r["status"]) for r, _ in got] == want, ([cz.status.name(r["status"]) for r, _ in got], [cz.status.name(w) for w in want])
+        finally:
+            c.close()
 
 
 @pytest.mark.parametrize("kind,n", [("raw_rle", 300), ("huf_literals", 40), ("mix", 600)])
