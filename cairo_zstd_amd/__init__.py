@@ -257,6 +257,29 @@ def decode_batch_multi(frames, caps, ctxs):
     return [(res[i], out[int(out_off[i]): int(out_off[i]) + min(int(res[i]["bytes_produced"]), int(caps[i]))].tobytes()) for i in range(len(frames))], dev
 
 
+def decode_batch_multi_device(ctxs, shares):
+    """cz_decode_batch_multi_device: shares = per context (d_in_base, d_in_off, d_in_len, n, d_out_base, d_out_off, d_out_cap, d_results),
+    all device pointers of that context's device.  Only enqueues."""
+    from ._lib import DeviceShare
+    arr = (DeviceShare * len(ctxs))(*[DeviceShare(*[int(v) for v in sh]) for sh in shares])
+    handles = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = lib().cz_decode_batch_multi_device(handles, len(ctxs), arr)
+    if st:
+        raise CzError(st, "cz_decode_batch_multi_device")
+
+
+def gather_to_root(ctxs, root, d_src, nbytes, d_dst_on_root):
+    """cz_gather_to_root: concurrent peer copies of the other contexts' decoded arenas to the root context's device."""
+    k = len(ctxs)
+    handles = (C.c_void_p * k)(*[c._h for c in ctxs])
+    src = (C.c_void_p * k)(*[int(v) for v in d_src])
+    dst = (C.c_void_p * k)(*[int(v) for v in d_dst_on_root])
+    nb = (C.c_size_t * k)(*[int(v) for v in nbytes])
+    st = lib().cz_gather_to_root(handles, k, int(root), src, nb, dst)
+    if st:
+        raise CzError(st, "cz_gather_to_root")
+
+
 def read_frame_header(src):
     """read_frame_header (src/frame.cairo:152-284).  Returns (status, FrameHeader, detail)."""
     a = _as_u8(src)

@@ -26,6 +26,11 @@ class FrameHeader(C.Structure):
                 ("window_size", C.c_uint64)]
 
 
+class DeviceShare(C.Structure):
+    _fields_ = [("d_in_base", C.c_void_p), ("d_in_off", C.c_void_p), ("d_in_len", C.c_void_p), ("n", C.c_size_t),
+                ("d_out_base", C.c_void_p), ("d_out_off", C.c_void_p), ("d_out_cap", C.c_void_p), ("d_results", C.c_void_p)]
+
+
 class BlockHeader(C.Structure):
     _fields_ = [("last_block", C.c_uint8), ("block_type", C.c_uint8), ("decompressed_size", C.c_uint32),
                 ("content_size", C.c_uint32)]
@@ -87,6 +92,10 @@ def lib() -> C.CDLL:
     L.cz_context_set_wexec_kernel.argtypes = [vp, C.c_int]
     L.cz_context_set_wexec_tuning.restype = C.c_int
     L.cz_context_set_wexec_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.cz_decode_batch_multi_device.restype = C.c_int
+    L.cz_decode_batch_multi_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cz_gather_to_root.restype = C.c_int
+    L.cz_gather_to_root.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.cz_context_set_debug_flags.restype = C.c_int
     L.cz_context_set_debug_flags.argtypes = [vp, C.c_uint32]
     L.cz_context_debug_read_chain_arena.restype = C.c_int

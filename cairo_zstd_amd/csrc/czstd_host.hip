@@ -20,6 +20,7 @@
 #include <functional>
 #include <new>
 #include <queue>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -82,6 +83,7 @@ struct cz_context {
     int last_hip_error = 0;
     /* staging for cz_decode_batch_host */
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
+    void* h_pin = nullptr; size_t h_pin_bytes = 0;                      /* pinned host staging of cz_decode_batch_multi's share */
     unsigned long long* d_prof = nullptr;   /* CZ_PROFILE builds: per-phase cycle sums */
     /* optional FSE-chain pre-pass */
     uint64_t* chain_arena = nullptr; uint64_t chain_capacity = 0;   /* 8-byte units */
@@ -157,6 +159,7 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->lit_scratch) (void)hipFree(c->lit_scratch);
     if (c->work_counter) (void)hipFree(c->work_counter);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->chain_arena) (void)hipFree(c->chain_arena);
     if (c->lit_arena) (void)hipFree(c->lit_arena);
@@ -433,7 +436,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         /* the pre-pass: block list (cz_scan_kernel), then the FSE chains of all blocks (cz_chain_kernel) -> records in the arena */
         if (c->frame_first_cap < n) {
             if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
-            CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8)); c->frame_first_cap = n;
+            CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8));        /* (frame_first_cap is set once every list below is there: a failure in between leaves the context asking again) */
             if (c->frame_order) (void)hipFree(c->frame_order);
             c->frame_order = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->frame_order, n * 4));
@@ -446,6 +449,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (c->wx_list) (void)hipFree(c->wx_list);
             c->wx_list = nullptr;
             CZ_HIP(c, hipMalloc((void**)&c->wx_list, n * 4));
+            c->frame_first_cap = n;
         }
         CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 64, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
@@ -628,7 +632,7 @@ CZ_EXPORT int cz_decode_batch_host(cz_context* c, const void* in_base, size_t in
 }
 
 /* ------------------------------------------------------------------ several devices */
-CZ_EXPORT int cz_partition_balanced(const uint64_t* weights, size_t n, size_t parts, uint32_t* part_of) {
+CZ_EXPORT int cz_partition_balanced(const uint64_t* weights, size_t n, size_t parts, uint32_t* part_of) try {
     if (!parts || (n && (!weights || !part_of))) return CZ_E_INVALID_ARG;
     std::vector<size_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = i;
@@ -643,12 +647,22 @@ CZ_EXPORT int cz_partition_balanced(const uint64_t* weights, size_t n, size_t pa
         heap.push(t);
     }
     return CZ_OK;
-}
+} catch (const std::bad_alloc&) { return CZ_E_OUT_OF_MEMORY; }
 
+static int cz_pin_reserve(cz_context* c, size_t bytes) {
+    if (c->h_pin_bytes >= bytes) return CZ_OK;
+    if (c->h_pin) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_bytes = 0; }
+    CZ_HIP(c, hipHostMalloc(&c->h_pin, bytes, hipHostMallocDefault)); c->h_pin_bytes = bytes;
+    return CZ_OK;
+}
+static int cz_distinct_contexts(cz_context* const* ctxs, size_t n_ctx) {
+    if (!ctxs || !n_ctx) return 0;
+    for (size_t d = 0; d < n_ctx; d++) { if (!ctxs[d]) return 0; for (size_t e = 0; e < d; e++) if (ctxs[e] == ctxs[d]) return 0; }   /* a context twice would race on its stream and staging */
+    return 1;
+}
 CZ_EXPORT int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx, const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
-                                    void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap, cz_frame_result* results, uint32_t* device_of) {
-    if (!ctxs || !n_ctx) return CZ_E_INVALID_ARG;
-    for (size_t d = 0; d < n_ctx; d++) if (!ctxs[d]) return CZ_E_INVALID_ARG;
+                                    void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap, cz_frame_result* results, uint32_t* device_of) try {
+    if (!cz_distinct_contexts(ctxs, n_ctx)) return CZ_E_INVALID_ARG;
     if (n == 0) return CZ_OK;
     if (!in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !results) return CZ_E_INVALID_ARG;
     for (size_t i = 0; i < n; i++) {
@@ -665,30 +679,77 @@ CZ_EXPORT int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx, const
     std::vector<std::thread> workers;
     for (size_t d = 0; d < n_ctx; d++) {
         workers.emplace_back([&, d]() {
-            /* this device's share, packed: compressed frames back to back (16-byte aligned), outputs in a layout of its own */
-            std::vector<size_t> mine;
-            for (size_t i = 0; i < n; i++) if (part[i] == d) mine.push_back(i);
-            if (mine.empty()) return;
-            std::vector<uint64_t> ioff(mine.size()), ilen(mine.size()), ooff(mine.size()), ocap(mine.size());
-            size_t ib = 0, ob = 0;
-            for (size_t k = 0; k < mine.size(); k++) {
-                ioff[k] = ib; ilen[k] = in_len[mine[k]]; ib += (size_t)((in_len[mine[k]] + 15) & ~15ull);
-                ooff[k] = ob; ocap[k] = out_cap[mine[k]]; ob += (size_t)((out_cap[mine[k]] + 255) & ~255ull);
-            }
-            std::vector<uint8_t> ibuf(ib + 16), obuf(ob + 16);
-            for (size_t k = 0; k < mine.size(); k++) memcpy(ibuf.data() + ioff[k], (const uint8_t*)in_base + in_off[mine[k]], (size_t)ilen[k]);
-            std::vector<cz_frame_result> res(mine.size());
-            status[d] = cz_decode_batch_host(ctxs[d], ibuf.data(), ib, ioff.data(), ilen.data(), mine.size(), obuf.data(), ob, ooff.data(), ocap.data(), res.data());
-            if (status[d]) return;
-            for (size_t k = 0; k < mine.size(); k++) {
-                results[mine[k]] = res[k];
-                const uint64_t w = res[k].bytes_produced < ocap[k] ? res[k].bytes_produced : ocap[k];
-                memcpy((uint8_t*)out_base + out_off[mine[k]], obuf.data() + ooff[k], (size_t)w);
-            }
+            try {
+                /* this device's share, packed straight into the context's PINNED staging buffer (one copy on the host, and the
+                   transfers to and from the device run at the bus's rate, asynchronously): descriptors, compressed frames back to
+                   back (16-byte aligned), results, outputs in a layout of its own */
+                std::vector<size_t> mine;
+                for (size_t i = 0; i < n; i++) if (part[i] == d) mine.push_back(i);
+                if (mine.empty()) return;
+                const size_t m = mine.size();
+                size_t ib = 0, ob = 0;
+                for (size_t k = 0; k < m; k++) { ib += (size_t)((in_len[mine[k]] + 15) & ~15ull); ob += (size_t)((out_cap[mine[k]] + 255) & ~255ull); }
+                auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+                const size_t p_desc = 0, p_res = p_desc + up(4 * m * 8), p_in = p_res + up(m * sizeof(cz_frame_result)), p_out = p_in + up(ib + 16), total = p_out + up(ob + 16);
+                cz_context* c = ctxs[d];
+                if (hipSetDevice(c->device) != hipSuccess) { status[d] = CZ_E_HIP; return; }
+                status[d] = cz_pin_reserve(c, total); if (status[d]) return;
+                uint8_t* hp = (uint8_t*)c->h_pin;
+                uint64_t* ioff = (uint64_t*)(hp + p_desc), *ilen = ioff + m, *ooff = ilen + m, *ocap = ooff + m;
+                size_t ia = 0, oa = 0;
+                for (size_t k = 0; k < m; k++) {
+                    ioff[k] = ia; ilen[k] = in_len[mine[k]]; ia += (size_t)((in_len[mine[k]] + 15) & ~15ull);
+                    ooff[k] = oa; ocap[k] = out_cap[mine[k]]; oa += (size_t)((out_cap[mine[k]] + 255) & ~255ull);
+                    memcpy(hp + p_in + ioff[k], (const uint8_t*)in_base + in_off[mine[k]], (size_t)ilen[k]);
+                }
+                cz_frame_result* res = (cz_frame_result*)(hp + p_res);
+                status[d] = cz_decode_batch_host(c, hp + p_in, ib, ioff, ilen, m, hp + p_out, ob, ooff, ocap, res);
+                if (status[d]) return;
+                for (size_t k = 0; k < m; k++) {
+                    results[mine[k]] = res[k];
+                    const uint64_t w = res[k].bytes_produced < ocap[k] ? res[k].bytes_produced : ocap[k];
+                    memcpy((uint8_t*)out_base + out_off[mine[k]], hp + p_out + ooff[k], (size_t)w);
+                }
+            } catch (const std::bad_alloc&) { status[d] = CZ_E_OUT_OF_MEMORY; }
         });
     }
     for (auto& t : workers) t.join();
     for (size_t d = 0; d < n_ctx; d++) if (status[d]) return status[d];
+    return CZ_OK;
+} catch (const std::bad_alloc&) { return CZ_E_OUT_OF_MEMORY; } catch (const std::system_error&) { return CZ_E_OUT_OF_MEMORY; }
+
+/* The same with everything already on the devices — no host buffer, no PCIe in the path: share d (device pointers of context d's
+   device) is launched on context d; the calls only enqueue (cz_decode_batch_device), so the devices run concurrently. */
+CZ_EXPORT int cz_decode_batch_multi_device(cz_context* const* ctxs, size_t n_ctx, const cz_device_share* shares) {
+    if (!cz_distinct_contexts(ctxs, n_ctx) || !shares) return CZ_E_INVALID_ARG;
+    for (size_t d = 0; d < n_ctx; d++) {
+        const cz_device_share& s = shares[d];
+        if (!s.n) continue;
+        const int st = cz_decode_batch_device(ctxs[d], s.d_in_base, s.d_in_off, s.d_in_len, s.n, s.d_out_base, s.d_out_off, s.d_out_cap, s.d_results);
+        if (st) return st;
+    }
+    return CZ_OK;
+}
+/* The exchange step of SURVEY.md §8 (e): the decoded arenas of the other contexts to the root's device, as n_ctx - 1 CONCURRENT
+   peer copies — each on its source context's stream, behind that context's decode — so that every xGMI link of the root carries
+   one of them (a ring would be bound by one link).  The root's stream then waits for all of them: work enqueued on it afterwards
+   (or cz_context_synchronize on the root) sees the gathered bytes. */
+CZ_EXPORT int cz_gather_to_root(cz_context* const* ctxs, size_t n_ctx, size_t root, const void* const* d_src, const size_t* bytes, void* const* d_dst_on_root) {
+    if (!cz_distinct_contexts(ctxs, n_ctx) || root >= n_ctx || !d_src || !bytes || !d_dst_on_root) return CZ_E_INVALID_ARG;
+    cz_context* r = ctxs[root];
+    for (size_t d = 0; d < n_ctx; d++) {
+        if (d == root || !bytes[d]) continue;
+        if (!d_src[d] || !d_dst_on_root[d]) return CZ_E_INVALID_ARG;
+        cz_context* c = ctxs[d];
+        CZ_HIP(c, hipSetDevice(c->device));
+        CZ_HIP(c, hipMemcpyPeerAsync(d_dst_on_root[d], r->device, d_src[d], c->device, bytes[d], c->stream));
+        hipEvent_t ev;
+        CZ_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        CZ_HIP(c, hipEventRecord(ev, c->stream));
+        CZ_HIP(r, hipSetDevice(r->device));
+        CZ_HIP(r, hipStreamWaitEvent(r->stream, ev, 0));
+        (void)hipEventDestroy(ev);                                      /* (released when it has completed) */
+    }
     return CZ_OK;
 }
 

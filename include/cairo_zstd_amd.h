@@ -108,8 +108,22 @@ int cz_decode_batch_host(cz_context* ctx,
  * frames with cz_partition_balanced (weight = in_len + out_cap), runs every share through cz_decode_batch_host on a thread
  * of its own — stage, launch, copy back, all concurrently across the devices — and leaves outputs and results in the
  * caller's layout, exactly as one cz_decode_batch_host call would.  device_of (optional, n entries): the context index every
- * frame went to.  Every context keeps its own arenas and options (cz_context_set_chain_arena ... per context). */
+ * frame went to.  Every context keeps its own arenas and options (cz_context_set_chain_arena ... per context); a context may
+ * appear once.  A share is packed once, into pinned staging memory the context keeps. */
 int cz_partition_balanced(const uint64_t* weights, size_t n, size_t parts, uint32_t* part_of);
+/* ... and without host buffers (no PCIe in the path): the caller has dealt the frames (cz_partition_balanced) and put every share
+ * on its device; cz_decode_batch_multi_device launches share d on context d (cz_decode_batch_device: it only enqueues, so the
+ * devices run concurrently).  A context may appear once.
+ * cz_gather_to_root is the one exchange the path has: `bytes[d]` bytes at d_src[d] on context d's device go
+ * to d_dst_on_root[d] on the root context's device, every d != root — n_ctx - 1 concurrent peer copies (hipMemcpyPeerAsync), each on
+ * its source context's stream behind that context's decode, so that all of the root's xGMI links carry traffic; the root's stream
+ * waits for them.  Entry `root` of the three arrays is ignored. */
+typedef struct cz_device_share {
+    const void* d_in_base; const uint64_t* d_in_off; const uint64_t* d_in_len; size_t n;
+    void* d_out_base; const uint64_t* d_out_off; const uint64_t* d_out_cap; cz_frame_result* d_results;
+} cz_device_share;
+int cz_decode_batch_multi_device(cz_context* const* ctxs, size_t n_ctx, const cz_device_share* shares);
+int cz_gather_to_root(cz_context* const* ctxs, size_t n_ctx, size_t root, const void* const* d_src, const size_t* bytes, void* const* d_dst_on_root);
 int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx,
                           const void* in_base, size_t in_bytes, const uint64_t* in_off, const uint64_t* in_len, size_t n,
                           void* out_base, size_t out_bytes, const uint64_t* out_off, const uint64_t* out_cap,

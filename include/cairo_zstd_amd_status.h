@@ -120,7 +120,8 @@ typedef enum cz_status {
                                       (DESIGN.md "Divergences": Huffman-weight FSE accuracy
                                       log > 9, literals scratch exceeded) */
     CZ_E_NO_DEVICE = 904,          /* library built without / cannot reach a gfx950 device */
-    CZ_E_NOT_FINISHED = 905        /* frame ran out of source before its last block */
+    CZ_E_NOT_FINISHED = 905,       /* frame ran out of source before its last block */
+    CZ_E_OUT_OF_MEMORY = 906       /* a host allocation failed inside the library (std::bad_alloc does not cross the C ABI) */
 } cz_status;
 
 #ifdef __cplusplus

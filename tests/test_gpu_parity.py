@@ -972,6 +972,61 @@ def test_decode_batch_multi_deals_frames_over_contexts(cz):
         c0.close()
         c1.close()
 
+def test_decode_batch_multi_device_and_gather_to_root(cz):
+    """The device-pointer form of the multi-device entry points (no host buffers, no PCIe in the path): the frames dealt with
+    cz_partition_balanced, every share put on its context's device, cz_decode_batch_multi_device (only enqueues), then
+    cz_gather_to_root — one peer copy per non-root context, on that context's stream behind its decode — and the root's copy of
+    every arena compared with the oracle.  Two contexts on the test box's one GPU; a context listed twice is refused."""
+    import torch
+    from cairo_zstd_amd import synth
+    b = synth.generate("mix", 500, first_index=1234)
+    n = b.n
+    w = (b.length + b.regen).astype(np.uint64)
+    part = np.zeros(n, dtype=np.uint32)
+    assert cz.lib().cz_partition_balanced(w.ctypes.data, n, 2, part.ctypes.data) == 0
+    dev = torch.device("cuda:0")
+    ctxs = [cz.Context(0), cz.Context(0)]
+    keep = []
+    try:
+        shares, outs, metas = [], [], []
+        for d, c in enumerate(ctxs):
+            c.set_chain_arena(128 << 20, min_sequences=0)
+            c.set_literal_arena(64 << 20)
+            mine = np.nonzero(part == d)[0]
+            lens = b.length[mine].astype(np.int64)
+            ioff = np.zeros(len(mine), dtype=np.int64); ioff[1:] = np.cumsum((lens[:-1] + 15) & ~15)
+            ibuf = np.zeros(int(ioff[-1] + lens[-1]) + 64, dtype=np.uint8)
+            for k, i in enumerate(mine):
+                ibuf[ioff[k]:ioff[k] + lens[k]] = b.base[int(b.off[i]):int(b.off[i]) + int(b.length[i])]
+            caps = b.regen[mine].astype(np.int64)
+            ooff = np.zeros(len(mine), dtype=np.int64); ooff[1:] = np.cumsum((caps[:-1] + 255) & ~255)
+            total = int(ooff[-1] + caps[-1]) + 256
+            t = [torch.from_numpy(x).to(dev) for x in (ibuf, ioff, lens, ooff, caps)]
+            t_out = torch.full((total,), 0xA5, dtype=torch.uint8, device=dev)
+            t_res = torch.zeros(len(mine) * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            keep += t + [t_out, t_res]
+            shares.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(mine), t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr()))
+            outs.append((t_out, t_res)); metas.append((mine, ooff, caps, total))
+        torch.cuda.synchronize()
+        cz.decode_batch_multi_device(ctxs, shares)
+        root_bufs = [None if d == 0 else torch.zeros(metas[d][3], dtype=torch.uint8, device=dev) for d in range(2)]
+        torch.cuda.synchronize()
+        cz.gather_to_root(ctxs, 0, [o[0].data_ptr() for o in outs], [m[3] for m in metas], [0 if rb is None else rb.data_ptr() for rb in root_bufs])
+        ctxs[0].synchronize()
+        with pytest.raises(cz.CzError):
+            cz.decode_batch_multi_device([ctxs[0], ctxs[0]], shares)
+        for d in range(2):
+            mine, ooff, caps, total = metas[d]
+            got = (outs[0][0] if d == 0 else root_bufs[d]).cpu().numpy()
+            res = outs[d][1].cpu().numpy().view(cz.RESULT_DTYPE)
+            for k, i in enumerate(mine):
+                st, ref, info = oracle.decode_frame(b.frame(int(i)), cap=int(caps[k]))
+                assert st == int(res[k]["status"]) == 0, (d, k)
+                assert got[int(ooff[k]):int(ooff[k]) + len(ref)].tobytes() == ref, (d, k)
+    finally:
+        for c in ctxs:
+            c.close()
+
 
 @pytest.mark.parametrize("pipeline", ["single_kernel", "prepass"])
 def test_damaged_synthetic_frames_status_and_output_parity(cz, pipeline):
