@@ -233,7 +233,8 @@ def main():
     alg_bytes = int(batch.length.sum() + batch.regen.sum())       # compressed bytes read once + decoded bytes written once
     regen_bytes = int(batch.regen.sum())
 
-    t_in = torch.from_numpy(batch.base).to(dev)
+    dev_base = czdist.rebalance_frames.last_device_base if balanced else None
+    t_in = dev_base if dev_base is not None and dev_base.device == dev else torch.from_numpy(batch.base).to(dev)   # (dealt frames stay on the GPU the exchange put them on)
     t_off = torch.from_numpy(batch.off.astype(np.int64)).to(dev)
     t_len = torch.from_numpy(batch.length.astype(np.int64)).to(dev)
     t_ooff = torch.from_numpy(out_off.astype(np.int64)).to(dev)
@@ -246,8 +247,12 @@ def main():
     ctx = cz.Context(local_dev, stream.cuda_stream)
     # the block-parallel pre-pass (cz_scan_kernel + cz_chain_kernel || cz_huf1_kernel || cz_tile_kernel + cz_huf_kernel) for every workload
     chain_prepass = not args.no_chain_prepass
-    arena_bytes = int(batch.length.sum()) * 8 + (64 << 20)            # 8 B per sequence + 1312 B per block with sequences
-    lit_bytes = regen_bytes + (16 << 20)                               # decoded literal bytes never exceed the decoded size
+    # the arenas, sized from the batch's own headers (cz_scan_kernel's counting pass; 8 B per sequence + 1 312 B per block with sequences,
+    # literal bytes of the blocks with sequences) + slack — not from a rule of thumb
+    torch.cuda.synchronize()
+    arena_bytes, lit_bytes = ctx.measure_batch(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), F, t_ocap.data_ptr())
+    arena_bytes += 8 << 20
+    lit_bytes += 8 << 20
     if chain_prepass:
         ctx.set_chain_arena(arena_bytes)
         ctx.set_exec_kernel(args.exec_kernel)
@@ -371,11 +376,13 @@ def main():
             # the chain pre-pass only pays for frames with long sequences sections
             ob = synth.generate(wl, nf, nthreads=max(1, min(32, ncpu)))
             pre = not args.no_chain_prepass
-            ctx.set_chain_arena(int(ob.length.sum()) * 8 + (64 << 20) if pre else 0)
-            ctx.set_literal_arena(int(ob.regen.sum()) + (16 << 20) if pre and not args.no_literals_pass else 0)
             o_off, o_cap, o_total = ob.out_layout(256)
             ti = torch.from_numpy(ob.base).to(dev)
             td = [torch.from_numpy(x.astype(np.int64)).to(dev) for x in (ob.off, ob.length, o_off, o_cap)]
+            torch.cuda.synchronize()
+            ab_, lb_ = ctx.measure_batch(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, td[3].data_ptr())
+            ctx.set_chain_arena(ab_ + (8 << 20) if pre else 0)
+            ctx.set_literal_arena(lb_ + (8 << 20) if pre and not args.no_literals_pass else 0)
             to = torch.empty(o_total, dtype=torch.uint8, device=dev)
             tr = torch.zeros(nf * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             ms = []
@@ -421,10 +428,12 @@ def main():
             rbase = np.frombuffer(b"".join(rf) + b"\0" * 64, dtype=np.uint8)
             SZ = len(ro[0])
             o_off = np.arange(nf, dtype=np.int64) * SZ
-            ctx.set_chain_arena(int(lens.sum()) * 8 + (64 << 20))
-            ctx.set_literal_arena(nf * SZ + (16 << 20) if not args.no_literals_pass else 0)
             ti = torch.from_numpy(rbase.copy()).to(dev)
             td = [torch.from_numpy(x).to(dev) for x in (roff, lens, o_off, np.full(nf, SZ, dtype=np.int64))]
+            torch.cuda.synchronize()
+            ab_, lb_ = ctx.measure_batch(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, td[3].data_ptr())
+            ctx.set_chain_arena(ab_ + (8 << 20))
+            ctx.set_literal_arena(lb_ + (8 << 20) if not args.no_literals_pass else 0)
             to = torch.empty(nf * SZ, dtype=torch.uint8, device=dev)
             tr = torch.zeros(nf * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
@@ -497,7 +506,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]}", "frames_per_gpu": args.frames,
                        "frames_total": int(frames_all), "compressed_bytes_rank0": int(batch.length.sum()),
-                       "decoded_bytes_rank0": regen_bytes,
+                       "decoded_bytes_rank0": regen_bytes, "chain_arena_bytes": int(arena_bytes) if chain_prepass else 0, "literal_arena_bytes": int(lit_bytes) if chain_prepass and not args.no_literals_pass else 0,
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"
                                       + (", dealt by algorithmic bytes (one untimed all_to_all of compressed bytes)" if balanced else ""),
                        "launches_per_step": launches},

@@ -123,6 +123,14 @@ class Context:
         if st:
             raise CzError(st, "cz_context_set_wexec_tuning")
 
+    def measure_batch(self, d_in_base: int, d_in_off: int, d_in_len: int, n: int, d_out_cap: int):
+        """(chain arena bytes, literal arena bytes) a batch on the device needs, from its headers (cz_context_measure_batch)."""
+        a, b = C.c_size_t(), C.c_size_t()
+        st = lib().cz_context_measure_batch(self._h, d_in_base, d_in_off, d_in_len, n, d_out_cap, C.byref(a), C.byref(b))
+        if st:
+            raise CzError(st, "cz_context_measure_batch")
+        return int(a.value), int(b.value)
+
     def set_debug_flags(self, flags: int):
         """Test knobs (cz_context_set_debug_flags): DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1."""
         lib().cz_context_set_debug_flags(self._h, int(flags))

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
     L.cz_context_set_wexec_kernel.argtypes = [vp, C.c_int]
     L.cz_context_set_wexec_tuning.restype = C.c_int
     L.cz_context_set_wexec_tuning.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.cz_context_measure_batch.restype = C.c_int
+    L.cz_context_measure_batch.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.cz_decode_batch_multi_device.restype = C.c_int
     L.cz_decode_batch_multi_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.cz_gather_to_root.restype = C.c_int

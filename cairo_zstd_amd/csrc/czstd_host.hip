@@ -583,6 +583,44 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     return CZ_OK;
 }
 
+/* What the arenas of a batch must hold, from the headers alone (cz_scan_kernel's counting pass over the batch as it sits on the
+   device; nothing is decoded): chain arena bytes = 8 per sequence + 1 312 per block with sequences + the reserved head, literal
+   arena bytes = the Huffman-coded literals of blocks that have sequences + 16 per such block.  Synchronises; meant for set-up, not
+   for the hot path. */
+CZ_EXPORT int cz_context_measure_batch(cz_context* c, const void* d_in_base, const uint64_t* d_in_off, const uint64_t* d_in_len, size_t n, const uint64_t* d_out_cap,
+                                       size_t* chain_arena_bytes, size_t* literal_arena_bytes) try {
+    if (!c || (n && (!d_in_base || !d_in_off || !d_in_len || !d_out_cap))) return CZ_E_INVALID_ARG;
+    if (chain_arena_bytes) *chain_arena_bytes = 0;
+    if (literal_arena_bytes) *literal_arena_bytes = 0;
+    if (!n) return CZ_OK;
+    if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
+    CZ_HIP(c, hipSetDevice(c->device));
+    const size_t waves = (n + CZ_WG_THREADS - 1) / CZ_WG_THREADS;
+    uint8_t* tmp = nullptr;                                             /* frame_first | lit_first | frame_pre | scan_ctl | scan_wave */
+    const size_t o_ff = 0, o_lf = o_ff + n * 8, o_fp = o_lf + n * 8, o_ctl = (o_fp + n * 4 + 15) & ~(size_t)15, o_sw = o_ctl + CZ_SCAN_CTL_WORDS * 4, total = o_sw + waves * 72 * 4;
+    CZ_HIP(c, hipMalloc((void**)&tmp, total));
+    int st = CZ_OK;
+    do {
+        if (hipMemsetAsync(tmp + o_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream) != hipSuccess) { st = CZ_E_HIP; break; }
+        cz_batch_args a; memset(&a, 0, sizeof a);
+        a.in_base = (const uint8_t*)d_in_base; a.in_off = d_in_off; a.in_len = d_in_len; a.out_cap = d_out_cap; a.n = (uint32_t)n;
+        a.frame_first = (uint64_t*)(tmp + o_ff); a.lit_first = (uint64_t*)(tmp + o_lf); a.frame_pre = (uint32_t*)(tmp + o_fp);
+        a.scan_ctl = (uint32_t*)(tmp + o_ctl); a.scan_wave = (uint32_t*)(tmp + o_sw);
+        a.lit_arena = tmp;                                              /* (not touched by the counting pass: it only says "count literals too") */
+        a.chain_min_nseq = c->chain_min_nseq; a.scan_pass = 0;
+        hipLaunchKernelGGL(cz_scan_kernel, dim3((unsigned)waves), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { st = CZ_E_HIP; break; }
+        std::vector<uint64_t> h(2 * n);
+        if (hipMemcpy(h.data(), tmp, 2 * n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = CZ_E_HIP; break; }
+        unsigned long long units = 0, lbytes = 0;
+        for (size_t i = 0; i < n; i++) { units += h[i]; lbytes += h[n + i]; }
+        if (chain_arena_bytes) *chain_arena_bytes = (size_t)((units + 64 + 4096) * 8);
+        if (literal_arena_bytes) *literal_arena_bytes = (size_t)(lbytes + 64 + 4096);
+    } while (0);
+    (void)hipFree(tmp);
+    return st;
+} catch (const std::bad_alloc&) { return CZ_E_OUT_OF_MEMORY; }
+
 CZ_EXPORT int cz_decode_batch_device(cz_context* c, const void* d_in_base, const uint64_t* d_in_off, const uint64_t* d_in_len, size_t n,
                                      void* d_out_base, const uint64_t* d_out_off, const uint64_t* d_out_cap, cz_frame_result* d_results) {
     if (!c) return CZ_E_INVALID_ARG;

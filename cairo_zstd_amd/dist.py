@@ -74,7 +74,8 @@ def rebalance_frames(base, off, length, regen, device):
     """Moves frames between ranks so that every rank holds a byte-balanced share of the GLOBAL batch (each rank
     starts with a contiguous slice).  The weight of a frame is its algorithmic bytes (compressed + decoded).
     One exchange of the compressed bytes (all_to_all_single: RCCL on the GPUs, gloo in the CPU tests), before any
-    timing.  Returns (base, off, length, regen, global_index) of the frames this rank now owns."""
+    timing.  Returns (base, off, length, regen, global_index) of the frames this rank now owns; the same bytes as a tensor on
+    `device` are left in rebalance_frames.last_device_base."""
     import numpy as np
     rank, world = dist.get_rank(), dist.get_world_size()
     n = int(length.size)
@@ -99,5 +100,12 @@ def rebalance_frames(base, off, length, regen, device):
     noff = np.zeros(idx.size, dtype=np.uint64)
     if idx.size > 1:
         noff[1:] = np.cumsum(nlen[:-1])
-    nbase = np.concatenate([t_out.cpu().numpy(), np.zeros(64, np.uint8)])
+    # The exchanged bytes stay where the exchange left them: on the GPU under RCCL (dev_base: what the decode reads — no trip through
+    # the host in the data path).  The host copy is for the caller's CPU-side checks only.
+    dev_base = torch.cat([t_out, torch.zeros(64, dtype=torch.uint8, device=t_out.device)])
+    nbase = dev_base.cpu().numpy()
+    rebalance_frames.last_device_base = dev_base
     return nbase, noff, nlen, gregen[idx].astype(np.uint64), idx
+
+
+rebalance_frames.last_device_base = None

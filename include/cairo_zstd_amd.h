@@ -147,6 +147,13 @@ int cz_context_set_chain_arena(cz_context* ctx, size_t bytes);
  * (sequence execution only: sequence_execution.cairo:12-129) unless cz_context_set_exec_kernel turned it off; frames that
  * did not fit, or that are irregular in any way, are decoded from scratch by cz_decode_frames_kernel in the same call. */
 int cz_context_set_literal_arena(cz_context* ctx, size_t bytes);
+/* What the two arenas must hold for a batch that already sits on the device, from its headers alone (cz_scan_kernel's counting pass:
+ * block_decoder.cairo:237-321, literals_section.cairo:81-175, sequence_section.cairo:77-114; nothing is decoded): 8 bytes per
+ * sequence + 1 312 per block with sequences, and the Huffman-coded literals of blocks with sequences + 16 per block.  For set-up
+ * (it synchronises): size the arenas once for the largest batch a caller will decode — a rule of thumb (8 x the compressed bytes)
+ * takes 2.5 x as much for config 4a. */
+int cz_context_measure_batch(cz_context* ctx, const void* d_in_base, const uint64_t* d_in_off, const uint64_t* d_in_len, size_t n,
+                             const uint64_t* d_out_cap, size_t* chain_arena_bytes, size_t* literal_arena_bytes);
 /* Frames whose first sequences section holds fewer sequences than `n` skip the pre-pass (default 0: every frame
  * with sequences takes it — the pre-pass works block by block, so short chains cost little). */
 int cz_context_set_chain_min_sequences(cz_context* ctx, uint32_t n);
