@@ -57,7 +57,7 @@ def main():
            "algorithmic_read_bytes": cfg.get("compressed_bytes_rank0", cfg.get("compressed_bytes_per_gpu")),
            "algorithmic_write_bytes": cfg.get("decoded_bytes_rank0", cfg.get("decoded_bytes_per_gpu")),
            # bench.py quotes this file only for the kernel sources and launch options it was measured on
-           "kernel_source_hash": line.get("kernel_source_hash"), "chain_prepass": line.get("chain_prepass"), "exec_kernel": bool(line.get("exec_kernel"))}
+           "kernel_source_hash": line.get("kernel_source_hash"), "chain_prepass": line.get("chain_prepass"), "exec_kernel": bool(line.get("exec_kernel")), "wexec_kernel": bool(line.get("wexec_kernel", False))}
     for k in sorted(set(fetch) | set(write)):
         res["per_kernel"][k] = {"FETCH_SIZE_KB_per_launch": fetch.get(k), "WRITE_SIZE_KB_per_launch": write.get(k)}
     res["fetch_bytes_uncorrected"] = sum(fetch.values()) * 1024.0
