@@ -548,6 +548,14 @@ def main():
             t = json.load(open(pmc))
             if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel) and bool(t.get("wexec_kernel", True)) == bool(args.wexec_kernel):
                 line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
+                alt = os.path.join(ROOT, "profiles", "r4", f"pmc_hbm_traffic_{args.workload}_alt.json")
+                if os.path.exists(alt):
+                    ta = json.load(open(alt))
+                    if ta.get("kernel_source_hash") == _kernel_source_hash():
+                        line["roofline"]["traffic_without_wexec_kernel"] = ta["fetch_bytes_uncorrected"] + ta["write_bytes"]
+                        line["roofline"]["traffic_note"] = ("a counter pass runs a step's kernels one after the other: cz_wexec_kernel, first in line, then executes every frame it is listed "
+                                                            "(traffic: records + literals in, output out); traffic_without_wexec_kernel is the same step with cz_execute_frames_kernel alone "
+                                                            "(match sources from HBM).  Side by side, as timed, each kernel does its share of the frames: see roofline.exec_stage")
                 line["roofline"]["traffic_source"] = f"profiles/r4/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
             else:
                 line["roofline"]["traffic_source"] = "profiles/r4 PMC file is from other kernel sources or launch options: not quoted"
