@@ -515,6 +515,12 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         if (lit_pass) {
             /* next to the chain kernel, on streams of their own: cz_huf1_kernel (one wave per literals section: what fits beside the
                chain kernel's LDS) and cz_tile_kernel; behind the chain kernel, with the whole chip: cz_huf_kernel for what is left */
+            /* (cz_tile_kernel is submitted first: behind cz_huf1_kernel its 256-thread workgroups waited for register space beside that
+               kernel's waves — up to 1.3 ms for 0.1 ms of copies on the corpus-like mix) */
+            CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+            hipLaunchKernelGGL(cz_tile_kernel, dim3(c->tile_grid), dim3(256), 0, c->stream3, a);
+            CZ_HIP(c, hipGetLastError());
+            CZ_HIP(c, hipEventRecord(c->ev_join3, c->stream3));
             CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             int h1grid = c->huf1_grid;
 #ifdef CZ_EXPERIMENT
@@ -523,10 +529,6 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (!(c->debug_flags & CZ_DEBUG_NO_HUF1)) hipLaunchKernelGGL(cz_huf1_kernel, dim3(h1grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-            CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-            hipLaunchKernelGGL(cz_tile_kernel, dim3(c->tile_grid), dim3(256), 0, c->stream3, a);
-            CZ_HIP(c, hipGetLastError());
-            CZ_HIP(c, hipEventRecord(c->ev_join3, c->stream3));
             hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));

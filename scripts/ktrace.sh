@@ -2,7 +2,7 @@
 # per-kernel durations of one workload: rocprofv3 --kernel-trace --stats over scripts/kernel_times.py --child -> gpurun_out/r3/kt_<workload>.txt
 set -o pipefail
 WL=${1:-full_4a}; N=${2:-10000}
-O=gpurun_out/r3; mkdir -p $O
+O=gpurun_out/${KT_OUT:-r4}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf $O/ktr_$WL
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktr_$WL -- python3 scripts/kernel_times.py --child $WL $N > $O/ktr_$WL.log 2>&1 || { tail -5 $O/ktr_$WL.log; exit 1; }
