@@ -69,7 +69,7 @@ struct cz_context {
     uint8_t* lit_scratch = nullptr; int lit_slots = 0; uint32_t* work_counter = nullptr;
     const struct cz_dictionary* batch_dict = nullptr;                   /* cz_context_set_dictionary */
     hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_mid2 = nullptr, ev_stop = nullptr; bool timed = false, timed_chain = false, timed_exec = false;
-    bool wexec_kernel = true;              /* of those, frames of at most 128 KiB with enough sequences run on cz_wexec_kernel first (a workgroup per frame, window in LDS) */
+    bool wexec_kernel = true;              /* far-offset batches: cz_wexec_kernel (a workgroup per frame, window in LDS) side by side with cz_execute_frames_kernel */
     int wexec_cus = 0;                     /* CUs (= workgroups) cz_wexec_kernel runs on; 0: half of them */
     uint32_t debug_flags = 0;              /* CZ_DEBUG_* */
     uint32_t exec_variant_force = 0;       /* 0: cz_exec_variant decides; 4 / 8: that variant of cz_execute_frames_kernel (A/B runs) */
@@ -348,7 +348,7 @@ CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 
-/* Frames of at most 128 KiB with enough sequences run on cz_wexec_kernel (default, 1) or, like the other pre-passed frames, on cz_execute_frames_kernel (0). */
+/* Far-offset batches run cz_wexec_kernel side by side with cz_execute_frames_kernel (default, 1), or cz_execute_frames_kernel alone (0). */
 CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->wexec_kernel = on != 0; return CZ_OK; }
 /* A/B knobs of the side-by-side execute stage: CUs cz_wexec_kernel runs on (0: half), frames per CU of it that cz_execute_frames_kernel
    leaves to it at the end of a batch (0: default), force = 1: side by side whatever the batch's offsets look like. */
@@ -477,11 +477,13 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         const bool use_exec = c->exec_kernel && lit_pass && !c->batch_dict;
-        const bool use_wx = use_exec && c->wexec_kernel;
+        bool use_wx = use_exec && c->wexec_kernel;
         if (use_wx && !c->wexec_ready) {
-            CZ_HIP(c, hipFuncSetAttribute((const void*)cz_wexec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS_BYTES));
-            CZ_HIP(c, hipEventCreate(&c->ev_wx));
-            c->wexec_ready = true;
+            /* (a workgroup of cz_wexec_kernel asks for more LDS than the default limit: where the runtime will not grant it,
+               cz_execute_frames_kernel does the whole batch, as with cz_context_set_wexec_kernel(ctx, 0)) */
+            if (hipFuncSetAttribute((const void*)cz_wexec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS_BYTES) != hipSuccess ||
+                hipEventCreate(&c->ev_wx) != hipSuccess) { (void)hipGetLastError(); c->wexec_kernel = false; use_wx = false; a.wx_list = nullptr; a.wx_counter = nullptr; }
+            else c->wexec_ready = true;
         }
         if (use_wx) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }

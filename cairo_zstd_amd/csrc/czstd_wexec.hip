@@ -15,21 +15,30 @@
  *      summary against the incoming history and publishes the state before chunk c + 1.  Nothing else is serial: the chain of
  *      publications runs ahead of the data movement;
  *   3  literals go from the literal buffer (HBM, read once) to their place in the window;
- *   4  matches copy window -> window.  A match may go once every byte of its source is final: below the position up to which ALL
- *      earlier chunks are done (the minimum over the waves of "start of the chunk I have not finished"), or inside the lane's own
- *      chunk below the first match of the chunk that is not done yet (the in-chunk rounds of cz_sequences_rec_fast).  The oldest
- *      chunk in flight never waits for another one, so the pipeline cannot lock up.
- * Per block: barrier, tail literals (sequence_execution.cairo:72-78), the block's bytes window -> HBM.
+ *   4  matches copy window -> window.  A match may go once every byte of its source is final.  That is kept per byte: a bitmap
+ *      of the window in LDS, a bit set (ds_or) when the byte's literal or match copy has been written.  Below a static HORIZON —
+ *      the output position of the chunk this wave worked on two turns ago: every chunk before that one is complete, because a
+ *      wave takes its chunks in order — nothing is looked up; above it a lane tests the words of the bitmap that cover its
+ *      source.  The oldest chunk in flight never waits for another one, so the pipeline cannot lock up.
+ * A wave keeps TWO chunks in flight (step 1 of the next chunk is issued before the data movement of the current one), and step 2
+ * is a decoupled look-back over the last 64 entries rather than a wait for the predecessor (entry flags: sums there / outgoing
+ * history there / state BEHIND the chunk there).
+ * Per block: barrier, tail literals (sequence_execution.cairo:72-78), the block's bytes window -> HBM.  The window positions are
+ * block-relative; a block whose output exceeds the window is done in passes (the first sequence that does not fit sets
+ * ctl.reset_at; flush; the next pass starts there), and sources in earlier blocks are read from the frame's output in HBM.
  *
- * The kernel is a pure accelerator, like cz_chain_kernel: it takes the frames cz_scan_kernel listed for it (regular to the last
- * block, everything pre-passed, output <= 128 KiB, enough sequences to be worth a workgroup) and marks those it finished
- * (frame_pre[f] |= CZ_PRE_WXDONE, result record written).  On ANY irregularity — a check of execute_sequences that fails, a
- * frame the pre-pass kernels took back — it leaves the frame as it was; cz_execute_frames_kernel, which runs behind it and skips
- * the marked frames, then does that frame in the reference's order of detection.  Nothing here reports errors.
+ * The kernel is a pure accelerator, like cz_chain_kernel: it takes frames off the list cz_scan_kernel made for it (regular to the
+ * last block, everything pre-passed, enough sequences to be worth a workgroup), claims each with an atomic OR on frame_pre[f]
+ * (CZ_PRE_CLAIMED) and marks those it finished (CZ_PRE_WXDONE, result record written).  cz_execute_frames_kernel runs SIDE BY SIDE
+ * with it on the other CUs, claims frames the same way and leaves the last few listed frames per workgroup to this kernel.  The
+ * whole kernel returns at once unless the batch's offset codes are mostly far ones (cz_wx_side_by_side: the sums cz_chain_kernel
+ * left in chain_top): near-offset frames are bound by their chain of dependent matches and gain nothing here (profiles/r4/NOTES.md).
+ * On ANY irregularity — a check of execute_sequences that fails, a frame the pre-pass kernels took back — the frame goes on
+ * fallback_list as it was, and cz_decode_frames_kernel does it in the reference's order of detection.  Nothing here reports errors.
  */
 #define WX_WAVES 16u
 #define WX_THREADS (64u * WX_WAVES)
-#define WX_RING CZ_WX_RING                   /* the window: frames of at most this many decoded bytes */
+#define WX_RING CZ_WX_RING                   /* the window, bytes */
 #define WX_NS 64u                            /* look-back entries, one per chunk in flight and the 48 before (an entry is not reused before its readers are done with it) */
 #define WX_F_AGG 1u                          /* entry flags: the chunk's sums are there / its outgoing history / the state BEHIND the chunk */
 #define WX_F_HOK 2u

@@ -304,6 +304,15 @@ def test_chain_prepass_matches_oracle(cz, arena_mb, lit_mb):
                 if not ok:
                     bad.append((i, "XXH64"))
         assert not bad, bad[:10]
+        if arena_mb == 256 and lit_mb == 0:
+            # without a literal arena cz_scan_kernel must list the same frames for the chain kernel as with one (its literal and
+            # copy counts are not computed then, and must not be looked at)
+            n_chain = c.last_prepass_counts(len(frames))[0]
+            assert n_chain >= 600, n_chain
+            c.set_literal_arena(256 << 20)
+            cz.decode_batch_host(frames, caps, c)
+            with_chain, with_lits = c.last_prepass_counts(len(frames))
+            assert with_chain == n_chain and with_lits > 0, (n_chain, with_chain, with_lits)
         c.set_chain_arena(0)
         cz.decode_batch_host(frames[:4], caps[:4], c)
         assert c.last_chain_ms() == 0.0
