@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: the same batch decoded over and over through the pre-pass pipeline (three streams, seven kernels), every run into a
 freshly poisoned buffer and compared on the device with the first run (which is compared with the oracle) — looks for anything
-that depends on timing between the kernels.   python scripts/soak.py [repeats=40]"""
+that depends on timing between the kernels.   python scripts/soak.py [repeats=40] [workloads]
+CZ_WEXEC=force: every listed frame on cz_wexec_kernel whatever the batch's offset codes say; CZ_WEXEC=0: never."""
 import os
 import sys
 
@@ -27,6 +28,8 @@ for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw
     ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
     ctx.set_chain_arena(int(b.length.sum()) * 8 + (64 << 20))
     ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
+    wx = os.environ.get("CZ_WEXEC", "1")
+    ctx.set_wexec_kernel(wx != "0", force=wx == "force")
     ref_out = ref_res = None
     bad = 0
     for it in range(reps + 1):
@@ -59,7 +62,7 @@ for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw
                 got = t_res.cpu().numpy().view(cz.RESULT_DTYPE)[fr]; want = ref_res.cpu().numpy().view(cz.RESULT_DTYPE)[fr]
                 msg += f"\n      got  {got}\n      want {want}"
             print(msg, flush=True)
-    print(f"{kind:14s} {reps} repeats, {bad} differing", flush=True)
+    print(f"{kind:14s} {reps} repeats, {bad} differing; cz_wexec_kernel listed / finished / handed on {ctx.last_wexec_counts()}", flush=True)
     bad_total += bad
     ctx.close()
 print("TOTAL DIFFERING", bad_total)
