@@ -64,6 +64,12 @@ class Context:
         lib().cz_context_launch_info(self._h, C.byref(wg), C.byref(th), C.byref(cu))
         return dict(workgroups=wg.value, threads_per_workgroup=th.value, compute_units=cu.value)
 
+    def execute_grid(self):
+        """(waves of cz_execute_frames_kernel, waves of its 8-waves build) a batch launch runs with."""
+        a, b = C.c_int(), C.c_int()
+        lib().cz_context_execute_grid(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def set_chain_arena(self, nbytes: int, min_sequences: int | None = None):
         """Enable (nbytes > 0) / disable (0) the FSE-chain pre-pass (cz_chain_kernel) for batch decodes."""
         if min_sequences is not None:

@@ -74,6 +74,9 @@ def lib() -> C.CDLL:
     L.cz_context_synchronize.argtypes = [vp]
     L.cz_context_last_hip_error.restype = C.c_int
     L.cz_context_last_hip_error.argtypes = [vp]
+    if hasattr(L, "cz_context_execute_grid"):                          # (scripts/ab.sh also loads diagnostic builds of earlier sources)
+        L.cz_context_execute_grid.restype = C.c_int
+        L.cz_context_execute_grid.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cz_context_launch_info.restype = C.c_int
     L.cz_context_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.cz_context_last_kernel_ms.restype = C.c_int

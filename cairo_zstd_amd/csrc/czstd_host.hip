@@ -205,6 +205,13 @@ CZ_EXPORT int cz_context_launch_info(const cz_context* c, int* workgroups, int* 
     if (compute_units) *compute_units = c->num_cu;
     return CZ_OK;
 }
+/* Waves cz_execute_frames_kernel / cz_execute_frames8_kernel are launched with (0 before the first cz_context_set_chain_arena). */
+CZ_EXPORT int cz_context_execute_grid(const cz_context* c, int* waves, int* waves8) {
+    if (!c) return CZ_E_INVALID_ARG;
+    if (waves) *waves = c->exec_grid;
+    if (waves8) *waves8 = c->exec8_grid;
+    return CZ_OK;
+}
 CZ_EXPORT int cz_context_last_kernel_ms(cz_context* c, float* ms) {
     if (!c || !ms || !c->timed) return CZ_E_INVALID_ARG;
     CZ_HIP(c, hipSetDevice(c->device));

@@ -91,8 +91,23 @@ enum { CZ_P_HDR = 0, CZ_P_HUFBUILD, CZ_P_HUFDEC, CZ_P_SEQTAB, CZ_P_RING, CZ_P_CH
 #define CZ_RING_BYTES 2048u
 #define CZ_RING_BLOCK 1024u
 #define CZ_RING_NEED 768u   /* >= 64 sequences x 89 bits */
-#define CZ_OBUF_BYTES 1024u /* chunk output assembled in LDS when it is at most this long (cz_execute_chunk) */
-#define CZ_OBUF_MAXLEN 64u  /* ... and no literal run or match of the chunk is longer than this */
+/* The chunk buffer: a chunk's output is assembled in LDS when it is at most CZ_OBUF_BYTES long and no literal run or match of the
+   chunk is longer than CZ_OBUF_MAXLEN.  cz_execute_frames_kernel at 4 waves per SIMD has the LDS for 3 KiB (+ as much again for the
+   chunk's literals): chunks of real encoder output average ~900 bytes, and every chunk beyond the buffer pays a memory round
+   trip per dependency round (profiles/r4/NOTES.md). */
+#undef CZ_OBUF_BYTES
+#undef CZ_OBUF_MAXLEN
+#if defined(CZ_EXEC_ONLY) && CZ_EXEC_WAVES == 4 && !defined(CZ_EXP_SMALL_OBUF)
+#define CZ_OBUF_BYTES 3072u
+#ifdef CZ_EXP_MAXLEN
+#define CZ_OBUF_MAXLEN CZ_EXP_MAXLEN
+#else
+#define CZ_OBUF_MAXLEN 128u
+#endif
+#else
+#define CZ_OBUF_BYTES 1024u
+#define CZ_OBUF_MAXLEN 64u
+#endif
 
 
 /* ------------------------------------------------------------------ LDS layout */
@@ -136,7 +151,8 @@ struct CzShared {
     union {
         uint16_t huf[512];                                              /* cz_xxh64_frame stages 2 x 512 B here */
         struct { uint8_t stage[512]; } t1;
-        struct { __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16]; } t4;
+        struct { __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16];
+                 __attribute__((aligned(16))) uint8_t lstage[CZ_OBUF_BYTES + 32]; } t4;   /* lstage: the literals of the chunk in hand (cz_copy_long_runs) */
     } a;
     struct { struct { uint32_t llml[96]; } c; } b;
     CzBroadcast bc;
@@ -156,7 +172,8 @@ struct CzShared {
         struct { uint8_t stage[512]; int16_t probs0[256]; uint16_t counters0[256]; uint32_t wtab[512]; uint32_t rank_cnt[16], rank_idx[16]; } t1;
         struct { uint8_t stage[512]; int16_t probs[3][256]; uint16_t counters[3][256]; } t3;
         struct { __attribute__((aligned(16))) uint8_t mirror[16]; uint8_t ring[CZ_RING_BYTES]; int32_t rec_pos[64]; uint32_t rec_st[64];
-                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16]; } t4;   /* + one dump byte per lane (+ 7: cz_fast_group) */   /* mirror[8..15] == ring[2040..2047] */
+                 __attribute__((aligned(16))) uint8_t obuf[CZ_OBUF_BYTES + 16 + 64 + 16];   /* + one dump byte per lane (+ 7: cz_fast_group) */   /* mirror[8..15] == ring[2040..2047] */
+                 __attribute__((aligned(16))) uint8_t lstage[CZ_OBUF_BYTES + 32]; } t4;
     } a;
     struct {
         struct { __attribute__((aligned(4))) uint8_t hbits[264]; uint16_t sym_base[264]; uint32_t llml[96]; } c;   /* llml: [0..35] LL base | bits<<24, [40..92] ML */
@@ -1229,6 +1246,101 @@ __device__ static inline void cz_copy_group0(uint8_t* ob, uint32_t orel, uint32_
 #pragma unroll
     for (uint32_t j = 0; j < NMB; j++) ob[j < mlim ? drel + j : dump] = (uint8_t)(mw[j >> 2] >> (8 * (j & 3)));
 }
+/* Unaligned accesses to the chunk buffer through LDS-address-space pointers (the conversion from the generic pointer folds away
+   once the callers are inlined). */
+#ifdef CZ_EMU
+#define CZ_LDS_AS
+#else
+#define CZ_LDS_AS __attribute__((address_space(3)))
+#endif
+struct __attribute__((packed)) CzP16 { uint16_t v; };
+struct __attribute__((packed)) CzP32 { uint32_t v; };
+struct __attribute__((packed)) CzP64 { uint64_t v; };
+typedef CZ_LDS_AS uint8_t* cz_lptr;
+__device__ static inline cz_lptr cz_lds(uint8_t* p) { return (cz_lptr)p; }
+__device__ static inline uint64_t cz_lds_r64(cz_lptr p) { return ((CZ_LDS_AS const CzP64*)p)->v; }
+/* exactly n <= 8 bytes of v */
+__device__ static inline void cz_lds_wn(cz_lptr q, uint64_t v, uint32_t n) {
+    if (n >= 8u) { ((CZ_LDS_AS CzP64*)q)->v = v; return; }
+    if (n & 4u) { ((CZ_LDS_AS CzP32*)q)->v = (uint32_t)v; q += 4; v >>= 32; }
+    if (n & 2u) { ((CZ_LDS_AS CzP16*)q)->v = (uint16_t)v; q += 2; v >>= 16; }
+    if (n & 1u) *q = (uint8_t)v;
+}
+/* n bytes to ob + d from ob + d - off inside the chunk buffer: the forward byte copy of decode_buffer.cairo:95-127, eight bytes a
+   step.  With off < n the output is periodic from d - off on, so any earlier multiple of off is as good a distance: the distance
+   doubles until it covers a step.  (A step reads at most 7 bytes beyond what it uses.) */
+__device__ static inline void cz_lane_l2l(uint8_t* ob_, uint32_t d, uint32_t off, uint32_t n) {
+    const cz_lptr ob = cz_lds(ob_);
+    uint32_t copied = 0, dist = off;
+    while (copied < n) {
+        while (dist < 8u && 2u * dist <= off + copied) dist += dist;
+        uint32_t step = n - copied < dist ? n - copied : dist;
+        if (step > 8u) step = 8u;
+        cz_lds_wn(ob + d + copied, cz_lds_r64(ob + d + copied - dist), step);
+        copied += step;
+    }
+}
+/* Chunks with longer runs (a literal run above 4 or a match above 8 bytes; none above CZ_OBUF_MAXLEN): what comes from global
+ * memory comes in ONE round trip (two for far matches above 64 bytes).  The literals of a chunk are one contiguous stretch of the
+ * literal buffer — [lit_used, lit_used + sum_ll) —, so the wave fetches them with 16-byte loads, a KiB per instruction, into a
+ * staging area in LDS, and every lane moves its run LDS -> LDS from there; the far matches' bytes are loaded by their lanes, four
+ * 16-byte pieces at a time, every load issued before the first use.  (One piece per loop turn, first the literal runs and then
+ * the matches, was a round trip per 16 bytes of the longest run of each kind.)  A 16-byte load may read beyond its run where
+ * that stays inside the literal buffer / the frame's output buffer; only the run's bytes are written. */
+__device__ static inline void cz_copy_long_runs(uint8_t* ob, uint8_t* stg, uint32_t orel, uint32_t drel, uint32_t lrel, uint32_t ll, uint32_t ml, uint32_t sum_ll,
+                                                const CzLit& lit, uint32_t lit_used, cz_gcptr ms, uint64_t ms_pos, uint64_t cap, int far_plain) {
+    constexpr uint32_t NST = CZ_OBUF_BYTES / 1024u;
+    const int staged = !lit.rle;
+    uint4 sv[NST], mv[4];
+#pragma unroll
+    for (uint32_t t = 0; t < NST; t++) {
+        const uint32_t lo = 1024u * t + 16u * (uint32_t)LANE;
+        sv[t] = uint4{0, 0, 0, 0};
+        if (staged && 1024u * t < sum_ll) {                              /* (uniform) */
+#if defined(CZ_EXP_LITNEAR)   /* diagnostic only (wrong output): the literals always from the start of the literal buffer (cache hits) */
+            if (lo < sum_ll) sv[t] = cz_load_upto16((cz_gcptr)lit.p + lo, sum_ll - lo < 16u ? sum_ll - lo : 16u, (uint64_t)lo + 16u <= lit.len);
+#elif defined(CZ_EXP_NOLOADS)  /* diagnostic only (wrong output): no loads at all here */
+            if (lo < sum_ll) sv[t] = uint4{lo, lo, lo, lo};
+#else
+            if (lo < sum_ll) sv[t] = cz_load_upto16((cz_gcptr)lit.p + lit_used + lo, sum_ll - lo < 16u ? sum_ll - lo : 16u, (uint64_t)lit_used + lo + 16u <= lit.len);
+#endif
+        }
+    }
+    for (uint32_t k = 0; k == 0 || __ballot(far_plain && k < ml); k += 64) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t at = k + 16u * j;
+            mv[j] = uint4{0, 0, 0, 0};
+#ifdef CZ_EXP_NOLOADS
+            if (far_plain && at < ml) mv[j] = uint4{ml, ml, ml, ml};
+#else
+            if (far_plain && at < ml) mv[j] = cz_load_upto16(ms + at, ml - at < 16u ? ml - at : 16u, ms_pos + at + 16u <= cap);
+#endif
+        }
+        if (k == 0) {
+#pragma unroll
+            for (uint32_t t = 0; t < NST; t++) if (staged && 1024u * t < sum_ll) __builtin_memcpy(stg + 1024u * t + 16u * (uint32_t)LANE, &sv[t], 16);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t at = k + 16u * j;
+            if (far_plain && at < ml) (cz_lds_store_upto16)(ob + drel + at, mv[j], ml - at < 16u ? ml - at : 16u);
+        }
+    }
+    cz_wave_sync();
+    for (uint32_t k = 0; __ballot(k < ll); k += 16) {
+        if (k < ll) {
+            uint4 v;
+            if (lit.rle) { const uint32_t w = 0x01010101u * lit.byte; v = uint4{w, w, w, w}; }
+#ifdef CZ_EXP_NOSTAGE   /* diagnostic only: the literals by their lanes from global memory, a round trip per 16 bytes (the scheme before) */
+            else v = cz_load_upto16((cz_gcptr)lit.p + lit_used + lrel + k, ll - k < 16u ? ll - k : 16u, (uint64_t)lit_used + lrel + k + 16u <= lit.len);
+#else
+            else __builtin_memcpy(&v, stg + lrel + k, 16);
+#endif
+            (cz_lds_store_upto16)(ob + orel + k, v, ll - k < 16u ? ll - k : 16u);
+        }
+    }
+}
 __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan& p) {
     CZ_PROF_DECL; CZ_PROF_T0();
     const uint32_t ll = p.ll, ml = p.ml, off = p.off, tot = ll + ml, incl_tot = p.orel + tot;
@@ -1265,29 +1377,7 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         const unsigned long long big = __ballot(ll > 4 || ml > 8), mid = __ballot(ll > 2 || ml > 4);
         if (!mid) cz_copy_group0<2, 4>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
         else if (!big) cz_copy_group0<4, 8>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
-        else {
-            cz_copy_group0<8, 16>(ob, orel, drel, ll, ml, ls, ms, lit, far_plain, lit_wide);
-            /* the rest of longer runs (up to CZ_OBUF_MAXLEN), sixteen bytes per step and every lane's load of a step issued before
-               the wait: a byte loop here pays one memory round trip per byte of the longest run, which on real encoder output
-               (text: runs of 10..40 bytes in most chunks) was most of this path's time.  A 16-byte load may read beyond its run
-               where that stays inside the literal buffer / the frame's output buffer; only the run's bytes are written. */
-            for (uint32_t k = 8; __ballot(k < ll); k += 16) {
-                if (k < ll) {
-                    const uint32_t m = ll - k < 16u ? ll - k : 16u;
-                    uint4 v;
-                    if (lit.rle) { const uint32_t w = 0x01010101u * lit.byte; v = uint4{w, w, w, w}; }
-                    else v = cz_load_upto16((cz_gcptr)ls + k, m, (uint64_t)lit_start + k + 16u <= lit.len);
-                    (cz_lds_store_upto16)(ob + orel + k, v, m);
-                }
-            }
-            for (uint32_t k = 16; __ballot(far_plain && k < ml); k += 16) {
-                if (far_plain && k < ml) {
-                    const uint32_t m = ml - k < 16u ? ml - k : 16u;
-                    const uint4 v = cz_load_upto16((cz_gcptr)ms + k, m, dst - off + k + 16u <= x.cap);
-                    (cz_lds_store_upto16)(ob + drel + k, v, m);
-                }
-            }
-        }
+        else cz_copy_long_runs(ob, sh.a.t4.lstage, orel, drel, p.lrel, ll, ml, sum_ll, lit, x.lit_used, (cz_gcptr)ms, dst - off, x.cap, far_plain);
         if (__ballot(far_period)) {                                     /* period-off pattern (decode_buffer.cairo:101-120) */
             uint8_t mt[8]; uint32_t idx = 0;
 #pragma unroll
@@ -1300,30 +1390,51 @@ __device__ static int cz_chunk_copy(CzExecCtx& x, const CzLit& lit, const CzPlan
         CZ_PROF_ACC(CZ_P_LITCOPY);
         /* matches that read this chunk's output: rounds.  W = destination of the first undone match;
            a match may go once its source range (clipped to its own destination) lies below W. */
+#ifdef CZ_EXP_NOROUNDS   /* diagnostic only (wrong output): ... without the dependency rounds */
+        int done = 1;
+#else
         int done = !near;
+#endif
         const int32_t send = srel + (int32_t)span;                      /* <= drel */
         for (;;) {
             const unsigned long long pend = __ballot(!done);
             if (!pend) break;
             const int f = __ffsll((long long)pend) - 1;
             const int32_t W = (int32_t)cz_readlane(drel, cz_unii(f));
-            if (!done && send <= W) {
-                uint32_t idx = 0;
-                for (uint32_t k = 0; k < ml; k++) {
-                    const int32_t q = srel + (int32_t)idx;
-                    ob[drel + k] = q < 0 ? cout[q] : ob[q];
-                    idx = idx + 1 == off ? 0 : idx + 1;
+            const int ready = !done && send <= W;
+            if (ready) {
+#if defined(CZ_EXEC_ONLY) && !defined(CZ_EXP_L2L_OFF)   /* (cz_decode_frames_kernel keeps the byte loop: with cz_lane_l2l in it this compiler ended
+                                                           its build with "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base") */
+                if (srel >= 0) cz_lane_l2l(ob, drel, off, ml);          /* the source lies inside the chunk buffer: 8 bytes a step */
+                else
+#endif
+                {
+                    uint32_t idx = 0;
+                    for (uint32_t k = 0; k < ml; k++) {
+                        const int32_t q = srel + (int32_t)idx;
+                        ob[drel + k] = q < 0 ? cout[q] : ob[q];
+                        idx = idx + 1 == off ? 0 : idx + 1;
+                    }
                 }
-                done = 1;
             }
+            if (ready) done = 1;
             cz_wave_sync();
         }
-        /* write the assembled chunk: 4 bytes per lane per pass (the global address need not be aligned).
+        /* write the assembled chunk: 16 bytes per lane per pass (the global address need not be aligned).
            Later loads of these bytes by this wave are ordered behind the stores by the memory pipeline. */
+#ifndef CZ_EXP_NOSTORE   /* diagnostic only (wrong output): ... without the stores of the assembled chunk */
+#ifdef CZ_EXP_STORE4
         for (uint32_t i = 4u * (uint32_t)LANE; i < sum_tot; i += 256) {
             if (i + 4 <= sum_tot) { uint32_t w = *(const uint32_t*)(ob + i); __builtin_memcpy(cout + i, &w, 4); }
             else for (uint32_t j = i; j < sum_tot; j++) cout[j] = ob[j];
         }
+#else
+        for (uint32_t i = 16u * (uint32_t)LANE; i < sum_tot; i += 1024) {
+            if (i + 16 <= sum_tot) { const uint4 w = *(const uint4*)(ob + i); __builtin_memcpy(cout + i, &w, 16); }
+            else for (uint32_t j = i; j < sum_tot; j++) cout[j] = ob[j];
+        }
+#endif
+#endif
         cz_wave_sync();
         CZ_PROF_ACC(CZ_P_MATCH);
         x.produced += sum_tot; x.lit_used += sum_ll;

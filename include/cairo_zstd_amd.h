@@ -73,6 +73,8 @@ int  cz_context_synchronize(cz_context* ctx);
 int  cz_context_last_hip_error(const cz_context* ctx);
 /* Kernel-launch geometry actually used (for bench / roofline reports). */
 int  cz_context_launch_info(const cz_context* ctx, int* workgroups, int* threads_per_wg, int* compute_units);
+/* Waves the execute-stage kernels of a batch launch run with: cz_execute_frames_kernel (4 waves per SIMD) and its 8-waves build. */
+int  cz_context_execute_grid(const cz_context* ctx, int* waves, int* waves8);
 
 /* ------------------------------------------------------- 2. batch (GPU hot path) */
 /*

@@ -17,9 +17,9 @@ def child(kind, n):
     import numpy as np
     import torch
     import cairo_zstd_amd as cz
-    from cairo_zstd_amd import synth
-    b = synth.generate(kind, n, nthreads=16)
-    out_off, out_cap, total = b.out_layout(256)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from _batches import make_batch
+    b, out_off, out_cap, total = make_batch(kind, n)
     dev = torch.device("cuda:0")
     t = [torch.from_numpy(x).to(dev) for x in (b.base, b.off.astype(np.int64), b.length.astype(np.int64), out_off.astype(np.int64), out_cap.astype(np.int64))]
     t_out = torch.empty(total, dtype=torch.uint8, device=dev)
@@ -54,7 +54,7 @@ def child(kind, n):
         ok = ok and nbad == 0
         print(f"oracle check: {nbad} of {n} frames differ", flush=True)
     print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
-          f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  near/far/long {ctx.last_sequence_stats()}  ok={ok}", flush=True)
+          f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  near/far/long {ctx.last_sequence_stats()}  execute grid {ctx.execute_grid() if hasattr(cz.lib(), 'cz_context_execute_grid') else '?'}  ok={ok}", flush=True)
     ctx.close()
 
 

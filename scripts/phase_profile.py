@@ -21,8 +21,9 @@ PHASES = ["hdr", "huf_build", "huf_decode", "seq_tables", "ring", "chain", "extr
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "full_4a"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    b = synth.generate(kind, n)
-    out_off, out_cap, total = b.out_layout()
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from _batches import make_batch
+    b, out_off, out_cap, total = make_batch(kind, n)
     dev = torch.device("cuda:0")
     t = [torch.from_numpy(x).to(dev) for x in (b.base, b.off.astype(np.int64), b.length.astype(np.int64), out_off.astype(np.int64), out_cap.astype(np.int64))]
     t_out = torch.empty(total, dtype=torch.uint8, device=dev)

@@ -136,6 +136,17 @@ def test_emu_execute_frames_kernel():
     done = int(err.split("EMU_EXEC: ")[1].split()[0])
     assert 0 < done < len(frames), (done, len(frames))                  # some frames took it, the malformed ones did not
 
+def test_emu_execute_frames_kernel_chunk_buffer_long_runs():
+    """The chunk buffer of cz_execute_frames_kernel at 4 waves per SIMD (3 KiB, runs up to 128 bytes: literals fetched by the wave
+    into the staging area, far matches four 16-byte pieces a turn, near matches 8 bytes a step): corpus files of 12-40 KB,
+    whose chunks run to a few KB, under ASan/UBSan."""
+    pairs = [p for p in corpus_pairs(max_orig=40000) if len(p[2]) >= 12000][:4]
+    assert len(pairs) >= 2
+    _run_and_compare([z for _, z, _ in pairs], [len(o) + 16 for _, _, o in pairs], chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True)
+    done = int(emu_runner.run.last_stderr.split("EMU_EXEC: ")[1].split()[0])
+    assert done == len(pairs), (done, len(pairs))
+
+
 def test_emu_wexec_kernel():
     """cz_wexec_kernel (czstd_wexec.hip: several waves per frame, LDS window, look-back over chunk entries, bitmap of final bytes)
     under ASan/UBSan with 4 waves per workgroup, ahead of cz_execute_frames_kernel and cz_decode_frames_kernel: corpus frames,
