@@ -16,11 +16,20 @@ from cairo_zstd_amd import synth
 
 def main():
     total_bad = 0
-    for kind, n, first in (("mix", 6000, 100000), ("mix", 6000, 300000), ("mix!", 6000, 500000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000),
-                           ("raw_rle", 300, 11000)):
+    sets = (("mix", 6000, 100000), ("mix", 6000, 300000), ("mix!", 6000, 500000), ("full_4a", 300, 5000), ("full_4b", 150, 7000), ("huf_literals", 200, 9000),
+            ("raw_rle", 300, 11000), ("real", 1536, 1), ("real!", 1536, 2))
+    only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+    for kind, n, first in sets:
+        if only and kind not in only:
+            continue
         damaged = kind.endswith("!")                                     # every third frame gets one flipped bit or loses its tail
         kind = kind.rstrip("!")
-        b = synth.generate(kind, n, first_index=first, nthreads=16)
+        if kind == "real":                                               # frames made by the box's libzstd (the bench line's real_libzstd_l3)
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from _batches import make_batch
+            b = make_batch("real", n, pad=0)[0]
+        else:
+            b = synth.generate(kind, n, first_index=first, nthreads=16)
         if damaged:
             rng = np.random.default_rng(first)
             for i in range(0, n, 3):
@@ -31,7 +40,12 @@ def main():
                     b.base[o + int(rng.integers(4, ln))] ^= np.uint8(1 << int(rng.integers(0, 8)))
         frames = [b.frame(i) for i in range(n)]
         caps = [int(r) for r in b.regen]                                 # the capacities the oracle gets below (out_layout)
-        o_off, o_cap, o_total = b.out_layout(64)
+        if kind == "real":
+            o_cap = b.regen.astype(np.uint64)
+            o_off = (np.concatenate([[0], np.cumsum((o_cap + 63) // 64 * 64)[:-1]])).astype(np.uint64)
+            o_total = int(o_off[-1] + o_cap[-1])
+        else:
+            o_off, o_cap, o_total = b.out_layout(64)
         _, olen, ost = oracle.decode_batch(b.base, b.off, b.length, o_off, o_cap, int(o_total) + 256, nthreads=32)
         ref_out = _
         for prepass in (0, 1, 2):                                        # 2: pre-pass + literals pass
