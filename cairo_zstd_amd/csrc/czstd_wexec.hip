@@ -56,7 +56,14 @@
 #include <stdio.h>
 #define WX_SPIN_GUARD(cnt, ...) do { if (++(cnt) == 20000u) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 #define WX_DBG(...) do { if (getenv("EMU_WX_DBG")) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+#define WX_AT(n) do { emu_site[threadIdx.x] = (void*)(uintptr_t)(0x1000 + (n)); } while (0)   /* where a lane is, for the emulator's watchdog */
+/* a word another wave may change while this wave reads it, made wave-uniform: on the device v_readfirstlane; the emulator's
+   readfirstlane is the identity (its callers pass uniform values), so here the lanes really take lane 0's copy — else a wave's
+   lanes part ways on ctl.reset_at / ctl.err and its barriers no longer pair up */
+#define WX_UNI(v) ((uint32_t)__shfl((int)(v), 0))
 #else
+#define WX_UNI(v) cz_uni(v)
+#define WX_AT(n) do { } while (0)
 #define WX_FENCE() asm volatile("" ::: "memory")
 #define WX_PAUSE() __builtin_amdgcn_s_sleep(1)
 #define WX_SPIN_GUARD(cnt, ...) do { } while (0)
@@ -84,6 +91,8 @@ struct WxCtl {
     uint32_t fin[WX_RING / 32u + 4u];                          /* one bit per byte of the window: final (set by the sequence that wrote it) */
     uint32_t err;                                              /* some wave met something irregular: the frame is left to cz_execute_frames_kernel */
     uint32_t reset_at;                                         /* first chunk of the block whose output does not fit the window any more (WX_INF: none) */
+    uint32_t slow_at;                                          /* ... and, when it is the same chunk, it would not fit an EMPTY window either: wx_slow_chunk does it (WX_INF: none) */
+    uint32_t slow_ok, slow_P, slow_L;                          /* wx_slow_chunk: its checks passed; positions behind the chunk */
     /* written by thread 0 between barriers */
     uint32_t fidx;
     uint32_t go;                                               /* 0 end of frame (ok), 1 block follows, 2 give the frame up */
@@ -271,6 +280,68 @@ __device__ static inline uint32_t wx_resolve(uint32_t s, uint32_t h0, uint32_t h
     return (s & WX_REL) ? base + (s & 0xFFFFu) - 0x8000u : s;
 }
 
+/* Step 1 of a chunk: values, the two prefix sums, the chunk's history transform (everything that does not depend on the chunks before) */
+struct WxStep1 { uint32_t ll, ml, orel, lrel, asym, sum_ll, sum_tot, o0, o1, o2; int active, bad, habs; };
+__device__ static inline WxStep1 wx_step1(const WxCtl& ctl, uint64_t r, cz_gcptr bits, uint32_t nseq, uint32_t y) {
+    const uint32_t lane = (uint32_t)LANE;
+    WxStep1 s1;
+    const uint32_t cnt = nseq - 64u * y < 64u ? nseq - 64u * y : 64u;
+    const int active = lane < cnt;
+    uint32_t ll = 0, ml = 0, ov = 4;
+    if (!__ballot((uint32_t)(r >> 32) & CZC_REC_WIDE)) { const uint32_t v = wx_rec_values<0>(ctl, r, bits, ll, ml); if (active) ov = v; else { ll = 0; ml = 0; } }
+    else if (active) ov = wx_rec_values<1>(ctl, r, bits, ll, ml);
+    s1.bad = active && ov >= 0x40000000u;                        /* (also keeps pushed values clear of WX_REL) */
+    const uint32_t tot = ll + ml;
+    if (!__ballot((ll | ml) >= 512u)) {                         /* both prefix sums in one scan */
+        const uint32_t pk = ll | (tot << 16), incl = cz_wave_incl_scan(pk), sums = cz_readlane(incl, 63), excl = incl - pk;
+        s1.sum_ll = sums & 0xFFFFu; s1.sum_tot = sums >> 16; s1.lrel = excl & 0xFFFFu; s1.orel = excl >> 16;
+    } else {
+        const uint32_t il = cz_wave_incl_scan(ll), it = cz_wave_incl_scan(tot);
+        s1.sum_ll = cz_readlane(il, 63); s1.sum_tot = cz_readlane(it, 63); s1.lrel = il - ll; s1.orel = it - tot;
+    }
+    /* history (sequence_execution.cairo:85-129): cz_history's packed transforms; pushed values stay symbolic where they are
+       "offset_value 3 with no literals" = what slot 0 held before the lane, minus one */
+    uint32_t T, M;
+    const int dec = active && ov == 3 && ll == 0;
+    {
+        const uint32_t kind = !active ? 0u : (ov > 3 ? 3u : ov - (ll > 0 ? 1u : 0u));
+        const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? (0x00010080u | lane) : 0x00010002u;
+        T = (kind & 2u) ? t23 : t01;
+        M = kind == 3u ? 0xFFu : 0u;
+    }
+#define WX_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pM = cz_dpp<CTRL, RM>(0u, M); \
+    const uint32_t R = __builtin_amdgcn_perm(T, pT, T); const uint32_t Mn = __builtin_amdgcn_perm(M, pM, T); \
+    T = (T & M) | (R & ~M); M = Mn; } while (0)
+    WX_HT_STEP(CZ_DPP_SHR1, 0xF); WX_HT_STEP(CZ_DPP_SHR2, 0xF); WX_HT_STEP(CZ_DPP_SHR4, 0xF); WX_HT_STEP(CZ_DPP_SHR8, 0xF);
+    WX_HT_STEP(CZ_DPP_BCAST15, 0xA); WX_HT_STEP(CZ_DPP_BCAST31, 0xC);
+#undef WX_HT_STEP
+    uint32_t pv = ov - 3u;
+    const unsigned long long dm = __ballot(dec);
+    if (dm) {
+        const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T);  /* transform of everything before the lane */
+        for (unsigned long long m = dm; m; m &= m - 1) {
+            const int j = cz_unii(__ffsll((long long)m) - 1);
+            const uint32_t bT = cz_readlane(eT, j) & 0xFFu;
+            const uint32_t before = (bT & 0x80u) ? cz_readlane(pv, cz_unii((int)(bT & 63u))) : (WX_REL | ((bT & 3u) << 29) | 0x8000u);
+            if ((int)lane == j) pv = before - 1u;
+        }
+    }
+    const uint32_t pushed = __shfl(pv, (int)(T & 63u));         /* every lane takes part */
+    s1.asym = (T & 0x80u) ? pushed : (WX_REL | ((T & 3u) << 29) | 0x8000u);
+    const uint32_t fT = cz_readlane(T, 63);
+    uint32_t osym[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t tk = (fT >> (8 * k)) & 0xFFu;
+        const uint32_t pk_ = cz_readlane(pv, cz_unii((int)(tk & 63u)));
+        osym[k] = (tk & 0x80u) ? pk_ : (WX_REL | ((tk & 3u) << 29) | 0x8000u);
+    }
+    s1.ll = ll; s1.ml = ml; s1.active = active;
+    s1.o0 = cz_uni(osym[0]); s1.o1 = cz_uni(osym[1]); s1.o2 = cz_uni(osym[2]);
+    s1.habs = !((s1.o0 | s1.o1 | s1.o2) & WX_REL);
+    return s1;
+}
+
 /* Matches of one chunk (step 4), in rounds: a match goes once every byte of its source is final.  Below `horizon` — the end of the
  * chunk this wave worked on two turns ago — everything is: a chunk passes its look-back only when all chunks before it have
  * published their sums, i.e. when their waves have finished the data phase two chunks before those.  Above it the `final` bitmap
@@ -303,7 +374,7 @@ __device__ static inline unsigned long long wx_match_rounds(WxCtl& ctl, uint8_t*
         }
         const unsigned long long rm = __ballot(ready);
         if (!rm) {                                                      /* every match left waits for another wave (or the frame has been given up) */
-            if (first || cz_uni(wx_ld(&ctl.err))) break;
+            if (first || WX_UNI(wx_ld(&ctl.err))) break;
             WX_PAUSE(); WX_PROF_CNT(8);
             WX_SPIN_GUARD(spins, "WX SPIN match: lane %u undone %d opos %u ll %u ml %u off %u src %u slen %u horizon %u rbase %u\n", lane, undone, opos, ll, ml, off, src, slen, horizon, rbase);
             continue;
@@ -375,66 +446,15 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
     uint32_t y = yfirst; int have_x = 0;
     unsigned long long m_undone = 0;                                    /* matches of chunk x that are not written yet */
     for (;;) {
-        const int have_y = y < nch && y < cz_uni(wx_ld(&ctl.reset_at));
+        const int have_y = y < nch && y < WX_UNI(wx_ld(&ctl.reset_at));
         if (have_y) {
             /* 1: values, sums, the chunk's history transform */
             const uint64_t r = r1;
             r1 = r2; r2 = r3; r3 = load_rec(y + 3u * nwaves);
             WX_PROF_T0(); WX_PROF_CNT(9);
-            const uint32_t cnt = nseq - 64u * y < 64u ? nseq - 64u * y : 64u;
-            const int active = lane < cnt;
-            uint32_t ll = 0, ml = 0, ov = 4;
-            if (!__ballot((uint32_t)(r >> 32) & CZC_REC_WIDE)) { const uint32_t v = wx_rec_values<0>(ctl, r, bits, ll, ml); if (active) ov = v; else { ll = 0; ml = 0; } }
-            else if (active) ov = wx_rec_values<1>(ctl, r, bits, ll, ml);
-            a_bad = active && ov >= 0x40000000u;                        /* (also keeps pushed values clear of WX_REL) */
-            const uint32_t tot = ll + ml;
-            if (!__ballot((ll | ml) >= 512u)) {                         /* both prefix sums in one scan */
-                const uint32_t pk = ll | (tot << 16), incl = cz_wave_incl_scan(pk), sums = cz_readlane(incl, 63), excl = incl - pk;
-                a_sum_ll = sums & 0xFFFFu; a_sum_tot = sums >> 16; a_lrel = excl & 0xFFFFu; a_orel = excl >> 16;
-            } else {
-                const uint32_t il = cz_wave_incl_scan(ll), it = cz_wave_incl_scan(tot);
-                a_sum_ll = cz_readlane(il, 63); a_sum_tot = cz_readlane(it, 63); a_lrel = il - ll; a_orel = it - tot;
-            }
-            /* history (sequence_execution.cairo:85-129): cz_history's packed transforms; pushed values stay symbolic where they are
-               "offset_value 3 with no literals" = what slot 0 held before the lane, minus one */
-            uint32_t T, M;
-            const int dec = active && ov == 3 && ll == 0;
-            {
-                const uint32_t kind = !active ? 0u : (ov > 3 ? 3u : ov - (ll > 0 ? 1u : 0u));
-                const uint32_t t01 = (kind & 1u) ? 0x00020001u : CZ_T_ID, t23 = (kind & 1u) ? (0x00010080u | lane) : 0x00010002u;
-                T = (kind & 2u) ? t23 : t01;
-                M = kind == 3u ? 0xFFu : 0u;
-            }
-#define WX_HT_STEP(CTRL, RM) do { const uint32_t pT = cz_dpp<CTRL, RM>(CZ_T_ID, T), pM = cz_dpp<CTRL, RM>(0u, M); \
-            const uint32_t R = __builtin_amdgcn_perm(T, pT, T); const uint32_t Mn = __builtin_amdgcn_perm(M, pM, T); \
-            T = (T & M) | (R & ~M); M = Mn; } while (0)
-            WX_HT_STEP(CZ_DPP_SHR1, 0xF); WX_HT_STEP(CZ_DPP_SHR2, 0xF); WX_HT_STEP(CZ_DPP_SHR4, 0xF); WX_HT_STEP(CZ_DPP_SHR8, 0xF);
-            WX_HT_STEP(CZ_DPP_BCAST15, 0xA); WX_HT_STEP(CZ_DPP_BCAST31, 0xC);
-#undef WX_HT_STEP
-            uint32_t pv = ov - 3u;
-            const unsigned long long dm = __ballot(dec);
-            if (dm) {
-                const uint32_t eT = cz_dpp<CZ_DPP_WAVE_SHR1, 0xF>(CZ_T_ID, T);  /* transform of everything before the lane */
-                for (unsigned long long m = dm; m; m &= m - 1) {
-                    const int j = cz_unii(__ffsll((long long)m) - 1);
-                    const uint32_t bT = cz_readlane(eT, j) & 0xFFu;
-                    const uint32_t before = (bT & 0x80u) ? cz_readlane(pv, cz_unii((int)(bT & 63u))) : (WX_REL | ((bT & 3u) << 29) | 0x8000u);
-                    if ((int)lane == j) pv = before - 1u;
-                }
-            }
-            const uint32_t pushed = __shfl(pv, (int)(T & 63u));         /* every lane takes part */
-            a_asym = (T & 0x80u) ? pushed : (WX_REL | ((T & 3u) << 29) | 0x8000u);
-            const uint32_t fT = cz_readlane(T, 63);
-            uint32_t osym[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const uint32_t tk = (fT >> (8 * k)) & 0xFFu;
-                const uint32_t pk_ = cz_readlane(pv, cz_unii((int)(tk & 63u)));
-                osym[k] = (tk & 0x80u) ? pk_ : (WX_REL | ((tk & 3u) << 29) | 0x8000u);
-            }
-            a_ll = ll; a_ml = ml; a_active = active;
-            a_o0 = cz_uni(osym[0]); a_o1 = cz_uni(osym[1]); a_o2 = cz_uni(osym[2]);
-            a_habs = !((a_o0 | a_o1 | a_o2) & WX_REL);
+            const WxStep1 s1 = wx_step1(ctl, r, bits, nseq, y);
+            a_ll = s1.ll; a_ml = s1.ml; a_orel = s1.orel; a_lrel = s1.lrel; a_asym = s1.asym; a_active = s1.active; a_bad = s1.bad;
+            a_sum_ll = s1.sum_ll; a_sum_tot = s1.sum_tot; a_o0 = s1.o0; a_o1 = s1.o1; a_o2 = s1.o2; a_habs = s1.habs;
             /* the chunk's sums — and its outgoing history when that does not depend on the incoming one (three pushes in 64
                sequences: nearly always) — are published at once */
             if (lane == 0) {
@@ -504,7 +524,7 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
                     const unsigned long long below = (1ull << k) - 1ull;
                     if ((aggm & below) == below && (cz_readlane(f, 0) & WX_F_HOK)) break;
                 }
-                if (cz_uni(wx_ld(&ctl.reset_at)) <= y) { stop = 1; break; }   /* a chunk before this one did not fit the window: the next pass */
+                if (WX_UNI(wx_ld(&ctl.reset_at)) <= y) { stop = 1; break; }   /* a chunk before this one did not fit the window: the next pass */
                 WX_PAUSE(); WX_PROF_CNT(6);
                 WX_SPIN_GUARD(lbspins, "WX SPIN look-back: y %u lane %u w0 %08x\n", y, lane, w0);
             }
@@ -521,9 +541,10 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
         /* (a position that has left the buffer stays where it is: no wrap-around can bring it back inside) */
         const uint32_t P_out = P_in > wlimit ? P_in : P_in + a_sum_tot, L_out = L_in > lit_len ? L_in : L_in + a_sum_ll;
         if (!stop && P_out <= wlimit && P_out - rbase > WX_RING) {
-            /* the chunk does not fit the window any more: the next pass starts with it (a chunk that would not fit an empty window
-               is given up below: its entry gets the state behind it, and later chunks, which cannot fit either, follow it there) */
-            if (P_out - P_in <= WX_RING) { if (lane == 0) WX_MIN(&ctl.reset_at, y); stop = 1; }
+            /* the chunk does not fit the window any more: the next pass starts with it — or, when it would not fit an empty window
+               either (64 sequences of more than 128 KiB: matches of tens of KB), wx_slow_chunk does it between two passes */
+            if (lane == 0) { if (P_out - P_in > WX_RING) WX_MIN(&ctl.slow_at, y); WX_MIN(&ctl.reset_at, y); }
+            stop = 1;
         }
         if (stop) {
             if (m_undone) { wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 0, wxp, m_undone); m_undone = 0; }
@@ -554,6 +575,71 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
         out3 = out2; out2 = out1; out1 = P_out;
         have_x = 1; y += nwaves;
     }
+}
+
+/* A chunk whose output is longer than the window (ctl.slow_at), by the whole workgroup, between two passes: the window has gone to
+ * HBM up to the position before the chunk; wave 0 does steps 1 and 2 (the state before the chunk is in the entry of chunk cs - 1,
+ * complete since the barrier behind the pass) and leaves the 64 sequences in `tab` (the empty window's first bytes); then the
+ * sequences go one after the other, literals and match copied by all threads straight in the frame's output (a match that
+ * overlaps itself by doubling: decode_buffer.cairo:95-127 is periodic from its source on); the entry of the chunk gets the state
+ * behind it, and the next pass starts with an empty window there.  Returns 0 when a check of execute_sequences fails (the frame
+ * is given up).  Every thread of the workgroup calls it. */
+__device__ static int wx_slow_chunk(WxCtl& ctl, uint32_t* tab, cz_gptr out, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, cz_gcptr lbase, uint32_t lit_len,
+                                    int lit_rle, uint32_t rle_byte, uint32_t cap, uint32_t cs, uint32_t tid, uint32_t nthreads) {
+    const uint32_t lane = (uint32_t)LANE;
+    const uint32_t cnt = nseq - 64u * cs < 64u ? nseq - 64u * cs : 64u;
+    WX_AT(1);
+    if (tid < 64u) {
+        const uint32_t i = 64u * cs + lane;
+        const WxStep1 s1 = wx_step1(ctl, rec[i < nseq ? i : nseq - 1u], bits, nseq, cs);
+        const uint32_t* const e = ctl.slot[(cs - 1u) & (WX_NS - 1u)];
+        const uint32_t P_in = cz_uni(wx_ld(&e[3])), L_in = cz_uni(wx_ld(&e[4])), h0 = cz_uni(wx_ld(&e[5])), h1 = cz_uni(wx_ld(&e[6])), h2 = cz_uni(wx_ld(&e[7]));
+        const uint32_t off = wx_resolve(s1.asym, h0, h1, h2), opos = P_in + s1.orel, lpos = L_in + s1.lrel;
+        const int bad = s1.bad | (s1.active && (off - 1u >= opos + s1.ll));   /* sequence_execution.cairo:47, decode_buffer.cairo:65 */
+        const uint64_t P_out = (uint64_t)P_in + s1.sum_tot, L_out = (uint64_t)L_in + s1.sum_ll;
+        const int ok = !(__ballot(bad) || P_out > cap || L_out > lit_len);   /* :28-36, and the caller's buffer */
+        tab[lane] = s1.ll; tab[64u + lane] = s1.ml; tab[128u + lane] = off; tab[192u + lane] = opos; tab[256u + lane] = lpos;
+        if (lane == 0) {
+            ctl.slow_ok = (uint32_t)ok; ctl.slow_P = (uint32_t)P_out; ctl.slow_L = (uint32_t)L_out;
+            uint32_t* const mine = ctl.slot[cs & (WX_NS - 1u)];
+            wx_st(&mine[5], wx_resolve(s1.o0, h0, h1, h2)); wx_st(&mine[6], wx_resolve(s1.o1, h0, h1, h2)); wx_st(&mine[7], wx_resolve(s1.o2, h0, h1, h2));
+            wx_st(&mine[1], s1.sum_tot); wx_st(&mine[2], s1.sum_ll); wx_st(&mine[4], (uint32_t)L_out); wx_st(&mine[3], (uint32_t)P_out);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) WX_DBG("WX slow chunk %u: ok %u, position behind it %u\n", cs, ctl.slow_ok, ctl.slow_P);
+    if (!cz_uni(ctl.slow_ok)) return 0;
+    for (uint32_t q = 0; q < cnt; q++) {
+        WX_AT(100 + q);
+        const uint32_t ll = cz_uni(tab[q]), ml = cz_uni(tab[64u + q]), off = cz_uni(tab[128u + q]), opos = cz_uni(tab[192u + q]), lpos = cz_uni(tab[256u + q]);
+        for (uint32_t i = 16u * tid; i < ll; i += 16u * nthreads) {    /* literals: literal buffer -> output */
+            const uint32_t m = ll - i < 16u ? ll - i : 16u;
+            uint4 v;
+            if (lit_rle) { const uint32_t w = 0x01010101u * rle_byte; v = uint4{w, w, w, w}; }
+            else v = cz_load_upto16(lbase + lpos + i, m, lpos + i + 16u <= lit_len);
+            (cz_store_upto16)(out + opos + i, v, m);
+        }
+        if (!ml) continue;
+        __syncthreads();                                                /* (the source may be this sequence's literals) */
+        const uint32_t d = opos + ll;
+        uint32_t copied = 0, dist = off;
+        while (copied < ml) {
+            WX_AT(200 + q);
+            while (dist < 16u * nthreads && 2u * dist <= off + copied) dist += dist;
+            const uint32_t step = ml - copied < dist ? ml - copied : dist;
+            for (uint32_t i = 16u * tid; i < step; i += 16u * nthreads) {   /* sources [.., + step) lie below the destinations: a 16-byte load stays inside them */
+                const uint32_t m = step - i < 16u ? step - i : 16u;
+                const uint4 v = cz_load_upto16((cz_gcptr)out + (d + copied - dist + i), m, m == 16u);
+                (cz_store_upto16)(out + d + copied + i, v, m);
+            }
+            __syncthreads();                                            /* the waves of a workgroup share their CU's L1: the barrier orders these stores before the next loads */
+            copied += step;
+        }
+    }
+    __syncthreads();
+    WX_AT(3);
+    if (tid == 0) wx_st(&ctl.slot[cs & (WX_NS - 1u)][0], ((cs + 1u) << 3) | WX_F_AGG | WX_F_HOK | WX_F_INCL);
+    return 1;
 }
 
 /* One workgroup per frame; frames from the list cz_scan_kernel made (a.wx_list, scan_ctl[206] entries). */
@@ -687,13 +773,15 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                     for (;;) {
                         /* one pass = as many chunks as fit the window; nothing of the pass is final yet */
                         for (uint32_t i = tid; i < WX_RING / 32u + 4u; i += nthreads) ctl.fin[i] = 0;
-                        if (tid == 0) ctl.reset_at = WX_INF;
+                        if (tid == 0) { ctl.reset_at = WX_INF; ctl.slow_at = WX_INF; }
                         __syncthreads();
                         wx_block_sequences(ctl, ring, (cz_gcptr)out, recp, nseq, bitp, lbase, lit_len, lit_rle, rle_byte, cap, wave, nwaves, wbase, c0, wxp);
                         __syncthreads();
                         WX_PROF_T0();
+                        WX_AT(4);
                         const uint32_t cs = cz_uni(ctl.reset_at);
-                        if (cz_uni(wx_ld(&ctl.err)) || (cs != WX_INF && (cs <= c0 || cs >= nch))) { give_up = 1; break; }
+                        const int slow = cs != WX_INF && cz_uni(ctl.slow_at) == cs;
+                        if (cz_uni(wx_ld(&ctl.err)) || (cs != WX_INF && ((cs <= c0 && !slow) || cs >= nch))) { give_up = 1; break; }
                         if (cs == WX_INF) break;
                         /* the window is full: its bytes go to HBM, and it starts again at the position before chunk cs (whose entries are
                            cleared of what the pass published of them: a chunk's sums say its wave has got there) */
@@ -701,7 +789,14 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                         wx_wg_flush(ring - wbase, wbase, out + wbase, pmid - wbase, tid, nthreads);
                         if (tid < WX_NS && (ctl.slot[tid][0] >> 3) > cs) ctl.slot[tid][0] = 0;
                         wbase = pmid; c0 = cs;
+                        WX_AT(5);
                         __syncthreads();
+                        if (slow) {                                     /* chunk cs is longer than the window: straight in the frame's output */
+                            if (!wx_slow_chunk(ctl, (uint32_t*)ring, out, recp, nseq, bitp, lbase, lit_len, lit_rle, rle_byte, cap, cs, tid, nthreads)) { give_up = 1; break; }
+                            __syncthreads();
+                            wbase = cz_uni(ctl.slow_P); c0 = cs + 1u;
+                            if (c0 >= nch) break;
+                        }
                     }
                     if (give_up) { ok = 0; break; }
                     const uint32_t* se = ctl.slot[(nch - 1u) & (WX_NS - 1u)];   /* the last chunk's entry */
