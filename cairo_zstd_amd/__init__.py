@@ -125,7 +125,7 @@ class Context:
         batches whose far offsets outweigh the near ones (decided on the device; default on).  cus / leave_per_cu / force: the A/B
         knobs of cz_context_set_wexec_tuning (force: side by side whatever the offsets look like)."""
         lib().cz_context_set_wexec_kernel(self._h, 1 if on else 0)
-        st = lib().cz_context_set_wexec_tuning(self._h, int(cus), int(leave_per_cu), 1 if force else 0)
+        st = lib().cz_context_set_wexec_tuning(self._h, int(cus), int(leave_per_cu), int(force))
         if st:
             raise CzError(st, "cz_context_set_wexec_tuning")
 

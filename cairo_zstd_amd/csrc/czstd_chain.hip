@@ -783,7 +783,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                 a.results[f] = r;
             }
             wx = good && !(pre & CZ_PRE_DONE) && first_hdr != 0 && units >= CZ_WX_MIN_UNITS && ocap < 0x80000000ull && !(a.verify_checksum && w.has_checksum) && a.wx_list != nullptr;
-            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre | (wx ? CZ_PRE_WXLIST : 0u);
+            int big = wx && units >= CZ_WX_BIG_UNITS;
+            if (big) big = atomicAdd(&a.scan_ctl[210], 1u) < CZ_WX_BIG_MAX;
+            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre | (wx ? CZ_PRE_WXLIST : 0u) | (big ? CZ_PRE_WXBIG : 0u);
         }
     }
     if (a.wx_list) {                                                    /* frames for cz_wexec_kernel: everything pre-passed, output fits its LDS window, enough sequences for a workgroup */

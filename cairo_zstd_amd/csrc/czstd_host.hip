@@ -361,7 +361,7 @@ CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) retur
    leaves to it at the end of a batch (0: default), force = 1: side by side whatever the batch's offsets look like. */
 CZ_EXPORT int cz_context_set_wexec_tuning(cz_context* c, int cus, int leave_per_cu, int force) {
     if (!c || cus < 0 || leave_per_cu < 0) return CZ_E_INVALID_ARG;
-    c->wexec_cus = cus; if (leave_per_cu) c->wexec_leave_per_cu = leave_per_cu; c->wexec_force = force ? 1u : 0u;
+    c->wexec_cus = cus; if (leave_per_cu) c->wexec_leave_per_cu = leave_per_cu; c->wexec_force = force == 2 ? 2u : (force ? 1u : 0u);   /* 1: side by side whatever the offsets; 2: never the large frames of a near-offset batch alone (A/B) */
     return CZ_OK;
 }
 /* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' code tables, in sequences

@@ -69,6 +69,13 @@ __device__ static inline uint32_t cz_exec_variant(const cz_batch_args& a) {
     const unsigned long long nearq = a.chain_top[5], farq = a.chain_top[6], longq = a.chain_top[7];
     return nearq > farq && longq * 256ull < nearq + farq ? 8u : 4u;
 }
+/* ... and on a near-offset batch that the 4-waves build runs: do the batch's LARGE frames (CZ_PRE_WXBIG, a few hundred at most) go to
+   cz_wexec_kernel, all the others to cz_execute_frames_kernel?  Such a batch ends when its largest frames do, and a large frame
+   shares its SIMD, the L2 and the memory system with 4 095 other waves there — 1.7 x its time alone; on cz_wexec_kernel it has a
+   CU and its window to itself (corpus-like mix: execute stage 7.9 -> 5.6 ms, profiles/r4/NOTES.md) */
+__device__ static inline int cz_wx_big_only(const cz_batch_args& a) {
+    return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && a.scan_ctl[210] != 0u && cz_exec_variant(a) == 4u;
+}
 #endif
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
  * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
@@ -2497,7 +2504,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
     if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
     if (::cz_exec_variant(a) != CZ_EXEC_WAVES) return;                  /* the build with the other register budget runs this batch */
     const uint32_t total = a.n;
-    const int wx_on = ::cz_wx_side_by_side(a);
+    const int wx_on = ::cz_wx_side_by_side(a), wx_big = ::cz_wx_big_only(a);
     cz_init_llml();
     for (;;) {
         __syncthreads();
@@ -2512,6 +2519,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
         const uint64_t first = cz_uni64(a.frame_first[f]), lfirst = cz_uni64(a.lit_first[f]);
         const uint32_t pre = cz_uni(a.frame_pre[f]);
         if (((pre & CZ_PRE_DONE) && lfirst != 0) || pre == CZ_PRE_PUSHED || (pre & (CZ_PRE_WXDONE | CZ_PRE_CLAIMED))) continue;
+        if (wx_big && (pre & CZ_PRE_WXBIG)) continue;                   /* cz_wexec_kernel's */
         if (wx_on && (pre & CZ_PRE_WXLIST)) {
             /* cz_wexec_kernel, which runs beside this kernel, may take this frame: whoever claims it first does it.  The last
                wx_leave listed frames are left to that kernel: a frame started here now would still be running on its one wave

@@ -72,10 +72,15 @@ typedef struct cz_blk_desc {
                                   [204] frames that are not CZ_PRE_DONE (cz_execute_frames_kernel has nothing to do when there are none),
                                   [205] waves of cz_chain_kernel that have finished (cz_huf1_kernel stops when all have),
                                   [206] frames listed for cz_wexec_kernel (wx_list), [207] of those, frames it did not finish,
-                                  [208] listed frames claimed so far (by either execute kernel), [209] frames cz_wexec_kernel finished */
+                                  [208] listed frames claimed so far (by either execute kernel), [209] frames cz_wexec_kernel finished,
+                                  [210] listed frames of CZ_WX_BIG_UNITS and more (the first CZ_WX_BIG_MAX of them carry CZ_PRE_WXBIG) */
 /* cz_wexec_kernel (czstd_wexec.hip): a workgroup per frame, the frame's window in LDS */
 #define CZ_WX_RING_LOG 17u
 #define CZ_WX_RING (1u << CZ_WX_RING_LOG)   /* frames of at most this many decoded bytes (out_cap) */
+#ifndef CZ_WX_BIG_UNITS
+#define CZ_WX_BIG_UNITS 36000u            /* ... and from this many on a frame is one of the batch's LARGE frames: on near-offset batches those alone go to cz_wexec_kernel */
+#endif
+#define CZ_WX_BIG_MAX 256u                /* at most this many of them (scan_ctl[210] counts the candidates) */
 #ifndef CZ_WX_MIN_UNITS
 #define CZ_WX_MIN_UNITS 512u                /* chain-arena units (~ sequences) a frame must have to be worth a workgroup */
 #endif
@@ -103,7 +108,8 @@ typedef struct cz_copy_seg {
 #define CZ_PRE_WXDONE  0x10000000u   /* cz_wexec_kernel finished the frame (result record written): cz_execute_frames_kernel skips it */
 #define CZ_PRE_WXLIST  0x08000000u   /* cz_scan_kernel listed the frame for cz_wexec_kernel */
 #define CZ_PRE_CLAIMED 0x04000000u   /* cz_wexec_kernel and cz_execute_frames_kernel run side by side and share the frames: whichever sets this bit first does the frame */
-#define CZ_PRE_COUNT   0x03FFFFFFu
+#define CZ_PRE_WXBIG   0x02000000u   /* one of the batch's large frames (CZ_WX_BIG_UNITS): on a near-offset batch cz_wexec_kernel does these, and only these */
+#define CZ_PRE_COUNT   0x01FFFFFFu
 
 /* chain_top (8 x u64, zeroed per launch): [0] arena units taken; bytes 16.. the work counters of the kernels; [5] / [6] sequences (units of 64, x 256) with
    near / far offset codes, [7] with a literal run above 8 or a match above 16 bytes, summed by cz_chain_kernel (see cz_wx_side_by_side, cz_exec_variant) */

@@ -648,7 +648,8 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
     WxCtl& ctl = *(WxCtl*)(ring + WX_RING);
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = cz_uni(tid >> 6);
     const uint32_t nlist = cz_uni(a.scan_ctl[206]);
-    if (nlist == 0 || !cz_wx_side_by_side(a)) return;
+    const int big_only = cz_wx_big_only(a);                             /* near-offset batch: only its large frames (CZ_PRE_WXBIG), and all of those */
+    if (nlist == 0 || !(cz_wx_side_by_side(a) || big_only)) return;
     unsigned long long wxp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CZ_PROFILE
     unsigned long long wxt_ = 0;
@@ -663,8 +664,12 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
         __syncthreads();
         WX_PROF_T0();
         if (tid == 0) {
-            const uint32_t i = atomicAdd(a.wx_counter, 1u);
-            uint32_t f = i < nlist ? a.wx_list[i] : 0xFFFFFFFFu;
+            uint32_t f;
+            for (;;) {
+                const uint32_t i = atomicAdd(a.wx_counter, 1u);
+                f = i < nlist ? a.wx_list[i] : 0xFFFFFFFFu;
+                if (f == 0xFFFFFFFFu || !big_only || (a.frame_pre[f] & CZ_PRE_WXBIG)) break;
+            }
             ctl.fidx = f; ctl.go = 2; ctl.err = 0;
             if (f != 0xFFFFFFFFu) {
                 /* still as the scan left it?  (cz_chain_kernel / the huff0 kernels may have taken the frame back) */

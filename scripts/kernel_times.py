@@ -31,7 +31,7 @@ def child(kind, n):
             ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
         cz.lib().cz_context_set_exec_kernel(ctx._h, int(os.environ.get("CZ_EXEC", "1")))   # 0 off, 1 on, 4 / 8: that register budget whatever the batch looks like
         wxe = os.environ.get("CZ_WEXEC", "1").split(",")               # on[,cus[,leave_per_cu[,force]]]
-        ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=len(wxe) > 3 and wxe[3] == "1")
+        ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=int(wxe[3]) if len(wxe) > 3 else 0)
     tot, ch, ex, lt, wx = [], [], [], [], []
     for it in range(5):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())

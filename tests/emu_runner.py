@@ -19,7 +19,7 @@ def build(target="emu_decode"):
     return os.path.join(EMU_DIR, target)
 
 
-def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None, wexec_waves=0, verify=True):
+def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None, wexec_waves=0, verify=True, wexec_auto=False):
     exe = build(target)
     with tempfile.TemporaryDirectory() as td:
         inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
@@ -33,6 +33,8 @@ def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kern
             env["EMU_DICT"] = dict_path
         if wexec_waves:
             env["EMU_WEXEC"] = str(int(wexec_waves))
+            if wexec_auto:
+                env["EMU_WX_AUTO"] = "1"
         env["EMU_VERIFY"] = "1" if verify else "0"
         p = subprocess.run([exe, inp, outp], capture_output=True, timeout=timeout, env=env)
         run.last_stderr = p.stderr.decode()[-2000:]

@@ -13,8 +13,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0, wexec_waves=0, verify=True):
-    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes, wexec_waves=wexec_waves, verify=verify)
+def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0, wexec_waves=0, verify=True, wexec_auto=False):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes, wexec_waves=wexec_waves, verify=verify, wexec_auto=wexec_auto)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -170,6 +170,25 @@ def test_emu_wexec_kernel():
     err = emu_runner.run.last_stderr
     listed, done = int(err.split("EMU_WEXEC: ")[1].split()[0]), int(err.split("frames listed, ")[1].split()[0])
     assert listed > 20 and 10 < done <= listed, (listed, done)
+
+
+def test_emu_wexec_kernel_large_frames_of_a_near_offset_batch_and_chunks_longer_than_the_window():
+    """The execute stage as it is arranged on a near-offset batch (decided from the code tables, as on the device): the batch's large
+    frames (the emulator build puts the mark at 600 sequences) on cz_wexec_kernel, all others on cz_execute_frames_kernel.  Three of
+    the large frames have a chunk of 64 sequences that regenerates more than the 128 KiB window (wx_slow_chunk)."""
+    frames, caps = [], []
+    for first in (8265, 9021, 1750):
+        b = synth.generate("mix", 1, first_index=first, nthreads=1)
+        frames.append(b.frame(0))
+        caps.append(int(b.regen[0]) + 8)
+    b = synth.generate("mix", 30, first_index=0, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:6]
+    frames += [b.frame(i) for i in keep]
+    caps += [int(b.regen[i]) + 8 for i in keep]
+    _run_and_compare(frames, caps, chain_bytes=16 << 20, lit_bytes=8 << 20, exec_kernel=True, wexec_waves=16, verify=False, wexec_auto=True)
+    err = emu_runner.run.last_stderr
+    done_wx, not_handed_on = int(err.split("frames listed, ")[1].split()[0]), int(err.split("EMU_EXEC: ")[1].split()[0])
+    assert done_wx == 3 and not_handed_on == len(frames), (done_wx, not_handed_on, len(frames))   # the large ones there, nothing left to cz_decode_frames_kernel
 
 
 def test_emu_d2_weight_log_10_unsupported():

@@ -587,7 +587,8 @@ def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
     Forced on (auto = False) every listed frame may go to either kernel — config 4a, config 4b (a block of 224 KiB: the window is
     filled more than once), corpus-like multi-block frames (blocks above the format's 128 KiB, matches into earlier blocks, long
     matches, `offset_value 3 with no literals`), the whole reference corpus (windows up to 3.5 MiB) and damaged frames, which it
-    must hand on.  auto = True: the device decides from the batch's offset codes, and takes the far-offset batch only."""
+    must hand on.  auto = True: the device decides from the batch's offset codes: the far-offset batch side by side, of the near-offset
+    batch only the large frames."""
     from cairo_zstd_amd import synth
     c = cz.Context(0)
     c.set_chain_arena(512 << 20, min_sequences=0)
@@ -621,7 +622,9 @@ def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
                 caps.append(len(orig) * 2 + 4096)
         listed, finished, handed = run(frames, caps)
         if auto:
-            assert finished == 0, (listed, finished, handed)            # near offsets: cz_execute_frames_kernel alone
+            # near offsets: the large frames (36 000 sequences and more: the config 4b frames, a few of the mix) on cz_wexec_kernel,
+            # all others on cz_execute_frames_kernel
+            assert 12 <= finished < 64 and handed == 0, (listed, finished, handed)
         else:
             assert listed > 100 and finished > 50 and handed > 0, (listed, finished, handed)
     finally:
