@@ -72,9 +72,11 @@ __device__ static inline uint32_t cz_exec_variant(const cz_batch_args& a) {
 /* ... and on a near-offset batch that the 4-waves build runs: do the batch's LARGE frames (CZ_PRE_WXBIG, a few hundred at most) go to
    cz_wexec_kernel, all the others to cz_execute_frames_kernel?  Such a batch ends when its largest frames do, and a large frame
    shares its SIMD, the L2 and the memory system with 4 095 other waves there — 1.7 x its time alone; on cz_wexec_kernel it has a
-   CU and its window to itself (corpus-like mix: execute stage 7.9 -> 5.6 ms, profiles/r4/NOTES.md) */
+   CU and its window to itself (corpus-like mix: execute stage 7.9 -> 5.6 ms, profiles/r4/NOTES.md).  Only where the chip IS that
+   full and the large frames are few: 2 048 frames or more, at most one in sixteen of them large. */
 __device__ static inline int cz_wx_big_only(const cz_batch_args& a) {
-    return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && a.scan_ctl[210] != 0u && cz_exec_variant(a) == 4u;
+    const uint32_t nbig = a.scan_ctl[210];
+    return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && nbig != 0u && a.n >= CZ_WX_BIG_MIN_FRAMES && (uint64_t)nbig * CZ_WX_BIG_SHARE <= a.n && cz_exec_variant(a) == 4u;
 }
 #endif
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates

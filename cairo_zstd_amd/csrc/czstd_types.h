@@ -80,6 +80,10 @@ typedef struct cz_blk_desc {
 #ifndef CZ_WX_BIG_UNITS
 #define CZ_WX_BIG_UNITS 36000u            /* ... and from this many on a frame is one of the batch's LARGE frames: on near-offset batches those alone go to cz_wexec_kernel */
 #endif
+#ifndef CZ_WX_BIG_MIN_FRAMES
+#define CZ_WX_BIG_MIN_FRAMES 2048u        /* ... in a batch of at least this many frames, of which at most one in CZ_WX_BIG_SHARE is large (cz_wx_big_only) */
+#define CZ_WX_BIG_SHARE 16u
+#endif
 #define CZ_WX_BIG_MAX 256u                /* at most this many of them (scan_ctl[210] counts the candidates) */
 #ifndef CZ_WX_MIN_UNITS
 #define CZ_WX_MIN_UNITS 512u                /* chain-arena units (~ sequences) a frame must have to be worth a workgroup */
