@@ -198,7 +198,9 @@ int cz_context_set_exec_kernel(cz_context* ctx, int on);   /* (on = 4 / 8: that 
  * reference's status.  on = 1, the default; on = 0: cz_execute_frames_kernel alone (A/B runs: bench.py --no-wexec-kernel). */
 int cz_context_set_wexec_kernel(cz_context* ctx, int on);
 /* A/B knobs: CUs cz_wexec_kernel runs on (0: half of them), frames per such CU that cz_execute_frames_kernel leaves to it at the end
- * of a batch (0: the default, 7), force = 1: side by side whatever the batch's offsets look like (tests use it). */
+ * of a batch (0: the default, 7), force = 1: side by side whatever the batch's offsets look like (tests use it); force = 2: never
+ * cz_wexec_kernel on a near-offset batch (by default it takes such a batch's few large frames — 36 000 sequences and more — when
+ * the batch has 2 048 frames or more: each has a CU to itself there instead of a wave among 4 096). */
 int cz_context_set_wexec_tuning(cz_context* ctx, int cus, int leave_per_cu, int force);
 /* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' LL / OF / ML code
  * tables, in sequences x 4 — with near offset codes (2..13: offsets below 16 KiB), with far ones, with a literal run above 8 or a
