@@ -25,14 +25,18 @@
  * history there / state BEHIND the chunk there).
  * Per block: barrier, tail literals (sequence_execution.cairo:72-78), the block's bytes window -> HBM.  The window positions are
  * block-relative; a block whose output exceeds the window is done in passes (the first sequence that does not fit sets
- * ctl.reset_at; flush; the next pass starts there), and sources in earlier blocks are read from the frame's output in HBM.
+ * ctl.reset_at; flush; the next pass starts there; a chunk that alone exceeds the window goes through wx_slow_chunk between two
+ * passes), and sources in earlier blocks are read from the frame's output in HBM.
  *
  * The kernel is a pure accelerator, like cz_chain_kernel: it takes frames off the list cz_scan_kernel made for it (regular to the
  * last block, everything pre-passed, enough sequences to be worth a workgroup), claims each with an atomic OR on frame_pre[f]
  * (CZ_PRE_CLAIMED) and marks those it finished (CZ_PRE_WXDONE, result record written).  cz_execute_frames_kernel runs SIDE BY SIDE
  * with it on the other CUs, claims frames the same way and leaves the last few listed frames per workgroup to this kernel.  The
  * whole kernel returns at once unless the batch's offset codes are mostly far ones (cz_wx_side_by_side: the sums cz_chain_kernel
- * left in chain_top): near-offset frames are bound by their chain of dependent matches and gain nothing here (profiles/r4/NOTES.md).
+ * left in chain_top): near-offset frames are bound by their chain of dependent matches and gain nothing here (profiles/r4/NOTES.md)
+ * — except the few LARGE frames of a batch that fills the chip (cz_wx_big_only: CZ_PRE_WXBIG, marked by the scan): the batch ends
+ * when they do, and here each has a CU and its window to itself instead of a wave among 4 096; then this kernel does exactly the
+ * marked frames and cz_execute_frames_kernel leaves them alone.
  * On ANY irregularity — a check of execute_sequences that fails, a frame the pre-pass kernels took back — the frame goes on
  * fallback_list as it was, and cz_decode_frames_kernel does it in the reference's order of detection.  Nothing here reports errors.
  */
