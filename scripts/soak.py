@@ -19,11 +19,16 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda:0")
 bad_total = 0
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
-for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw_rle", 3000), ("full_4b", 1500)):
+for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw_rle", 3000), ("full_4b", 1500), ("real", 8000)):
     if only and kind not in only:
         continue
-    b = synth.generate(kind, n, first_index=777, nthreads=16)
-    out_off, out_cap, total = b.out_layout(256)
+    if kind == "real":                                                  # frames made by the box's libzstd (the bench line's real_libzstd_l3)
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from _batches import make_batch
+        b, out_off, out_cap, total = make_batch("real", n)
+    else:
+        b = synth.generate(kind, n, first_index=777, nthreads=16)
+        out_off, out_cap, total = b.out_layout(256)
     t = [torch.from_numpy(x).to(dev) for x in (b.base, b.off.astype(np.int64), b.length.astype(np.int64), out_off.astype(np.int64), out_cap.astype(np.int64))]
     ctx = cz.Context(0, torch.cuda.current_stream().cuda_stream)
     ctx.set_chain_arena(int(b.length.sum()) * 8 + (64 << 20))
