@@ -385,11 +385,14 @@ def main():
             ctx.set_literal_arena(lb_ + (8 << 20) if pre and not args.no_literals_pass else 0)
             to = torch.empty(o_total, dtype=torch.uint8, device=dev)
             tr = torch.zeros(nf * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            ms = []
+            ms, cms_, ems_, wms_ = [], [], [], []
             for it in range(3):
                 ctx.decode_batch_device(ti.data_ptr(), td[0].data_ptr(), td[1].data_ptr(), nf, to.data_ptr(), td[2].data_ptr(),
                                         td[3].data_ptr(), tr.data_ptr())
                 ms.append(ctx.last_kernel_ms())
+                if pre:
+                    cms_.append(ctx.last_chain_ms()); ems_.append(ctx.last_exec_ms()); wms_.append(ctx.last_wexec_ms())
+            wxc = ctx.last_wexec_counts() if pre else (0, 0, 0)
             # one more launch into a poisoned buffer, every frame compared with the oracle by XXH64 (as for the headline workload)
             to.fill_(0xA5)
             tr.zero_()
@@ -416,6 +419,11 @@ def main():
             others[wl] = {"frames": nf, "decompressed_MBps": float(ob.regen.sum()) / (k * 1e-3) / 1e6, "kernel_ms": k,
                           "algorithmic_GBps": ab / (k * 1e-3) / 1e9, "roofline_frac": ab / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "all_frames_ok": okw, "bit_exact": exact, "frames_verified_vs_oracle": nver}
+            if pre and cms_:
+                # how the device arranged the execute stage of this batch: frames cz_wexec_kernel finished (side by side on far-offset
+                # batches; the few large frames of a near-offset batch), the rest on cz_execute_frames_kernel / its 8-waves build
+                others[wl].update({"chain_kernel_ms": float(np.mean(cms_[1:])), "exec_stage_ms": float(np.mean(ems_[1:])), "wexec_kernel_ms": float(np.mean(wms_[1:])),
+                                   "frames_finished_by_wexec_kernel": int(wxc[1]), "frames_handed_on_by_wexec_kernel": int(wxc[2])})
             del ti, td, to, tr
         # real encoder output (not a BASELINE config: what a user of the library decodes): frames made here by the box's libzstd,
         # every decoded frame compared with its original, the distinct frames also with the oracle
