@@ -114,7 +114,7 @@ def _libzstd():
 def _real_frames(n: int, level: int = 3, distinct: int = 384):
     """n frames of 128 KiB as a real encoder leaves them: text-like, log-like and mixed binary / text data compressed by the box's
     libzstd at `level`.  `distinct` different inputs are made (Python builds them: the bound), the batch repeats them.
-    Returns (frames, originals) or None without a libzstd."""
+    Returns (frames, originals, number of distinct frames), or None without a libzstd (or when it fails to compress)."""
     import ctypes
     try:
         Z = ctypes.CDLL("libzstd.so.1")
@@ -122,6 +122,8 @@ def _real_frames(n: int, level: int = 3, distinct: int = 384):
         return None
     Z.ZSTD_compress.restype = ctypes.c_size_t
     Z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    Z.ZSTD_isError.restype = ctypes.c_uint
+    Z.ZSTD_isError.argtypes = [ctypes.c_size_t]
     rng = np.random.default_rng(7)
     SZ = 131072
     words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(3000)]
@@ -148,6 +150,8 @@ def _real_frames(n: int, level: int = 3, distinct: int = 384):
             d = bytes(rec[:SZ])
         d = d.ljust(SZ, b".")
         m = Z.ZSTD_compress(dst, 2 * SZ, d, len(d), level)
+        if Z.ZSTD_isError(m):                                           # (an error code is a huge size_t: never slice with it)
+            return None
         frames.append(dst.raw[:m])
         origs.append(d)
     k = len(frames)

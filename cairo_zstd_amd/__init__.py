@@ -18,7 +18,7 @@ from . import status
 from ._lib import (RESULT_CHECKSUM_COMPUTED, RESULT_CHECKSUM_MATCH, RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM,
                    BlockHeader, FrameHeader, build, lib)
 
-DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1 = 1, 2     # cz_context_set_debug_flags
+DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1, DEBUG_WX_POISON = 1, 2, 4     # cz_context_set_debug_flags
 from .status import CzError
 
 __all__ = ["Context", "FrameDecoder", "BlockDecodingStrategy", "decode_batch_host", "read_frame_header",
@@ -138,7 +138,7 @@ class Context:
         return int(a.value), int(b.value)
 
     def set_debug_flags(self, flags: int):
-        """Test knobs (cz_context_set_debug_flags): DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1."""
+        """Test knobs (cz_context_set_debug_flags): DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1, DEBUG_WX_POISON."""
         lib().cz_context_set_debug_flags(self._h, int(flags))
 
     def debug_read_chain_arena(self, nbytes: int):
@@ -156,6 +156,12 @@ class Context:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         lib().cz_context_last_sequence_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
         return int(a.value), int(b.value), int(c.value)
+
+    def last_fallback_count(self) -> int:
+        """Frames the pre-pass and execute kernels of the last launch handed to cz_decode_frames_kernel (each listed once)."""
+        a = C.c_size_t()
+        lib().cz_context_last_fallback_count(self._h, C.byref(a))
+        return int(a.value)
 
     def last_wexec_counts(self):
         """(frames listed for cz_wexec_kernel, frames it finished, frames it handed on) in the last launch."""

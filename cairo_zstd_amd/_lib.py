@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.cz_context_debug_read_chain_arena.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.cz_context_last_sequence_stats.restype = C.c_int
     L.cz_context_last_sequence_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.cz_context_last_fallback_count.restype = C.c_int
+    L.cz_context_last_fallback_count.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.cz_context_last_wexec_counts.restype = C.c_int
     L.cz_context_last_wexec_counts.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.cz_context_last_wexec_ms.restype = C.c_int

@@ -766,7 +766,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
     }
     int wx = 0;
     if (valid) {
-        const int good = placed && w.ok;
+        const int good = placed && w.ok && pre_blocks <= CZ_PRE_COUNT;   /* (the count shares frame_pre[f] with the marks) */
         a.frame_first[f] = good ? first_hdr : 0;
         if (with_lits) {
             uint32_t pre = good ? (CZ_PRE_REGULAR | pre_blocks) : 0;

@@ -396,6 +396,19 @@ CZ_EXPORT int cz_context_last_wexec_counts(cz_context* c, size_t* listed, size_t
     if (finished) *finished = h[3];
     return CZ_OK;
 }
+/* Diagnostics of the most recent batch launch (synchronises): entries on the fall-back list, i.e. frames the pre-pass and execute
+   kernels handed to cz_decode_frames_kernel (0 without the execute stage, where that kernel takes all n frames anyway). */
+CZ_EXPORT int cz_context_last_fallback_count(cz_context* c, size_t* listed) {
+    if (!c || !listed) return CZ_E_INVALID_ARG;
+    *listed = 0;
+    if (!c->chain_top || !c->fallback_list) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t h = 0;
+    CZ_HIP(c, hipMemcpy(&h, (uint8_t*)c->chain_top + 28, 4, hipMemcpyDeviceToHost));
+    *listed = h;
+    return CZ_OK;
+}
 /* Part of the last launch spent in cz_wexec_kernel (0 when it did not run). */
 CZ_EXPORT int cz_context_last_wexec_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
@@ -475,24 +488,24 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
             a.lit_segs = c->lit_segs; a.lit_seg_capacity = c->seg_capacity; a.copy_segs = c->copy_segs; a.copy_seg_capacity = c->seg_capacity; a.frame_pre = c->frame_pre;
         }
-        /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
-        if (c->exec_kernel && lit_pass && !c->batch_dict && c->wexec_kernel) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
-        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
-        CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
-        const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
-        a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
-        a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
-        CZ_HIP(c, hipGetLastError());
+        /* which kernels the execute stage has is settled BEFORE the scan, so that every kernel of the batch sees the same wx_list */
         const bool use_exec = c->exec_kernel && lit_pass && !c->batch_dict;
         bool use_wx = use_exec && c->wexec_kernel;
         if (use_wx && !c->wexec_ready) {
             /* (a workgroup of cz_wexec_kernel asks for more LDS than the default limit: where the runtime will not grant it,
                cz_execute_frames_kernel does the whole batch, as with cz_context_set_wexec_kernel(ctx, 0)) */
             if (hipFuncSetAttribute((const void*)cz_wexec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS_BYTES) != hipSuccess ||
-                hipEventCreate(&c->ev_wx) != hipSuccess) { (void)hipGetLastError(); c->wexec_kernel = false; use_wx = false; a.wx_list = nullptr; a.wx_counter = nullptr; }
+                hipEventCreate(&c->ev_wx) != hipSuccess) { (void)hipGetLastError(); c->wexec_kernel = false; use_wx = false; }
             else c->wexec_ready = true;
         }
         if (use_wx) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
+        /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
+        a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
+        CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
+        const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
+        a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        CZ_HIP(c, hipGetLastError());
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         /* the literal and copy kernels may start when the chain kernel does (not before: they would take the LDS the chain
            kernel's workgroups need and hold them up) */
@@ -607,6 +620,7 @@ CZ_EXPORT int cz_context_measure_batch(cz_context* c, const void* d_in_base, con
     if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
     CZ_HIP(c, hipSetDevice(c->device));
     const size_t waves = (n + CZ_WG_THREADS - 1) / CZ_WG_THREADS;
+    std::vector<uint64_t> h(2 * n);                                     /* (before the device buffer: a bad_alloc here leaves nothing to free) */
     uint8_t* tmp = nullptr;                                             /* frame_first | lit_first | frame_pre | scan_ctl | scan_wave */
     const size_t o_ff = 0, o_lf = o_ff + n * 8, o_fp = o_lf + n * 8, o_ctl = (o_fp + n * 4 + 15) & ~(size_t)15, o_sw = o_ctl + CZ_SCAN_CTL_WORDS * 4, total = o_sw + waves * 72 * 4;
     CZ_HIP(c, hipMalloc((void**)&tmp, total));
@@ -621,7 +635,6 @@ CZ_EXPORT int cz_context_measure_batch(cz_context* c, const void* d_in_base, con
         a.chain_min_nseq = c->chain_min_nseq; a.scan_pass = 0;
         hipLaunchKernelGGL(cz_scan_kernel, dim3((unsigned)waves), dim3(CZ_WG_THREADS), 0, c->stream, a);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { st = CZ_E_HIP; break; }
-        std::vector<uint64_t> h(2 * n);
         if (hipMemcpy(h.data(), tmp, 2 * n * 8, hipMemcpyDeviceToHost) != hipSuccess) { st = CZ_E_HIP; break; }
         unsigned long long units = 0, lbytes = 0;
         for (size_t i = 0; i < n; i++) { units += h[i]; lbytes += h[n + i]; }
@@ -698,6 +711,8 @@ CZ_EXPORT int cz_partition_balanced(const uint64_t* weights, size_t n, size_t pa
     return CZ_OK;
 } catch (const std::bad_alloc&) { return CZ_E_OUT_OF_MEMORY; }
 
+/* (the staging buffer is only ever touched by cz_decode_batch_multi's worker of this context, which waits for the stream — in
+   cz_decode_batch_host — before it returns: no copy is in flight when the buffer is grown here) */
 static int cz_pin_reserve(cz_context* c, size_t bytes) {
     if (c->h_pin_bytes >= bytes) return CZ_OK;
     if (c->h_pin) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_bytes = 0; }
@@ -726,6 +741,10 @@ CZ_EXPORT int cz_decode_batch_multi(cz_context* const* ctxs, size_t n_ctx, const
     if (device_of) memcpy(device_of, part.data(), n * sizeof(uint32_t));
     std::vector<int> status(n_ctx, CZ_OK);
     std::vector<std::thread> workers;
+    workers.reserve(n_ctx);
+    /* (a thread that cannot be started must not unwind past the ones already running: joinable std::thread objects would end the
+       process in their destructors — they are joined first, then the caller gets CZ_E_OUT_OF_MEMORY) */
+    struct Joiner { std::vector<std::thread>& w; ~Joiner() { for (auto& t : w) if (t.joinable()) t.join(); } } joiner{workers};
     for (size_t d = 0; d < n_ctx; d++) {
         workers.emplace_back([&, d]() {
             try {
@@ -794,10 +813,12 @@ CZ_EXPORT int cz_gather_to_root(cz_context* const* ctxs, size_t n_ctx, size_t ro
         CZ_HIP(c, hipMemcpyPeerAsync(d_dst_on_root[d], r->device, d_src[d], c->device, bytes[d], c->stream));
         hipEvent_t ev;
         CZ_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        CZ_HIP(c, hipEventRecord(ev, c->stream));
-        CZ_HIP(r, hipSetDevice(r->device));
-        CZ_HIP(r, hipStreamWaitEvent(r->stream, ev, 0));
-        (void)hipEventDestroy(ev);                                      /* (released when it has completed) */
+        hipError_t e = hipEventRecord(ev, c->stream);
+        cz_context* at = c;
+        if (e == hipSuccess) { at = r; e = hipSetDevice(r->device); }
+        if (e == hipSuccess) e = hipStreamWaitEvent(r->stream, ev, 0);
+        (void)hipEventDestroy(ev);                                      /* (released when it has completed; on every path) */
+        if (e != hipSuccess) { at->last_hip_error = (int)e; return CZ_E_HIP; }
     }
     return CZ_OK;
 }

@@ -78,6 +78,16 @@ __device__ static inline int cz_wx_big_only(const cz_batch_args& a) {
     const uint32_t nbig = a.scan_ctl[210];
     return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && nbig != 0u && a.n >= CZ_WX_BIG_MIN_FRAMES && (uint64_t)nbig * CZ_WX_BIG_SHARE <= a.n && cz_exec_variant(a) == 4u;
 }
+/* Hands frame f to cz_decode_frames_kernel (fallback_list).  Several kernels may hand the same frame back — a huff0 kernel that
+   met something irregular in one of its sections, the execute kernel that then finds the frame without literals, cz_wexec_kernel
+   that still has it on its list — so the entry is made by whoever sets CZ_PRE_LISTED first: a frame is listed ONCE, the list never
+   holds more than n entries, and no frame is decoded twice at the same time.  One lane calls it. */
+__device__ static inline void cz_list_fallback(const cz_batch_args& a, uint32_t f) {
+    if (!a.fallback_list) return;
+    if (a.frame_pre && (atomicOr(&a.frame_pre[f], CZ_PRE_LISTED) & CZ_PRE_LISTED)) return;
+    const uint32_t i = atomicAdd(a.fallback_count, 1u);
+    if (i < a.n) a.fallback_list[i] = f;
+}
 #endif
 /* Diagnostic build only (-DCZ_PROFILE, csrc/Makefile target `prof`): lane 0 accumulates
  * s_memtime deltas per phase into sh.prof[] and adds them to args.prof[] at the end of each
@@ -2520,7 +2530,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
            cz_chain_kernel gave up on (first == 0 with sequences in it) comes back from cz_run_frame */
         const uint64_t first = cz_uni64(a.frame_first[f]), lfirst = cz_uni64(a.lit_first[f]);
         const uint32_t pre = cz_uni(a.frame_pre[f]);
-        if (((pre & CZ_PRE_DONE) && lfirst != 0) || pre == CZ_PRE_PUSHED || (pre & (CZ_PRE_WXDONE | CZ_PRE_CLAIMED))) continue;
+        if (((pre & CZ_PRE_DONE) && lfirst != 0) || (pre & (CZ_PRE_WXDONE | CZ_PRE_CLAIMED | CZ_PRE_LISTED))) continue;   /* done by the pre-pass kernels / the other execute kernel's / handed back already */
         if (wx_big && (pre & CZ_PRE_WXBIG)) continue;                   /* cz_wexec_kernel's */
         if (wx_on && (pre & CZ_PRE_WXLIST)) {
             /* cz_wexec_kernel, which runs beside this kernel, may take this frame: whoever claims it first does it.  The last
@@ -2547,7 +2557,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
             err = cz_run_frame(io, nullptr, nullptr, (CZ_GLOBAL cz_frame_result*)&a.results[f], (cz_gcptr64)a.chain_arena, first, lp);
             if (err != CZX_FALLBACK && LANE == 0 && a.results[f].status == 0 && !(a.results[f].flags & CZ_RESULT_FINISHED)) a.results[f].status = CZ_E_NOT_FINISHED;
         }
-        if (err == CZX_FALLBACK && LANE == 0) a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f;
+        if (err == CZX_FALLBACK && LANE == 0) ::cz_list_fallback(a, f);
 #ifdef CZ_PROFILE
         if (LANE == 0 && a.prof) for (int i = 0; i < CZ_P_COUNT; i++) { atomicAdd(&a.prof[i], sh.prof[i]); sh.prof[i] = 0; }
 #endif
@@ -2568,7 +2578,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_MAIN_WAVES) cz_de
         __syncthreads();
         const uint32_t fi = cz_uni(sh.frame_idx);
         /* behind cz_execute_frames_kernel: only the frames it left (args.fallback_list, in the order it met them) */
-        if (fi >= (a.fallback_list ? cz_uni(*a.fallback_count) : a.n)) break;
+        if (fi >= (a.fallback_list ? (cz_uni(*a.fallback_count) < a.n ? cz_uni(*a.fallback_count) : a.n) : a.n)) break;
         const uint32_t f = a.fallback_list ? cz_uni(a.fallback_list[fi]) : (a.frame_order ? cz_uni(a.frame_order[fi]) : fi);   /* the pre-pass sorted the frames: longest first */
         CzFrameIO io;
         if (a.tasks) {

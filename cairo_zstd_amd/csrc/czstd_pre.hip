@@ -272,6 +272,16 @@ __device__ static int czh_parse_block(cz_gcptr blk, uint32_t bsize) {
     return 0;
 }
 
+/* A section the huff0 kernels will not do: the whole frame goes back to cz_decode_frames_kernel, which does it from scratch (no
+   literals, no leading blocks: lit_first[f] = 0 and the count and the "regular" / "done" marks of frame_pre[f] cleared; the marks of
+   the execute stage — listed for cz_wexec_kernel, claimed, on the fall-back list — stay, so that exactly one kernel owns the frame
+   from here on) and listed here, once however many of its sections fail.  One lane calls it. */
+__device__ static inline void czh_hand_back(const cz_batch_args& a, uint32_t f) {
+    a.lit_first[f] = 0;
+    atomicAnd(&a.frame_pre[f], ~(CZ_PRE_REGULAR | CZ_PRE_DONE | CZ_PRE_COUNT));
+    cz_list_fallback(a, f);
+}
+
 extern "C" __global__ void __launch_bounds__(CZH_THREADS, CZH_WAVES == 2 ? 6 : 8) cz_huf_kernel(cz_batch_args a) {
     const uint32_t wave = threadIdx.x >> 6;
     uint32_t nseg = 0; for (int c = 0; c < 20; c++) nseg += a.scan_ctl[136 + c];
@@ -332,13 +342,7 @@ extern "C" __global__ void __launch_bounds__(CZH_THREADS, CZH_WAVES == 2 ? 6 : 8
         }
         __syncthreads();
         if (threadIdx.x == 0 && (czh_i.fail | czh_i.wave_fail[0] | czh_i.wave_fail[1] | czh_i.wave_fail[2] | czh_i.wave_fail[3])) {
-            /* the frame goes back to cz_decode_frames_kernel; one whose result record the scan already wrote is no longer looked at by
-               cz_execute_frames_kernel, so it is listed here */
-            a.lit_first[f] = 0;
-            const uint32_t old = atomicExch(&a.frame_pre[f], 0u);
-            /* (a frame is listed once however many of its sections fail: the mark stays, or cz_execute_frames_kernel would list it again) */
-            if ((old & CZ_PRE_DONE) && a.fallback_list) { a.frame_pre[f] = CZ_PRE_PUSHED; a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
-            else if (old == CZ_PRE_PUSHED) a.frame_pre[f] = CZ_PRE_PUSHED;
+            czh_hand_back(a, f);
         }
     }
 }
@@ -398,11 +402,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 4) cz_huf1_kernel(cz
         if (!bad) bad = cz_decode_huf_literals(blk, (cz_gptr)((sg.direct ? a.out_base : a.lit_arena) + sg.dst)) != 0;
         __syncthreads();
         if (bad && LANE == 0) {
-            a.lit_first[f] = 0;
-            const uint32_t old = atomicExch(&a.frame_pre[f], 0u);
-            /* (a frame is listed once however many of its sections fail: the mark stays, or cz_execute_frames_kernel would list it again) */
-            if ((old & CZ_PRE_DONE) && a.fallback_list) { a.frame_pre[f] = CZ_PRE_PUSHED; a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
-            else if (old == CZ_PRE_PUSHED) a.frame_pre[f] = CZ_PRE_PUSHED;
+            czh_hand_back(a, f);
         }
     }
 }

@@ -108,12 +108,12 @@ typedef struct cz_copy_seg {
 } cz_copy_seg;
 #define CZ_PRE_REGULAR 0x80000000u   /* frame_pre[f]: the scan walked the frame to its end and listed all of it; low bits: leading blocks done by the pre-pass kernels */
 #define CZ_PRE_DONE    0x40000000u   /* ... and ALL its blocks are done by them: the scan also wrote the frame's result record (no content checksum to verify) */
-#define CZ_PRE_PUSHED  0x20000000u   /* (without CZ_PRE_REGULAR) cz_huf_kernel took a CZ_PRE_DONE frame back and listed it for cz_decode_frames_kernel itself */
 #define CZ_PRE_WXDONE  0x10000000u   /* cz_wexec_kernel finished the frame (result record written): cz_execute_frames_kernel skips it */
 #define CZ_PRE_WXLIST  0x08000000u   /* cz_scan_kernel listed the frame for cz_wexec_kernel */
 #define CZ_PRE_CLAIMED 0x04000000u   /* cz_wexec_kernel and cz_execute_frames_kernel run side by side and share the frames: whichever sets this bit first does the frame */
 #define CZ_PRE_WXBIG   0x02000000u   /* one of the batch's large frames (CZ_WX_BIG_UNITS): on a near-offset batch cz_wexec_kernel does these, and only these */
-#define CZ_PRE_COUNT   0x01FFFFFFu
+#define CZ_PRE_LISTED  0x01000000u   /* the frame is on fallback_list (cz_list_fallback: whoever sets this bit first lists it, so a frame is listed ONCE); every kernel of the execute stage skips it */
+#define CZ_PRE_COUNT   0x00FFFFFFu
 
 /* chain_top (8 x u64, zeroed per launch): [0] arena units taken; bytes 16.. the work counters of the kernels; [5] / [6] sequences (units of 64, x 256) with
    near / far offset codes, [7] with a literal run above 8 or a match above 16 bytes, summed by cz_chain_kernel (see cz_wx_side_by_side, cz_exec_variant) */

@@ -73,6 +73,17 @@
 #define WX_SPIN_GUARD(cnt, ...) do { } while (0)
 #define WX_DBG(...) do { } while (0)
 #endif
+/* Every wait on another wave is BOUNDED: the two polling loops (a match that waits for its source bytes, a look-back that waits
+ * for the entries before its chunk) count their polls, and past WX_SPIN_LIMIT the wave sets ctl.err — the frame is given up and
+ * goes to cz_decode_frames_kernel like any other frame this kernel cannot finish, and every other wave of the workgroup leaves its
+ * own wait at its next poll.  A correct protocol never gets near the bound (a poll is >= 64 clocks of s_sleep plus the LDS reads:
+ * the limit is >= 30 ms of waiting, a whole frame takes 0.1-5 ms); it is there because the input is untrusted bytes and a hung
+ * wave is a hung GPU.  The emulator's limit is small, so that the test that forces it (CZ_DEBUG_WX_POISON) runs in seconds. */
+#ifdef CZ_EMU
+#define WX_SPIN_LIMIT 3000u
+#else
+#define WX_SPIN_LIMIT (1u << 20)
+#endif
 
 /* diagnostic build only (-DCZ_PROFILE): per-wave s_memtime sums per phase, added to args.prof[40..49] when the kernel ends */
 #ifdef CZ_PROFILE
@@ -367,7 +378,7 @@ __device__ static inline unsigned long long wx_match_rounds(WxCtl& ctl, uint8_t*
     const int smallseq = !__ballot(tot > 32u);
     const int small4 = !__ballot(ml > 4u || n1 != 0u);
     const unsigned long long longm = __ballot(undone && ml > WX_COOP_LEN), hugem = __ballot(undone && tot > 512u);
-    uint32_t spins = 0; (void)spins;
+    uint32_t spins = 0;
     for (;;) {
         if (!__ballot(undone)) break;
         WX_PROF_CNT(7);
@@ -379,6 +390,7 @@ __device__ static inline unsigned long long wx_match_rounds(WxCtl& ctl, uint8_t*
         const unsigned long long rm = __ballot(ready);
         if (!rm) {                                                      /* every match left waits for another wave (or the frame has been given up) */
             if (first || WX_UNI(wx_ld(&ctl.err))) break;
+            if (++spins > WX_SPIN_LIMIT) { if (lane == 0) wx_st(&ctl.err, 1u); break; }   /* bounded: give the frame up */
             WX_PAUSE(); WX_PROF_CNT(8);
             WX_SPIN_GUARD(spins, "WX SPIN match: lane %u undone %d opos %u ll %u ml %u off %u src %u slen %u horizon %u rbase %u\n", lane, undone, opos, ll, ml, off, src, slen, horizon, rbase);
             continue;
@@ -425,7 +437,7 @@ __device__ static inline unsigned long long wx_match_rounds(WxCtl& ctl, uint8_t*
  * sums of a chunk are out a whole data phase before anybody's look-back asks for them, and literal bytes have a whole step 1 to
  * arrive. */
 __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr out, cz_gcptr64 rec, uint32_t nseq, cz_gcptr bits, cz_gcptr lbase, uint32_t lit_len,
-                                          int lit_rle, uint32_t rle_byte, uint32_t cap, uint32_t wave, uint32_t nwaves, uint32_t pstart, uint32_t c0, unsigned long long* wxp) {
+                                          int lit_rle, uint32_t rle_byte, uint32_t cap, uint32_t wave, uint32_t nwaves, uint32_t pstart, uint32_t c0, unsigned long long* wxp, const int poison) {
     /* The window holds the block's output from position `pstart` on: byte `pos` of the frame at rw[pos].  Chunks from c0 on (c0 > 0:
        the pass before this one filled the window; its bytes are in HBM now and the window starts again at the position before chunk
        c0).  The first chunk whose output would pass the end of the window sets ctl.reset_at; chunks from there on are left for
@@ -461,7 +473,7 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
             a_sum_ll = s1.sum_ll; a_sum_tot = s1.sum_tot; a_o0 = s1.o0; a_o1 = s1.o1; a_o2 = s1.o2; a_habs = s1.habs;
             /* the chunk's sums — and its outgoing history when that does not depend on the incoming one (three pushes in 64
                sequences: nearly always) — are published at once */
-            if (lane == 0) {
+            if (lane == 0 && !(poison && y == 2u)) {                    /* (CZ_DEBUG_WX_POISON: chunk 2 never publishes, every look-back behind it runs into its bound) */
                 uint32_t* const mine = ctl.slot[y & (WX_NS - 1u)];
                 if (a_habs) { wx_st(&mine[5], a_o0); wx_st(&mine[6], a_o1); wx_st(&mine[7], a_o2); }
                 wx_st(&mine[1], a_sum_tot); wx_st(&mine[2], a_sum_ll);
@@ -518,7 +530,7 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
             /* wait (one word per entry): the nearest chunk before y whose own state is known (chunk y - 16, this wave's previous
                one, at the latest), the sums of those between, and the history behind chunk y - 1 */
             const uint32_t* const ent = ctl.slot[(y - 1u - (lane & 15u)) & (WX_NS - 1u)];
-            uint32_t k = 0, lbspins = 0; (void)lbspins;
+            uint32_t k = 0, lbspins = 0;
             for (;;) {
                 const uint32_t w0 = wx_ld(&ent[0]);
                 const uint32_t f = lane < 16u && (w0 >> 3) == y - lane ? (w0 & 7u) : 0u;   /* (an entry may still be that of a chunk 64 earlier) */
@@ -529,6 +541,8 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
                     if ((aggm & below) == below && (cz_readlane(f, 0) & WX_F_HOK)) break;
                 }
                 if (WX_UNI(wx_ld(&ctl.reset_at)) <= y) { stop = 1; break; }   /* a chunk before this one did not fit the window: the next pass */
+                if (WX_UNI(wx_ld(&ctl.err))) { stop = 1; break; }            /* the frame has been given up */
+                if (++lbspins > WX_SPIN_LIMIT) { if (lane == 0) wx_st(&ctl.err, 1u); stop = 1; break; }   /* bounded: give the frame up */
                 WX_PAUSE(); WX_PROF_CNT(6);
                 WX_SPIN_GUARD(lbspins, "WX SPIN look-back: y %u lane %u w0 %08x\n", y, lane, w0);
             }
@@ -554,7 +568,7 @@ __device__ static void wx_block_sequences(WxCtl& ctl, uint8_t* ring, cz_gcptr ou
             if (m_undone) { wx_match_rounds(ctl, rw, out, rbase, cap, x, out3, dump, 0, wxp, m_undone); m_undone = 0; }
             break;
         }
-        if (lane == 0) {
+        if (lane == 0 && !(poison && y == 2u)) {
             uint32_t* const mine = ctl.slot[y & (WX_NS - 1u)];
             if (!a_habs) { wx_st(&mine[5], wx_resolve(a_o0, h0, h1, h2)); wx_st(&mine[6], wx_resolve(a_o1, h0, h1, h2)); wx_st(&mine[7], wx_resolve(a_o2, h0, h1, h2)); }
             wx_st(&mine[4], L_out); wx_st(&mine[3], P_out);
@@ -680,7 +694,7 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                 const uint32_t pre = atomicOr(&a.frame_pre[f], CZ_PRE_CLAIMED);   /* (cz_execute_frames_kernel runs beside this kernel: whoever claims a frame first does it) */
                 chain_cursor = a.frame_first[f]; lit_cursor = a.lit_first[f]; pre_blocks = pre & CZ_PRE_COUNT;
                 if (!(pre & CZ_PRE_CLAIMED)) atomicAdd(&a.scan_ctl[208], 1u);
-                if (pre & CZ_PRE_CLAIMED) ctl.go = 3;
+                if (pre & (CZ_PRE_CLAIMED | CZ_PRE_LISTED)) ctl.go = 3;   /* the other kernel's, or handed back already (a huff0 kernel took it back and listed it) */
                 else if ((pre & CZ_PRE_REGULAR) && !(pre & CZ_PRE_DONE) && chain_cursor != 0 && lit_cursor != 0 && a.out_cap[f] < 0x80000000ull) {
                     czs_begin(w, a.in_base + a.in_off[f], a.in_len[f], 1);
                     if (w.active) { ctl.go = 1; ctl.P = 0; ctl.blocks = 0; ctl.hist[0] = 1; ctl.hist[1] = 4; ctl.hist[2] = 8; }   /* scratch.cairo:35 */
@@ -691,7 +705,7 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
         const uint32_t f = cz_uni(ctl.fidx);
         if (f == 0xFFFFFFFFu) break;
         if (cz_uni(ctl.go) != 1u) {                                     /* taken by the other kernel (3), or not what the scan left (2): cz_decode_frames_kernel does it from scratch */
-            if (tid == 0 && ctl.go == 2u && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }
+            if (tid == 0 && ctl.go == 2u && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); cz_list_fallback(a, f); }
             continue;
         }
         cz_gcptr fsrc = (cz_gcptr)(a.in_base + a.in_off[f]);
@@ -784,7 +798,7 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                         for (uint32_t i = tid; i < WX_RING / 32u + 4u; i += nthreads) ctl.fin[i] = 0;
                         if (tid == 0) { ctl.reset_at = WX_INF; ctl.slow_at = WX_INF; }
                         __syncthreads();
-                        wx_block_sequences(ctl, ring, (cz_gcptr)out, recp, nseq, bitp, lbase, lit_len, lit_rle, rle_byte, cap, wave, nwaves, wbase, c0, wxp);
+                        wx_block_sequences(ctl, ring, (cz_gcptr)out, recp, nseq, bitp, lbase, lit_len, lit_rle, rle_byte, cap, wave, nwaves, wbase, c0, wxp, (a.debug_flags & CZ_DEBUG_WX_POISON) != 0u);
                         __syncthreads();
                         WX_PROF_T0();
                         WX_AT(4);
@@ -844,7 +858,7 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                 atomicAdd(&a.scan_ctl[209], 1u);
             } else ok = 0;
         }
-        if (!ok && tid == 0 && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); a.fallback_list[atomicAdd(a.fallback_count, 1u)] = f; }   /* cz_decode_frames_kernel does it from scratch and reports what is wrong with it */
+        if (!ok && tid == 0 && a.fallback_list) { atomicAdd(&a.scan_ctl[207], 1u); cz_list_fallback(a, f); }   /* cz_decode_frames_kernel does it from scratch and reports what is wrong with it */
     }
 #ifdef CZ_PROFILE
     if ((tid & 63u) == 0 && a.prof) for (int i = 0; i < 10; i++) atomicAdd(&a.prof[40 + i], wxp[i]);

@@ -205,11 +205,15 @@ int cz_context_set_wexec_tuning(cz_context* ctx, int cus, int leave_per_cu, int 
 /* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' LL / OF / ML code
  * tables, in sequences x 4 — with near offset codes (2..13: offsets below 16 KiB), with far ones, with a literal run above 8 or a
  * match above 16 bytes.  The execute stage is arranged from these on the device: cz_wexec_kernel beside cz_execute_frames_kernel
- * when far > near; the 8-waves-per-SIMD build of cz_execute_frames_kernel when near > far and long < (near + far) / 512. */
+ * when far > near; the 8-waves-per-SIMD build of cz_execute_frames_kernel when near > far and long < (near + far) / 256. */
 int cz_context_last_sequence_stats(cz_context* ctx, uint64_t* near_offsets, uint64_t* far_offsets, uint64_t* long_runs);
 /* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it
  * handed on to cz_decode_frames_kernel. */
 int cz_context_last_wexec_counts(cz_context* ctx, size_t* listed, size_t* finished, size_t* given_up);
+/* Diagnostics of the most recent batch launch (synchronises): entries on the fall-back list — frames the pre-pass and execute
+ * kernels handed to cz_decode_frames_kernel, each listed once whoever handed it back.  The list has no analogue in the reference:
+ * it is the device-side form of "decode this frame by the reference's own order of steps" (src/frame_decoder.cairo:156-222). */
+int cz_context_last_fallback_count(cz_context* ctx, size_t* listed);
 /* The part of the most recent launch spent in cz_wexec_kernel (0 when it did not run). */
 int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
 
@@ -220,6 +224,8 @@ int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
  * 4-stream split back, cz_huf1_kernel keeps it). */
 #define CZ_DEBUG_CHAIN_CPP_STEP 1u
 #define CZ_DEBUG_NO_HUF1 2u
+#define CZ_DEBUG_WX_POISON 4u       /* cz_wexec_kernel: chunk 2 of every block never publishes its look-back entry, so every wave behind it waits until the
+                                       bound of its polling loop (WX_SPIN_LIMIT) and the frame is handed to cz_decode_frames_kernel: the test of that bound */
 int cz_context_set_debug_flags(cz_context* ctx, uint32_t flags);
 /* Copies the first `bytes` of the chain arena (headers, state -> code maps and per-sequence records of the most recent batch
  * launch, as cz_chain_kernel left them) to host memory and returns the arena units in use; synchronises.  For tests. */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU parity suite, smoke() and the default bench line in one call: scripts/gpu_suite.sh <out-subdir> [bench args...]
 set -o pipefail
-D=gpurun_out/${1:-r4}; shift
+D=gpurun_out/${1:-r5}; shift
 mkdir -p $D
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $D/pytest_gpu.log 2>&1; rc=$?; tail -3 $D/pytest_gpu.log; [ $rc = 0 ] || exit $rc
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 || exit 1

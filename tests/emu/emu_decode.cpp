@@ -121,6 +121,7 @@ int main(int argc, char** argv) {
     /* EMU_WEXEC=<waves>: cz_wexec_kernel (that many waves per workgroup) ahead of cz_execute_frames_kernel */
     const int wx_waves = with_exec && getenv("EMU_WEXEC") ? atoi(getenv("EMU_WEXEC")) : 0;
     std::vector<uint32_t> wx_list(n ? n : 1, 0); uint32_t wx_counter = 0;
+    a.debug_flags = getenv("EMU_DEBUG_FLAGS") ? (uint32_t)atoi(getenv("EMU_DEBUG_FLAGS")) : 0u;   /* CZ_DEBUG_* */
     if (wx_waves > 0) { a.wx_list = wx_list.data(); a.wx_counter = &wx_counter; a.wx_force = getenv("EMU_WX_AUTO") ? 0u : 1u; a.wx_leave = 0; }   /* forced on unless EMU_WX_AUTO: the batch's offset codes decide, as on the device */
     uint32_t fallback_count = 0; std::vector<uint32_t> fallback_list(n ? n : 1, 0);
     std::vector<cz_blk_desc> blk_desc; std::vector<uint32_t> scan_ctl(CZ_SCAN_CTL_WORDS, 0), frame_order, scan_wave;
@@ -159,7 +160,10 @@ int main(int argc, char** argv) {
        "done" and takes every literals section; default: it sees it done at once and cz_huf_kernel takes them all */
     const int huf1_all = getenv("EMU_HUF1") && atoi(getenv("EMU_HUF1")) > 0;
     a.chain_grid = (uint32_t)grid;
-    const int order[10] = {4, 5, 0, 9, 7, 8, 10, 2, 11, 1};            /* 2 / 11: cz_execute_frames_kernel beside / behind cz_wexec_kernel (10) */
+    int order[10] = {4, 5, 0, 9, 7, 8, 10, 2, 11, 1};                  /* 2 / 11: cz_execute_frames_kernel beside / behind cz_wexec_kernel (10) */
+    /* EMU_EXEC_FIRST=1: cz_execute_frames_kernel ahead of cz_wexec_kernel — on the device the two run side by side, and which of them
+       meets a frame first depends on timing; the emulator runs them one after the other, in either order */
+    if (getenv("EMU_EXEC_FIRST") && atoi(getenv("EMU_EXEC_FIRST")) > 0) { order[6] = 2; order[7] = 10; }
     for (int pi = arena ? 0 : 9; pi < 10; pi++) {
         const int which = order[pi];
         if ((which == 2 || which == 11) && !with_exec) continue;
@@ -190,7 +194,13 @@ int main(int argc, char** argv) {
                 scan_ctl[168] + scan_ctl[169] + scan_ctl[170] + scan_ctl[171] + scan_ctl[172] + scan_ctl[173] + scan_ctl[174] + scan_ctl[175] + scan_ctl[176] + scan_ctl[177] + scan_ctl[178] + scan_ctl[179] + scan_ctl[180] + scan_ctl[181] + scan_ctl[182] + scan_ctl[183] + scan_ctl[184] + scan_ctl[185] + scan_ctl[186] + scan_ctl[187], scan_ctl[202]);
         free(lit_arena);
     }
-    if (with_exec) fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_execute_frames_kernel\n", (unsigned long long)(n - fallback_count));
+    if (with_exec) {
+        fprintf(stderr, "EMU_EXEC: %llu frames finished by cz_execute_frames_kernel\n", (unsigned long long)(n - fallback_count));
+        /* a frame is handed to cz_decode_frames_kernel ONCE (cz_list_fallback), whoever hands it back */
+        std::vector<int> seen(n ? n : 1, 0);
+        for (uint32_t i = 0; i < fallback_count && i < n; i++) { if (fallback_list[i] >= n || seen[fallback_list[i]]++) { fprintf(stderr, "EMU_EXEC: frame %u is on the fall-back list twice (or not a frame)\n", fallback_list[i]); return 4; } }
+        if (fallback_count > n) { fprintf(stderr, "EMU_EXEC: %u entries on the fall-back list of %llu frames\n", fallback_count, (unsigned long long)n); return 4; }
+    }
     if (wx_waves > 0) { unsigned long long nd = 0; for (uint64_t i = 0; i < n; i++) nd += (frame_pre[i] & CZ_PRE_WXDONE) != 0; fprintf(stderr, "EMU_WEXEC: %u frames listed, %llu finished by cz_wexec_kernel\n", scan_ctl[206], nd); }
     FILE* g = fopen(argv[2], "wb"); if (!g) return 2;
     for (uint64_t i = 0; i < n; i++) {

@@ -19,7 +19,7 @@ def build(target="emu_decode"):
     return os.path.join(EMU_DIR, target)
 
 
-def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None, wexec_waves=0, verify=True, wexec_auto=False):
+def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kernel=False, lit_bytes=0, dict_path=None, wexec_waves=0, verify=True, wexec_auto=False, debug_flags=0):
     exe = build(target)
     with tempfile.TemporaryDirectory() as td:
         inp, outp = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
@@ -36,6 +36,7 @@ def run(frames, caps, target="emu_decode", timeout=900, chain_bytes=0, exec_kern
             if wexec_auto:
                 env["EMU_WX_AUTO"] = "1"
         env["EMU_VERIFY"] = "1" if verify else "0"
+        env["EMU_DEBUG_FLAGS"] = str(int(debug_flags))
         p = subprocess.run([exe, inp, outp], capture_output=True, timeout=timeout, env=env)
         run.last_stderr = p.stderr.decode()[-2000:]
         if p.returncode != 0:

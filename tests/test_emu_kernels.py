@@ -13,8 +13,8 @@ from cairo_zstd_amd import status, synth
 from conftest import corpus_pairs, raw_frame_with_checksum
 
 
-def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0, wexec_waves=0, verify=True, wexec_auto=False):
-    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes, wexec_waves=wexec_waves, verify=verify, wexec_auto=wexec_auto)
+def _run_and_compare(frames, caps, chain_bytes=0, exec_kernel=False, lit_bytes=0, wexec_waves=0, verify=True, wexec_auto=False, debug_flags=0):
+    res = emu_runner.run(frames, caps, chain_bytes=chain_bytes, exec_kernel=exec_kernel, lit_bytes=lit_bytes, wexec_waves=wexec_waves, verify=verify, wexec_auto=wexec_auto, debug_flags=debug_flags)
     bad = []
     for i, (fr, cap, (r, out)) in enumerate(zip(frames, caps, res)):
         st, ref, info = oracle.decode_frame(fr, cap=cap)
@@ -189,6 +189,48 @@ def test_emu_wexec_kernel_large_frames_of_a_near_offset_batch_and_chunks_longer_
     err = emu_runner.run.last_stderr
     done_wx, not_handed_on = int(err.split("frames listed, ")[1].split()[0]), int(err.split("EMU_EXEC: ")[1].split()[0])
     assert done_wx == 3 and not_handed_on == len(frames), (done_wx, not_handed_on, len(frames))   # the large ones there, nothing left to cz_decode_frames_kernel
+
+
+def test_emu_wexec_kernel_bounded_waits_poisoned_lookback_entry():
+    """Every device-side wait of cz_wexec_kernel is bounded (WX_SPIN_LIMIT).  CZ_DEBUG_WX_POISON: chunk 2 of every block never
+    publishes its look-back entry, so every chunk behind it polls until the bound, sets ctl.err, and the frame is handed to
+    cz_decode_frames_kernel — which decodes it like any other frame.  Frames of at most two chunks are not affected."""
+    import cairo_zstd_amd as cz
+    pairs = [p for p in corpus_pairs(max_orig=30000) if len(p[2]) >= 6000][:3] + corpus_pairs(max_orig=1500)[:3]   # blocks of several chunks, and small ones
+    frames, caps = [z for _, z, _ in pairs], [len(o) + 16 for _, _, o in pairs]
+    _run_and_compare(frames, caps, chain_bytes=16 << 20, lit_bytes=8 << 20, exec_kernel=True, wexec_waves=4, verify=False)
+    err = emu_runner.run.last_stderr
+    listed, done = int(err.split("EMU_WEXEC: ")[1].split()[0]), int(err.split("frames listed, ")[1].split()[0])
+    _run_and_compare(frames, caps, chain_bytes=16 << 20, lit_bytes=8 << 20, exec_kernel=True, wexec_waves=4, verify=False, debug_flags=cz.DEBUG_WX_POISON)
+    err = emu_runner.run.last_stderr
+    listed_p, done_p = int(err.split("EMU_WEXEC: ")[1].split()[0]), int(err.split("frames listed, ")[1].split()[0])
+    assert listed_p == listed and done_p < done, (listed, done, listed_p, done_p)     # the frames with a third chunk were given up at the bound ...
+    assert int(err.split("EMU_EXEC: ")[1].split()[0]) == len(frames) - (done - done_p)  # ... and went to cz_decode_frames_kernel, once each
+
+
+def test_emu_frames_handed_back_by_huf_kernel_are_listed_once_beside_wexec_kernel():
+    """a frame listed for cz_wexec_kernel whose literals cz_huf_kernel hands back (the D5 block — an uneven 4-stream
+    split — with a sequence behind it) used to be put on the fall-back list by BOTH execute kernels.  Now whoever sets CZ_PRE_LISTED first lists it: the
+    emulator fails the run when a frame is on the list twice or the list has more than n entries."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors")
+    man = json.load(open(os.path.join(d, "manifest_r5.json")))
+    name = "d5_uneven_split_with_sequences.zst"                          # the D5 block + one sequence: chain records, so both execute kernels have it
+    z5s = open(os.path.join(d, name), "rb").read()
+    frames, caps = [z5s] * 12, [man[name]["orig_len"] + 16] * 12
+    for _, z, orig in corpus_pairs(max_orig=1500)[:4]:
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    for exec_first in ("0", "1"):                                       # either execute kernel may meet a frame first
+        os.environ["EMU_EXEC_FIRST"] = exec_first
+        try:
+            _run_and_compare(frames, caps, chain_bytes=8 << 20, lit_bytes=4 << 20, exec_kernel=True, wexec_waves=4, verify=False)
+        finally:
+            del os.environ["EMU_EXEC_FIRST"]
+        err = emu_runner.run.last_stderr
+        assert int(err.split("EMU_LIT: ")[1].split()[0]) <= len(frames) - 12, err      # cz_huf_kernel handed the D5 frames back
+        assert int(err.split("EMU_WEXEC: ")[1].split()[0]) >= 12, err                  # ... which were listed for cz_wexec_kernel
+        assert int(err.split("EMU_EXEC: ")[1].split()[0]) <= len(frames) - 12, err     # and they are on the fall-back list (once: the emulator checks)
 
 
 def test_emu_d2_weight_log_10_unsupported():

@@ -580,6 +580,76 @@ def test_execute_frames_kernel_matches_oracle(cz):
     finally:
         c.close()
 
+def test_wexec_kernel_waits_are_bounded(cz):
+    """Every device-side wait of cz_wexec_kernel counts its polls (WX_SPIN_LIMIT).  CZ_DEBUG_WX_POISON: chunk 2 of every block never
+    publishes its look-back entry — a protocol error made on purpose —, so the chunks behind it poll to the bound, the workgroup
+    gives the frame up, and cz_decode_frames_kernel decodes it (sequence_execution.cairo:12-83 by one wave): same bytes as the
+    oracle, nothing hangs.  Frames of at most two chunks per block are not affected."""
+    from cairo_zstd_amd import synth
+    c = cz.Context(0)
+    c.set_chain_arena(256 << 20, min_sequences=0)
+    c.set_literal_arena(64 << 20)
+    c.set_wexec_kernel(True, force=True)
+    try:
+        b = synth.generate("full_4a", 40, first_index=31)
+        frames, caps = [b.frame(i) for i in range(b.n)], [int(r) for r in b.regen]
+        for name, z, orig in corpus_pairs(max_orig=1500)[:8]:
+            frames.append(z)
+            caps.append(len(orig) + 32)
+        refs = [oracle.decode_frame(fr, cap=cap) for fr, cap in zip(frames, caps)]
+        for flags in (0, cz.DEBUG_WX_POISON):
+            c.set_debug_flags(flags)
+            got = cz.decode_batch_host(frames, caps, c)
+            for i, ((st, ref, _), (r, out)) in enumerate(zip(refs, got)):
+                assert int(r["status"]) == st == 0 and out == ref, (flags, i, cz.status.name(r["status"]))
+            listed, finished, handed = c.last_wexec_counts()
+            if flags:
+                assert listed >= b.n and finished < listed - b.n + 1 and handed >= b.n, (listed, finished, handed)   # every config-4a frame ran into the bound
+                assert c.last_fallback_count() >= b.n
+            else:
+                assert finished + handed <= listed and finished >= 1, (listed, finished, handed)
+    finally:
+        c.set_debug_flags(0)
+        c.close()
+
+
+def test_frames_handed_back_by_huf_kernel_are_listed_once(cz):
+    """a frame listed for cz_wexec_kernel whose literals section cz_huf_kernel hands back (the D5 block — 4 huff0 streams
+    that do not split ceil(regen / 4), literals_section_decoder.cairo:95-115 — with a sequence behind it, so that it has chain
+    records) was put on the fall-back list by whichever execute kernel met it — both, when their timing allowed — and decoded
+    twice at once; with most of a batch handed back the list overflowed.  Now the kernel that sets CZ_PRE_LISTED first lists the
+    frame: the list holds every handed-back frame exactly once."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors")
+    man = json.load(open(os.path.join(d, "manifest_r5.json")))
+    name = "d5_uneven_split_with_sequences.zst"
+    z, want = open(os.path.join(d, name), "rb").read(), open(os.path.join(d, name[:-4] + ".orig"), "rb").read()
+    assert hashlib.sha256(want).hexdigest() == man[name]["orig_sha256"]
+    n_bad = 6000
+    good = [(zz, orig) for _, zz, orig in corpus_pairs(max_orig=4000)][:40]
+    frames = [z] * n_bad + [zz for zz, _ in good]
+    caps = [len(want) + 16] * n_bad + [len(o) + 32 for _, o in good]
+    c = cz.Context(0)
+    c.set_chain_arena(256 << 20, min_sequences=0)
+    c.set_literal_arena(64 << 20)
+    try:
+        for force, flags in ((True, cz.DEBUG_NO_HUF1), (True, 0), (False, cz.DEBUG_NO_HUF1)):
+            c.set_wexec_kernel(True, force=force)
+            c.set_debug_flags(flags)
+            for rep in range(3):
+                got = cz.decode_batch_host(frames, caps, c)
+                for i, (r, out) in enumerate(got):
+                    assert int(r["status"]) == 0 and out == (want if i < n_bad else good[i - n_bad][1]), (force, flags, rep, i, cz.status.name(r["status"]))
+                fb = c.last_fallback_count()
+                if flags:
+                    assert n_bad <= fb <= len(frames), (force, rep, fb)     # every D5 frame handed back (cz_huf_kernel alone decodes literals), none twice
+                else:
+                    assert fb <= len(frames), (force, rep, fb)              # (cz_huf1_kernel keeps the sections it gets to first)
+    finally:
+        c.set_debug_flags(0)
+        c.close()
+
+
 @pytest.mark.parametrize("auto", [False, True])
 def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
     """cz_wexec_kernel (a workgroup of 16 waves per frame, the block in hand in an LDS window, chunks of 64 sequences composed by a
