@@ -157,6 +157,16 @@ class Context:
         lib().cz_context_last_sequence_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
         return int(a.value), int(b.value), int(c.value)
 
+    def set_early_execute(self, on: bool):
+        """Two chain launches (large blocks / all others) with the early execute launches behind the second, or one (default)."""
+        lib().cz_context_set_early_execute(self._h, 1 if on else 0)
+
+    def last_small_ms(self) -> float:
+        """When the small blocks' chains and all literals of the last launch were done, ms from its start (0: not a split launch)."""
+        ms = C.c_float(0)
+        lib().cz_context_last_small_ms(self._h, C.byref(ms))
+        return float(ms.value)
+
     def last_fallback_count(self) -> int:
         """Frames the pre-pass and execute kernels of the last launch handed to cz_decode_frames_kernel (each listed once)."""
         a = C.c_size_t()

@@ -107,6 +107,10 @@ def lib() -> C.CDLL:
     L.cz_context_debug_read_chain_arena.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.cz_context_last_sequence_stats.restype = C.c_int
     L.cz_context_last_sequence_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.cz_context_set_early_execute.restype = C.c_int
+    L.cz_context_set_early_execute.argtypes = [vp, C.c_int]
+    L.cz_context_last_small_ms.restype = C.c_int
+    L.cz_context_last_small_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_last_fallback_count.restype = C.c_int
     L.cz_context_last_fallback_count.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.cz_context_last_wexec_counts.restype = C.c_int

@@ -315,6 +315,12 @@ __device__ static inline void czc_step(CzcLane& c, const CzcRole& ro, CZ_GLOBAL 
    address, all others into the sink. */
 #ifdef CZC_EXP_NOSTORE   /* diagnostic builds (make exp): what the record store costs */
 #define CZC_ASM_STORE(OFF) "s_nop 0\n"
+#elif defined(CZC_EXP_SC1)   /* diagnostic: write-through record stores */
+#define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF " sc1\n"
+#elif defined(CZC_EXP_SC01)
+#define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF " sc0 sc1\n"
+#elif defined(CZC_EXP_NT)
+#define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF " nt\n"
 #else
 #define CZC_ASM_STORE(OFF) "global_store_dwordx4 %[RP], v[120:123], off offset:" #OFF "\n"
 #endif
@@ -700,6 +706,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
     uint32_t base[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { base[c] = run; run += a.scan_ctl[c]; } }   /* larger classes first */
     uint32_t lbase[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { lbase[c] = run; run += with_lits ? a.scan_ctl[136 + c] : 0u; } }
     uint64_t first_hdr = 0, prev_hdr = 0, first_node = 0, prev_node = 0;
+    int has_large = 0;                                                  /* a block of CZ_BIG_BLOCK_SEQS sequences or more: its chain runs in the launch of the large blocks */
     uint32_t defidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, tree_seg = 0xFFFFFFFFu;
     const uint64_t ibase = valid ? a.in_off[f] : 0, obase = valid ? a.out_off[f] : 0;
     while (__ballot(w.active)) {
@@ -732,8 +739,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
                     if (md != 3) defidx[t] = idx;
                 }
                 a.blk_desc[idx] = d;
+                if (cls >= CZ_BIG_BLOCK_CLASS) has_large = 1;
                 if (at) {
-                    a.chain_arena[at + 2] = 0;
+                    a.chain_arena[at + 2] = 0; a.chain_arena[at + 3] = 0;   /* word 3: "chain done" (cz_chain_kernel, the large blocks' launch) */
                     if (prev_hdr) a.chain_arena[prev_hdr + 2] = at; else first_hdr = at;
                     prev_hdr = at; at += 4ull + CZC_MAP_WORDS + b.nseq;
                 }
@@ -764,7 +772,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
             else { cz_copy_seg d; d.src = ibase + q.copy_src; d.dst = obase + kout_here; d.len = placed ? q.copy_len : 0u; d.fill = q.copy_fill; a.copy_segs[cticket] = d; }
         }
     }
-    int wx = 0;
+    int wx = 0, early = 0;
     if (valid) {
         const int good = placed && w.ok && pre_blocks <= CZ_PRE_COUNT;   /* (the count shares frame_pre[f] with the marks) */
         a.frame_first[f] = good ? first_hdr : 0;
@@ -785,9 +793,12 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
             wx = good && !(pre & CZ_PRE_DONE) && first_hdr != 0 && units >= CZ_WX_MIN_UNITS && ocap < 0x80000000ull && !(a.verify_checksum && w.has_checksum) && a.wx_list != nullptr;
             int big = wx && units >= CZ_WX_BIG_UNITS;
             if (big) big = atomicAdd(&a.scan_ctl[210], 1u) < CZ_WX_BIG_MAX;
-            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre | (wx ? CZ_PRE_WXLIST : 0u) | (big ? CZ_PRE_WXBIG : 0u);
+            /* a frame without a large block, and not one of the batch's large frames: the early execute launch may take it */
+            early = good && !(pre & CZ_PRE_DONE) && first_hdr != 0 && !has_large && !big && a.exec_counter != nullptr;
+            a.lit_first[f] = good ? (first_node ? first_node : 1) : 0; a.frame_pre[f] = pre | (wx ? CZ_PRE_WXLIST : 0u) | (big ? CZ_PRE_WXBIG : 0u) | (early ? CZ_PRE_EARLY : 0u);
         }
     }
+    { const unsigned long long em = __ballot(early); if (em && LANE == __ffsll((long long)em) - 1) atomicAdd(&a.scan_ctl[211], (uint32_t)__popcll(em)); }
     if (a.wx_list) {                                                    /* frames for cz_wexec_kernel: everything pre-passed, output fits its LDS window, enough sequences for a workgroup */
         const unsigned long long wm = __ballot(wx);
         if (wm) {
@@ -864,15 +875,22 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
 #ifdef CZ_PROFILE
     unsigned long long cprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ct_ = __builtin_amdgcn_s_memtime();
 #endif
-    uint32_t ndesc = 0; for (int c = 0; c < 20; c++) ndesc += a.scan_ctl[c];
+    uint32_t ndesc = 0, nlarge = 0; for (int c = 0; c < 20; c++) { ndesc += a.scan_ctl[c]; if ((uint32_t)c >= CZ_BIG_BLOCK_CLASS) nlarge += a.scan_ctl[c]; }
     if (ndesc > a.blk_capacity) ndesc = a.blk_capacity;
+    if (nlarge > ndesc) nlarge = ndesc;
+    /* this launch's share of the block list (largest class first, so the large blocks are its head) and its work counter;
+       the launch of the large blocks publishes every block it is done with (CZ_RELEASE_AGENT, header word 3) */
+    const uint32_t list_lo = a.chain_part == 2u ? nlarge : 0u, list_hi = a.chain_part == 1u ? nlarge : ndesc;
+    uint32_t* const list_counter = a.chain_part == 2u ? &a.scan_ctl[212] : &a.scan_ctl[64];
+    const int publish = a.chain_part == 1u;
+    if (list_lo >= list_hi) { if (LANE == 0) atomicAdd(&a.scan_ctl[205], 1u); return; }   /* nothing for this launch: its waves leave at once */
     /* per slot (the same values in the four lanes of its quad, except where noted) */
     int chain_live = 0, wide = 0, exhausted = 0;                        /* exhausted: owner lanes */
     uint32_t qnseq = 0, done = 0, sbits = 0;
     uintptr_t S = 0, E = 0; intptr_t ring_base = 0, loaded_lo = 0;
     CZ_GLOBAL uint64_t* rec = nullptr;
     /* owner lanes: the block in hand */
-    uint32_t o_frame = 0, o_nseq = 0, o_mapflags = 0, o_bitoff = 0, o_bad0 = 0; uint64_t o_hdr = 0; int o_have = 0;
+    uint32_t o_frame = 0, o_nseq = 0, o_mapflags = 0, o_bitoff = 0, o_bad0 = 0; uint64_t o_hdr = 0; int o_have = 0, o_pub = 0;
     CzcLane c; c.E = (uint32_t)CZC_E16_IDLE << 16; c.S = 0; c.u = 0; c.ph = 0; c.w0 = c.w1 = c.w2 = 0; c.slow = 0;
     CzcPre pre;
     for (uint32_t r = 0; r < CZC_PF; r++) pre.v[r] = uint4{0, 0, 0, 0};
@@ -883,13 +901,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             int got = 0;
             if (owner && !o_have && !exhausted) {
                 for (;;) {
-                    const uint32_t idx = atomicAdd(&a.scan_ctl[64], 1u);
-                    if (idx >= ndesc) { exhausted = 1; break; }
+                    const uint32_t idx = list_lo + atomicAdd(list_counter, 1u);
+                    if (idx >= list_hi) { exhausted = 1; break; }
                     const cz_blk_desc d = a.blk_desc[idx];
                     if (!d.nseq) continue;                              /* void entry: its frame is not pre-passed */
                     blk = (cz_gcptr)(a.in_base + a.in_off[d.frame] + d.blk_off); bsize = d.bsize; sbody = d.sbody; modes = d.modes;
                     def[0] = d.def[0]; def[1] = d.def[1]; def[2] = d.def[2];
                     o_frame = d.frame; o_nseq = d.nseq; o_hdr = d.hdr; o_have = 1; got = 1;
+                    o_pub = publish && (a.frame_pre[d.frame] & CZ_PRE_WXBIG) != 0u;   /* a block of one of the batch's large frames: cz_wexec_kernel's early launch may wait for it */
                     break;
                 }
             }
@@ -935,7 +954,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 }
                 if (go) { uint32_t dummy; bad = czc_parse_tables(dblk, dbsize, dsbody, dmodes, 1u << t, sl.stage, 256u, sl.probs, &binfo, rles, &dummy); }
             }
-            if (got && bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
+            if (got && bad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; if (o_pub) CZ_ST_AGENT(&a.chain_arena[o_hdr + 3], (uint64_t)2); }
             /* What the batch's offsets look like, for the execute stage (cz_wx_side_by_side): sequences (in units of 64) weighted by
                the share of their block's offset codes that are near (2..13: offsets below 16 KiB, which a frame's waves in
                cz_wexec_kernel would have to wait on each other for) and far (14 and up). */
@@ -990,7 +1009,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     if (sbad && LANE == ol) tbad = 1;
                 }
                 __syncthreads();
-                if (got && tbad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; }
+                if (got && tbad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; if (o_pub) CZ_ST_AGENT(&a.chain_arena[o_hdr + 3], (uint64_t)2); }
                 if (got) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
                     table[0] = CZC_E16(0u, 0u, t == 1 ? (uint32_t)rles[t] : (cs.llml[(t == 2 ? 40u : 0u) + (uint32_t)rles[t]] >> 24));
@@ -1103,11 +1122,20 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
         /* ---- finished chains: finalize the block (owner) and free the slot */
         if (__ballot(chain_live && done >= qnseq)) {
             const int fin = chain_live && done >= qnseq;
+            int fbad = 0;
             if (fin && owner) {
                 /* the cursor only moves down, so an overrun (NotEnoughBytes, :281) shows in its final value */
-                if (o_bad0 || c.u - (int32_t)sbits != 0) a.frame_first[o_frame] = 0;    /* padding / overrun / ExtraBits: the frame is not pre-passed */
-                else { uint64_t* h = a.chain_arena + o_hdr; h[0] = ((uint64_t)o_nseq << 32) | o_mapflags; h[1] = o_bitoff; h[3] = 0; }
+                fbad = o_bad0 || c.u - (int32_t)sbits != 0;
+                if (fbad) a.frame_first[o_frame] = 0;                   /* padding / overrun / ExtraBits: the frame is not pre-passed */
+                else { uint64_t* h = a.chain_arena + o_hdr; h[0] = ((uint64_t)o_nseq << 32) | o_mapflags; h[1] = o_bitoff; if (!o_pub) h[3] = 0; }
                 o_have = 0;
+            }
+            if (__ballot(fin && owner && o_pub)) {
+                /* the block's records, maps and header — stores of every lane of this wave — leave this XCD's L2 before the flag does:
+                   cz_wexec_kernel's early launch, on another CU, starts on the block when it sees the flag.  (Only blocks of the batch's
+                   LARGE frames — a few hundred at most — are published: the write-back is a whole L2's.) */
+                CZ_RELEASE_AGENT();
+                if (fin && owner && o_pub) CZ_ST_AGENT(&a.chain_arena[o_hdr + 3], (uint64_t)(fbad ? 2 : 1));
             }
             if (fin) { chain_live = 0; wide = 0; ro.tb = cs.idle; c.S = 0; c.E = (uint32_t)CZC_E16_IDLE << 16; }
             CZC_PROF_ACC(4);

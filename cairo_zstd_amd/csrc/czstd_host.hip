@@ -76,6 +76,8 @@ struct cz_context {
     uint32_t wexec_force = 0;              /* 0: the kernels decide from the batch's offset codes; 1: always side by side (A/B runs) */
     int wexec_leave_per_cu = 7;           /* frames per workgroup of cz_wexec_kernel that cz_execute_frames_kernel leaves to it at the end of a batch */
     bool wexec_ready = false; uint32_t* wx_list = nullptr; hipEvent_t ev_wx = nullptr; bool timed_wx = false;
+    bool early_execute = false;            /* (off by default: measured, profiles/r5/NOTES.md) the chain pre-pass as two launches (large blocks / all others) and the early execute launches behind the second (cz_launch) */
+    hipStream_t stream4 = nullptr; hipEvent_t ev_small = nullptr, ev_e1 = nullptr, ev_w1 = nullptr, ev_x4 = nullptr; bool timed_small = false;
     bool exec_kernel = true;               /* frames the pre-pass finished (chain records + literals) run on cz_execute_frames_kernel; 0: all on cz_decode_frames_kernel */
     int exec_grid = 0, exec8_grid = 0;
     uint32_t* fallback_list = nullptr;                                  /* n entries, allocated with frame_first */
@@ -183,6 +185,11 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->fallback_list) (void)hipFree(c->fallback_list);
     if (c->wx_list) (void)hipFree(c->wx_list);
     if (c->ev_wx) (void)hipEventDestroy(c->ev_wx);
+    if (c->ev_small) (void)hipEventDestroy(c->ev_small);
+    if (c->ev_e1) (void)hipEventDestroy(c->ev_e1);
+    if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
+    if (c->ev_x4) (void)hipEventDestroy(c->ev_x4);
+    if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_mid2) (void)hipEventDestroy(c->ev_mid2);
@@ -355,6 +362,20 @@ CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 
+/* The chain pre-pass as two launches — large blocks / all others — with the early execute launches behind the second (1), or one
+   launch and the execute stage behind all of it (0, the default: on the corpus-like mix the small blocks' launch takes as long as
+   the large blocks' — table parse and build per block, not chain steps — so nothing is ready early; profiles/r5/NOTES.md). */
+CZ_EXPORT int cz_context_set_early_execute(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->early_execute = on != 0; return CZ_OK; }
+/* When the small blocks' chains and every literal of the last launch were done, in ms from its start (0: not a split launch). */
+CZ_EXPORT int cz_context_last_small_ms(cz_context* c, float* ms) {
+    if (!c || !ms) return CZ_E_INVALID_ARG;
+    *ms = 0.0f;
+    if (!c->timed || !c->timed_small) return CZ_OK;
+    CZ_HIP(c, hipSetDevice(c->device));
+    CZ_HIP(c, hipEventSynchronize(c->ev_stop));
+    CZ_HIP(c, hipEventElapsedTime(ms, c->ev_start, c->ev_small));
+    return CZ_OK;
+}
 /* Far-offset batches run cz_wexec_kernel side by side with cz_execute_frames_kernel (default, 1), or cz_execute_frames_kernel alone (0). */
 CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->wexec_kernel = on != 0; return CZ_OK; }
 /* A/B knobs of the side-by-side execute stage: CUs cz_wexec_kernel runs on (0: half), frames per CU of it that cz_execute_frames_kernel
@@ -502,11 +523,29 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
         a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
         CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
+        if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
         a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
-        if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
+        /* With the execute stage on, the chain pre-pass is TWO launches (czstd_types.h, CZ_BIG_BLOCK_SEQS): the large blocks on the
+           context's stream — the batch lasts as long as its longest chain —, all others on a stream of their own, followed there by
+           cz_huf_kernel and the joins of the literal kernels.  When THAT stream is done (ev_small), every frame without a large block
+           is ready, and two early launches start beside the large blocks' chains: cz_execute_frames_kernel for those frames, and
+           cz_wexec_kernel for the batch's large frames, block by block behind their chains' flags.  The launches behind the large
+           chains are the ones there always were; frames are claimed, so whoever gets to a frame first does it. */
+        const bool split = use_exec && c->early_execute;
+        /* FOUR streams in all (the runtime multiplexes more than that onto four hardware queues, and two streams on one queue run one
+           after the other): the context's — large chains, then cz_wexec_kernel's later launch; stream2 — cz_huf1_kernel, then
+           cz_wexec_kernel's early launch; stream3 — cz_tile_kernel, then cz_execute_frames_kernel's early launch; stream4 — small
+           chains, cz_huf_kernel, then cz_execute_frames_kernel's later launch. */
+        if (split && !c->stream4) {
+            if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_small) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_x4, hipEventDisableTiming) != hipSuccess) {
+                c->last_hip_error = (int)hipGetLastError(); return CZ_E_HIP;
+            }
+        }
         /* the literal and copy kernels may start when the chain kernel does (not before: they would take the LDS the chain
            kernel's workgroups need and hold them up) */
 #ifdef CZ_EXPERIMENT
@@ -530,10 +569,20 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
 #endif
         if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
         const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
-        a.chain_grid = (uint32_t)cgrid;
+        a.chain_grid = (uint32_t)(split ? 2 * cgrid : cgrid);           /* (cz_huf1_kernel stops when this many chain waves have counted themselves out) */
+        a.chain_part = split ? 1u : 0u;
         hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
         CZ_HIP(c, hipGetLastError());
         CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
+        hipStream_t sl = c->stream;                                     /* the stream the rest of the pre-pass is enqueued on */
+        if (split) {
+            sl = c->stream4;
+            CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_fork, 0));
+            a.chain_part = 2u;
+            hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, sl, a);
+            CZ_HIP(c, hipGetLastError());
+            a.chain_part = 0u;
+        }
         if (lit_pass) {
             /* next to the chain kernel, on streams of their own: cz_huf1_kernel (one wave per literals section: what fits beside the
                chain kernel's LDS) and cz_tile_kernel; behind the chain kernel, with the whole chip: cz_huf_kernel for what is left */
@@ -551,22 +600,45 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             if (!(c->debug_flags & CZ_DEBUG_NO_HUF1)) hipLaunchKernelGGL(cz_huf1_kernel, dim3(h1grid), dim3(CZ_WG_THREADS), 0, c->stream2, a);
             CZ_HIP(c, hipGetLastError());
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream, a);
+            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, sl, a);
             CZ_HIP(c, hipGetLastError());
-            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
+            CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_join, 0));
+            CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_join3, 0));
+            if (split) {
+                CZ_HIP(c, hipEventRecord(c->ev_small, sl));             /* the small blocks' chains and every literal: done */
+                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_small, 0));
+            }
             CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* all of the pre-pass done */
             c->timed_lit = true;
         } else c->timed_lit = false;
         c->timed_chain = true;
-        c->timed_exec = false; c->timed_wx = false;
+        c->timed_exec = false; c->timed_wx = false; c->timed_small = split;
         if (use_exec) {
             int egrid = (int)(n < (size_t)c->exec_grid ? n : (size_t)c->exec_grid);
 #ifdef CZ_EXPERIMENT
             if (const char* e = getenv("CZ_EXEC_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < egrid) egrid = g; }
 #endif
             const int egrid8 = (int)(n < (size_t)c->exec8_grid ? n : (size_t)c->exec8_grid);
-            a.wx_leave = 0; a.exec_variant_force = c->exec_variant_force;
+            a.wx_leave = 0; a.exec_variant_force = c->exec_variant_force; a.wx_force = c->wexec_force;
+            if (split) {
+                /* the early launches, behind ev_small, beside the large blocks' chains; work counters of their own */
+                cz_batch_args e = a;
+                e.early = 1u;
+                e.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 12);
+                if (use_wx) {                                           /* (first: its workgroups need whole CUs) */
+                    e.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 8);
+                    CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_small, 0));
+                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(c->num_cu), dim3(WX_THREADS), WX_LDS_BYTES, c->stream2, e);
+                    CZ_HIP(c, hipGetLastError());
+                    CZ_HIP(c, hipEventRecord(c->ev_w1, c->stream2));
+                }
+                CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_small, 0));
+                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream3, e);
+                CZ_HIP(c, hipGetLastError());
+                CZ_HIP(c, hipEventRecord(c->ev_e1, c->stream3));
+                a.early = 2u;
+            }
+            hipStream_t sx = split ? c->stream4 : c->stream2;           /* where cz_execute_frames_kernel's later launch goes when cz_wexec_kernel runs beside it */
             if (use_wx) {
                 /* Two kernels execute the sequences side by side and share the frames (each claims a frame before it starts on it):
                    cz_wexec_kernel — a workgroup of 16 waves per frame, the block in hand in an LDS window: bound by instruction
@@ -576,17 +648,17 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                    gets its CUs.  (If it does not, it finds every frame claimed when it starts: nothing is lost but the overlap.) */
                 int wgrid = c->wexec_cus > 0 ? c->wexec_cus : c->num_cu / 2;
                 if (wgrid > c->num_cu) wgrid = c->num_cu;
-                a.wx_leave = (uint32_t)(wgrid * c->wexec_leave_per_cu); a.wx_force = c->wexec_force;
+                a.wx_leave = (uint32_t)(wgrid * c->wexec_leave_per_cu);
                 hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
                 CZ_HIP(c, hipGetLastError());
                 CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
                 c->timed_wx = true;
-                CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_lit, 0));
-                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a);
-                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a);   /* (only one of the two builds does anything) */
+                CZ_HIP(c, hipStreamWaitEvent(sx, c->ev_lit, 0));
+                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);
+                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
-                CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
-                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                CZ_HIP(c, hipEventRecord(split ? c->ev_x4 : c->ev_join, sx));
+                CZ_HIP(c, hipStreamWaitEvent(c->stream, split ? c->ev_x4 : c->ev_join, 0));
             } else {
                 /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of its
                    own); it lists every frame it cannot do for cz_decode_frames_kernel */
@@ -594,10 +666,14 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
             }
+            if (split) {                                                /* the early launches may outlast these */
+                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_e1, 0));
+                if (use_wx) CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_w1, 0));
+            }
             CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
             c->timed_exec = true;
         }
-    } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; c->timed_wx = false; }
+    } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; c->timed_wx = false; c->timed_small = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
     hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_MAIN_DYN_LDS, c->stream, a);

@@ -78,6 +78,22 @@ __device__ static inline int cz_wx_big_only(const cz_batch_args& a) {
     const uint32_t nbig = a.scan_ctl[210];
     return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && nbig != 0u && a.n >= CZ_WX_BIG_MIN_FRAMES && (uint64_t)nbig * CZ_WX_BIG_SHARE <= a.n && cz_exec_variant(a) == 4u;
 }
+/* Agent-scope hand-off between kernels that run at the same time (the large blocks' chains -> cz_wexec_kernel's early launch).
+   Producer: its stores, s_waitcnt vmcnt(0), CZ_RELEASE_AGENT (writes the XCD's L2 back; the explicit wait after it is not
+   optional: the compiler drops its own when the scoreboard looks empty), then the flag with CZ_ST_AGENT.  Consumer: polls the flag
+   with CZ_LD_AGENT (bypasses its CU's L1), then CZ_ACQUIRE_AGENT (invalidates that L1; waits for it), a workgroup barrier for the
+   other waves, then plain loads. */
+#ifdef CZ_EMU
+#define CZ_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define CZ_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define CZ_ST_AGENT(p, v) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+#define CZ_LD_AGENT(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#else
+#define CZ_RELEASE_AGENT() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define CZ_ACQUIRE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define CZ_ST_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define CZ_LD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
 /* Hands frame f to cz_decode_frames_kernel (fallback_list).  Several kernels may hand the same frame back — a huff0 kernel that
    met something irregular in one of its sections, the execute kernel that then finds the frame without literals, cz_wexec_kernel
    that still has it on its list — so the entry is made by whoever sets CZ_PRE_LISTED first: a frame is listed ONCE, the list never
@@ -1994,7 +2010,11 @@ __device__ static __attribute__((noinline)) int cz_sequences_rec_fast(CzExecCtx&
     uint32_t P = cz_uni((uint32_t)xref.produced), lit_used = cz_uni(xref.lit_used);
     uint32_t h0 = cz_uni(sh.hist[0]), h1 = cz_uni(sh.hist[1]), h2 = cz_uni(sh.hist[2]);
     uint8_t* const ob = sh.a.t4.obuf;
+#if defined(CZ_EXP_NT_REC) && defined(__HIP_DEVICE_COMPILE__)
+    auto load_rec = [&](uint32_t first) -> uint64_t { const uint32_t i = first + (uint32_t)LANE; return __builtin_nontemporal_load(&rec[i < nseq ? i : nseq - 1]); };   /* (diagnostic: records are read once — keep them out of the caches' way) */
+#else
     auto load_rec = [&](uint32_t first) -> uint64_t { const uint32_t i = first + (uint32_t)LANE; return rec[i < nseq ? i : nseq - 1]; };   /* coalesced 8-byte loads */
+#endif
     uint32_t done = cz_uni(first_);
     uint64_t r1 = load_rec(done), r2 = load_rec(done + 64), r3 = load_rec(done + 128);
     for (; done < nseq; done += 64) {
@@ -2514,9 +2534,15 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
     if (LANE == 0) for (int i = 0; i < CZ_P_COUNT; i++) sh.prof[i] = 0;
 #endif
     if (cz_uni(a.scan_ctl[204]) == 0) return;                           /* every frame is CZ_PRE_DONE: nothing to walk (a shared work counter serves ~90 pulls per microsecond) */
-    if (::cz_exec_variant(a) != CZ_EXEC_WAVES) return;                  /* the build with the other register budget runs this batch */
+    /* The EARLY launch (args.early == 1; the 4-waves build) runs beside the launch of the large blocks' chains, behind the small
+       blocks' chains and the literal kernels: it takes exactly the frames cz_scan_kernel marked CZ_PRE_EARLY — no large block,
+       so all of their pre-pass is behind a kernel boundary.  Later launches of such a batch (args.early == 2) may still find it
+       at work: every frame is claimed with an atomic OR before it is executed. */
+    const int early = a.early == 1u;
+    if (early && cz_uni(a.scan_ctl[211]) == 0) return;
+    if (!early && ::cz_exec_variant(a) != CZ_EXEC_WAVES) return;        /* the build with the other register budget runs this batch */
     const uint32_t total = a.n;
-    const int wx_on = ::cz_wx_side_by_side(a), wx_big = ::cz_wx_big_only(a);
+    const int wx_on = !early && ::cz_wx_side_by_side(a), wx_big = !early && ::cz_wx_big_only(a);
     cz_init_llml();
     for (;;) {
         __syncthreads();
@@ -2532,6 +2558,17 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
         const uint32_t pre = cz_uni(a.frame_pre[f]);
         if (((pre & CZ_PRE_DONE) && lfirst != 0) || (pre & (CZ_PRE_WXDONE | CZ_PRE_CLAIMED | CZ_PRE_LISTED))) continue;   /* done by the pre-pass kernels / the other execute kernel's / handed back already */
         if (wx_big && (pre & CZ_PRE_WXBIG)) continue;                   /* cz_wexec_kernel's */
+        if (early && !(pre & CZ_PRE_EARLY)) continue;                   /* waits for the large blocks' chains: the later launches */
+        if (early || (a.early == 2u && !(wx_on && (pre & CZ_PRE_WXLIST)))) {
+            __syncthreads();
+            if (LANE == 0) {
+                const uint32_t got = atomicOr(&a.frame_pre[f], CZ_PRE_CLAIMED);
+                if (!(got & CZ_PRE_CLAIMED) && (got & CZ_PRE_WXLIST)) atomicAdd(&a.scan_ctl[208], 1u);   /* (listed frames claimed so far: see wx_leave) */
+                sh.frame_idx = got;
+            }
+            __syncthreads();
+            if (cz_uni(sh.frame_idx) & CZ_PRE_CLAIMED) continue;        /* the other launch has it */
+        }
         if (wx_on && (pre & CZ_PRE_WXLIST)) {
             /* cz_wexec_kernel, which runs beside this kernel, may take this frame: whoever claims it first does it.  The last
                wx_leave listed frames are left to that kernel: a frame started here now would still be running on its one wave

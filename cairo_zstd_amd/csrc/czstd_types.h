@@ -73,7 +73,18 @@ typedef struct cz_blk_desc {
                                   [205] waves of cz_chain_kernel that have finished (cz_huf1_kernel stops when all have),
                                   [206] frames listed for cz_wexec_kernel (wx_list), [207] of those, frames it did not finish,
                                   [208] listed frames claimed so far (by either execute kernel), [209] frames cz_wexec_kernel finished,
-                                  [210] listed frames of CZ_WX_BIG_UNITS and more (the first CZ_WX_BIG_MAX of them carry CZ_PRE_WXBIG) */
+                                  [210] listed frames of CZ_WX_BIG_UNITS and more (the first CZ_WX_BIG_MAX of them carry CZ_PRE_WXBIG),
+                                  [211] frames marked CZ_PRE_EARLY, [212] work counter of the small-block launch of cz_chain_kernel (args.chain_part 2) */
+/* The chain pre-pass runs as TWO launches of cz_chain_kernel (args.chain_part): part 1 the LARGE blocks — CZ_BIG_BLOCK_SEQS sequences and
+   more: the head of the block list, which is sorted by size class — part 2 all others.  A batch is as long as its longest chain
+   (sequences x ~95 ns), and on ragged batches that is ONE block: with the small blocks in a launch of their own, everything that
+   does not depend on a large block is ready at that launch's end, and the execute stage starts on it while the large chains
+   still run.  Part 1 publishes every block it finishes (header word 3: 1 done, 2 given up; agent-scope release), so that
+   cz_wexec_kernel's early launch — the batch's large frames, a workgroup each — can execute a frame block by block behind its chains. */
+#ifndef CZ_BIG_BLOCK_CLASS
+#define CZ_BIG_BLOCK_CLASS 13u            /* size class (bit length of the sequence count) from which a block is large */
+#endif
+#define CZ_BIG_BLOCK_SEQS (1u << (CZ_BIG_BLOCK_CLASS - 1u))   /* 4 096 */
 /* cz_wexec_kernel (czstd_wexec.hip): a workgroup per frame, the frame's window in LDS */
 #define CZ_WX_RING_LOG 17u
 #define CZ_WX_RING (1u << CZ_WX_RING_LOG)   /* frames of at most this many decoded bytes (out_cap) */
@@ -108,6 +119,9 @@ typedef struct cz_copy_seg {
 } cz_copy_seg;
 #define CZ_PRE_REGULAR 0x80000000u   /* frame_pre[f]: the scan walked the frame to its end and listed all of it; low bits: leading blocks done by the pre-pass kernels */
 #define CZ_PRE_DONE    0x40000000u   /* ... and ALL its blocks are done by them: the scan also wrote the frame's result record (no content checksum to verify) */
+#define CZ_PRE_EARLY   0x20000000u   /* every block with sequences of the frame is SMALL (below CZ_BIG_BLOCK_SEQS) and the frame is not one of the batch's large ones: its
+                                        pre-pass is complete when the small-block chain launch and the literal kernels are (a kernel boundary), long before the
+                                        launch that runs the large blocks' chains ends — the early execute launch takes it (cz_execute_frames_kernel, args.early) */
 #define CZ_PRE_WXDONE  0x10000000u   /* cz_wexec_kernel finished the frame (result record written): cz_execute_frames_kernel skips it */
 #define CZ_PRE_WXLIST  0x08000000u   /* cz_scan_kernel listed the frame for cz_wexec_kernel */
 #define CZ_PRE_CLAIMED 0x04000000u   /* cz_wexec_kernel and cz_execute_frames_kernel run side by side and share the frames: whichever sets this bit first does the frame */
@@ -152,6 +166,10 @@ typedef struct cz_batch_args {
     uint32_t debug_flags;                     /* CZ_DEBUG_* (cz_context_set_debug_flags): test knobs, 0 in normal use */
     uint32_t exec_variant_force;              /* 0: cz_exec_variant decides between the two register budgets of cz_execute_frames_kernel; 4 / 8: that one */
     uint32_t wx_force;                        /* 0: cz_wx_side_by_side decides from the batch's offset codes; 1: on; 2: off (A/B runs) */
+    uint32_t chain_part;                      /* cz_chain_kernel: 0 every listed block; 1 the large ones (and it publishes each block it finishes); 2 the others */
+    uint32_t early;                           /* execute kernels: 1 = the EARLY launch, beside the large blocks' chains (cz_execute_frames_kernel: the CZ_PRE_EARLY frames;
+                                                 cz_wexec_kernel: the batch's large frames, each block behind its chain's flag); 2 = a later launch of a batch that had early ones
+                                                 (every frame is claimed with an atomic before it is executed) */
     uint32_t wx_leave;                        /* cz_execute_frames_kernel leaves the last wx_leave listed frames to cz_wexec_kernel (a frame takes one wave of the former far longer than a workgroup of the latter) */
 } cz_batch_args;
 

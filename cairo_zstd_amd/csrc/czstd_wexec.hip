@@ -81,8 +81,10 @@
  * wave is a hung GPU.  The emulator's limit is small, so that the test that forces it (CZ_DEBUG_WX_POISON) runs in seconds. */
 #ifdef CZ_EMU
 #define WX_SPIN_LIMIT 3000u
+#define WX_CHAIN_WAIT_POLLS 2000u
 #else
 #define WX_SPIN_LIMIT (1u << 20)
+#define WX_CHAIN_WAIT_POLLS (1u << 15)      /* x >= 4 096 clocks of s_sleep: >= 50 ms for the chain of ONE block (131 072 sequences take 12 ms) */
 #endif
 
 /* diagnostic build only (-DCZ_PROFILE): per-wave s_memtime sums per phase, added to args.prof[40..49] when the kernel ends */
@@ -660,6 +662,23 @@ __device__ static int wx_slow_chunk(WxCtl& ctl, uint32_t* tab, cz_gptr out, cz_g
     return 1;
 }
 
+/* The early launch, at a large block: waits until cz_chain_kernel's launch of the large blocks has published the block (header word 3:
+   1 done, 2 given up), then makes this CU see what that kernel wrote (the caller's workgroup barrier lets the other waves go on).
+   The wait is bounded like every other wait of this kernel: past it the frame goes to cz_decode_frames_kernel.  One thread calls it. */
+__device__ static inline int wx_wait_chain(const cz_batch_args& a, uint64_t hdr) {
+    uint32_t polls = 0; uint64_t v;
+    while ((v = CZ_LD_AGENT(&a.chain_arena[hdr + 3])) == 0) {
+        if (++polls > WX_CHAIN_WAIT_POLLS) return 0;
+#ifdef CZ_EMU
+        sched_yield();
+#else
+        __builtin_amdgcn_s_sleep(64);
+#endif
+    }
+    CZ_ACQUIRE_AGENT();
+    return v == 1;
+}
+
 /* One workgroup per frame; frames from the list cz_scan_kernel made (a.wx_list, scan_ctl[206] entries). */
 extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_batch_args a) {
     uint8_t* const ring = (uint8_t*)cz_dyn_lds;
@@ -667,7 +686,13 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6, wave = cz_uni(tid >> 6);
     const uint32_t nlist = cz_uni(a.scan_ctl[206]);
     const int big_only = cz_wx_big_only(a);                             /* near-offset batch: only its large frames (CZ_PRE_WXBIG), and all of those */
-    if (nlist == 0 || !(cz_wx_side_by_side(a) || big_only)) return;
+    /* The EARLY launch (args.early == 1) starts behind the small blocks' chains and the literal kernels, while the launch of the large
+       blocks' chains still runs: it takes the batch's large frames (a batch arranged that way only) and executes each block by
+       block, waiting for a large block's chain at the block (wx_wait_chain).  What it decides from — the sums cz_chain_kernel
+       takes from the code tables — may still be growing: whatever it and the later launch decide, a frame is executed by whoever
+       claims it. */
+    const int early = a.early == 1u;
+    if (nlist == 0 || !((!early && cz_wx_side_by_side(a)) || big_only)) return;
     unsigned long long wxp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CZ_PROFILE
     unsigned long long wxt_ = 0;
@@ -740,6 +765,7 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
                             }
                         }
                         ctl.lit_lo = (uint32_t)lp; ctl.lit_hi = (uint32_t)(lp >> 32); ctl.lit_rle = rle; ctl.lit_byte = byte; ctl.lit_len = b.regen;
+                        if (go == 1 && b.nseq && chain_cursor && early && cz_hbs(b.nseq) >= CZ_BIG_BLOCK_CLASS && !wx_wait_chain(a, chain_cursor)) go = 2;
                         if (go == 1 && b.nseq) {
                             if (!chain_cursor) go = 2;
                             else {

@@ -210,6 +210,15 @@ int cz_context_last_sequence_stats(cz_context* ctx, uint64_t* near_offsets, uint
 /* Diagnostics of the most recent batch launch (synchronises): frames listed for cz_wexec_kernel, frames it finished, frames it
  * handed on to cz_decode_frames_kernel. */
 int cz_context_last_wexec_counts(cz_context* ctx, size_t* listed, size_t* finished, size_t* given_up);
+/* The chain pre-pass of a batch is two launches of cz_chain_kernel — the LARGE blocks (4 096 sequences and more: a batch lasts as
+ * long as its longest chain, sequence_section_decoder.cairo:223-286) on one stream, all others on another — and the execute stage
+ * starts behind the second: cz_execute_frames_kernel on every frame without a large block, cz_wexec_kernel on the batch's large
+ * frames, block by block behind their chains (frames share nothing: src/frame_decoder.cairo:78-104).  on = 0: one chain launch,
+ * the execute stage behind all of it.  Default 0: measured in round 5, the arrangement does not pay yet (profiles/r5/NOTES.md): kept
+ * as an experiment, covered by the GPU suite. */
+int cz_context_set_early_execute(cz_context* ctx, int on);
+/* When the small blocks' chains and every literal of the most recent launch were done, in ms from its start (0: not such a launch). */
+int cz_context_last_small_ms(cz_context* ctx, float* ms);
 /* Diagnostics of the most recent batch launch (synchronises): entries on the fall-back list — frames the pre-pass and execute
  * kernels handed to cz_decode_frames_kernel, each listed once whoever handed it back.  The list has no analogue in the reference:
  * it is the device-side form of "decode this frame by the reference's own order of steps" (src/frame_decoder.cairo:156-222). */

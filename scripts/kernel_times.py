@@ -32,6 +32,8 @@ def child(kind, n):
         cz.lib().cz_context_set_exec_kernel(ctx._h, int(os.environ.get("CZ_EXEC", "1")))   # 0 off, 1 on, 4 / 8: that register budget whatever the batch looks like
         wxe = os.environ.get("CZ_WEXEC", "1").split(",")               # on[,cus[,leave_per_cu[,force]]]
         ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=int(wxe[3]) if len(wxe) > 3 else 0)
+    if os.environ.get("CZ_EARLY") is not None and hasattr(ctx, "set_early_execute"):
+        ctx.set_early_execute(os.environ["CZ_EARLY"] == "1")
     tot, ch, ex, lt, wx = [], [], [], [], []
     for it in range(5):
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
@@ -53,7 +55,7 @@ def child(kind, n):
                 nbad += 1
         ok = ok and nbad == 0
         print(f"oracle check: {nbad} of {n} frames differ", flush=True)
-    print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
+    print(f"{os.path.basename(os.environ.get('CAIRO_ZSTD_AMD_LIB', 'default')):40s} early={os.environ.get('CZ_EARLY', '-')} small done at {ctx.last_small_ms() if hasattr(ctx, 'last_small_ms') else 0:6.3f} ms  total {np.mean(tot[2:]):8.3f} ms  chain {np.mean(ch[2:]):8.3f} ms  "
           f"lit tail {np.mean(lt[2:]):6.3f} ms  wexec {np.mean(wx[2:]):8.3f} ms  exec {np.mean(ex[2:]):8.3f} ms  wexec listed/finished/handed on {ctx.last_wexec_counts()}  near/far/long {ctx.last_sequence_stats()}  execute grid {ctx.execute_grid() if hasattr(cz.lib(), 'cz_context_execute_grid') else '?'}  ok={ok}", flush=True)
     ctx.close()
 

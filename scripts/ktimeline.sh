@@ -3,7 +3,7 @@
 #   CAIRO_ZSTD_AMD_LIB=... [env for the library] scripts/ktimeline.sh <workload> <frames> <tag>
 set -o pipefail
 WL=${1:-full_4a}; N=${2:-10000}; TAG=${3:-$WL}
-O=gpurun_out/r3; mkdir -p $O
+O=gpurun_out/${KT_OUT:-r5}; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf $O/tlr_$TAG
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/tlr_$TAG -- python3 scripts/kernel_times.py --child $WL $N > $O/tlr_$TAG.log 2>&1 || { tail -5 $O/tlr_$TAG.log; exit 1; }
@@ -18,6 +18,6 @@ first = scans[-2] if len(scans) >= 2 else 0
 t0 = int(rows[first]["Start_Timestamp"])
 for r in rows[first:]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    print(f'{r["Kernel_Name"][:34]:34s} start {s/1e6:8.3f} ms  end {e/1e6:8.3f} ms  dur {(e-s)/1e6:8.3f} ms')
+    print(f'{r["Kernel_Name"][:34]:34s} q {r.get("Queue_Id", "?"):>3s} start {s/1e6:8.3f} ms  end {e/1e6:8.3f} ms  dur {(e-s)/1e6:8.3f} ms')
 PY
 rm -rf $O/tlr_$TAG

@@ -46,6 +46,24 @@
 #define I_SBCNT "s_bcnt1_i32_b64 s20, s[22:23]\n s_bcnt1_i32_b64 s21, s[22:23]\n s_bcnt1_i32_b64 s24, s[26:27]\n s_bcnt1_i32_b64 s25, s[26:27]\n s_bcnt1_i32_b64 s20, s[22:23]\n s_bcnt1_i32_b64 s21, s[22:23]\n s_bcnt1_i32_b64 s24, s[26:27]\n s_bcnt1_i32_b64 s25, s[26:27]\n"
 #define I_LDSW  "ds_write_b32 v109, v100\n ds_write_b32 v109, v101 offset:256\n ds_write_b32 v109, v102 offset:512\n ds_write_b32 v109, v103 offset:768\n ds_write_b32 v109, v104 offset:1024\n ds_write_b32 v109, v105 offset:1280\n ds_write_b32 v109, v106 offset:1536\n ds_write_b32 v109, v107 offset:1792\n s_waitcnt lgkmcnt(0)\n"
 #define I_LDSR64 "ds_read_b64 v[100:101], v110\n ds_read_b64 v[102:103], v110 offset:512\n ds_read_b64 v[104:105], v110 offset:1024\n ds_read_b64 v[106:107], v110 offset:1536\n ds_read_b64 v[100:101], v110 offset:2048\n ds_read_b64 v[102:103], v110 offset:2560\n ds_read_b64 v[104:105], v110 offset:3072\n ds_read_b64 v[106:107], v110 offset:3584\n s_waitcnt lgkmcnt(0)\n"
+#define I_OR    RR("v_or_b32", ", %[Y]")
+#define I_MAX   RR("v_max_u32", ", %[Y]")
+#define I_ADDS  RC("v_add_u32", "s22")
+#define I_ANDS  RC("v_and_b32", "s22")
+#define I_BFES  "v_bfe_u32 v100, v100, s22, 5\n v_bfe_u32 v101, v101, s22, 5\n v_bfe_u32 v102, v102, s22, 5\n v_bfe_u32 v103, v103, s22, 5\n v_bfe_u32 v104, v104, s22, 5\n v_bfe_u32 v105, v105, s22, 5\n v_bfe_u32 v106, v106, s22, 5\n v_bfe_u32 v107, v107, s22, 5\n"
+#define I_CNDS  RR("v_cndmask_b32_e64", ", %[Y], s[26:27]")
+#define I_CNDV4 "v_cmp_lt_u32 vcc, v100, %[Y]\n v_add_u32 v104, v104, %[Y]\n v_add_u32 v105, v105, %[Y]\n v_add_u32 v106, v106, %[Y]\n v_cndmask_b32 v101, v101, %[Y], vcc\n v_add_u32 v107, v107, %[Y]\n v_add_u32 v102, v102, %[Y]\n v_add_u32 v103, v103, %[Y]\n"
+#define I_CND2  "v_cmp_lt_u32 vcc, v100, %[Y]\n v_cndmask_b32 v101, v101, %[Y], vcc\n v_cndmask_b32 v102, v102, %[Y], vcc\n v_cndmask_b32 v103, v103, %[Y], vcc\n v_cmp_lt_u32 vcc, v104, %[Y]\n v_cndmask_b32 v105, v105, %[Y], vcc\n v_cndmask_b32 v106, v106, %[Y], vcc\n v_cndmask_b32 v107, v107, %[Y], vcc\n"
+#define I_CNDSM "s_mov_b64 vcc, s[26:27]\n v_cndmask_b32 v101, v101, %[Y], vcc\n s_mov_b64 vcc, s[22:23]\n v_cndmask_b32 v103, v103, %[Y], vcc\n s_mov_b64 vcc, s[26:27]\n v_cndmask_b32 v105, v105, %[Y], vcc\n s_mov_b64 vcc, s[22:23]\n v_cndmask_b32 v107, v107, %[Y], vcc\n"
+#define I_CMP64 "v_cmp_lt_u32_e64 s[20:21], v100, %[Y]\n v_cmp_lt_u32_e64 s[24:25], v101, %[Y]\n v_cmp_lt_u32_e64 s[20:21], v102, %[Y]\n v_cmp_lt_u32_e64 s[24:25], v103, %[Y]\n v_cmp_lt_u32_e64 s[20:21], v104, %[Y]\n v_cmp_lt_u32_e64 s[24:25], v105, %[Y]\n v_cmp_lt_u32_e64 s[20:21], v106, %[Y]\n v_cmp_lt_u32_e64 s[24:25], v107, %[Y]\n"
+#define I_RFL   "v_readfirstlane_b32 s20, v100\n v_readfirstlane_b32 s21, v101\n v_readfirstlane_b32 s22, v102\n v_readfirstlane_b32 s23, v103\n v_readfirstlane_b32 s24, v104\n v_readfirstlane_b32 s25, v105\n v_readfirstlane_b32 s20, v106\n v_readfirstlane_b32 s21, v107\n"
+#define I_ADDCO "v_add_co_u32 v100, vcc, v100, %[Y]\n v_add_co_u32 v101, vcc, v101, %[Y]\n v_add_co_u32 v102, vcc, v102, %[Y]\n v_add_co_u32 v103, vcc, v103, %[Y]\n v_add_co_u32 v104, vcc, v104, %[Y]\n v_add_co_u32 v105, vcc, v105, %[Y]\n v_add_co_u32 v106, vcc, v106, %[Y]\n v_add_co_u32 v107, vcc, v107, %[Y]\n"
+#define I_ADD64B "v_add_co_u32 v100, vcc, v100, %[Y]\n v_addc_co_u32 v101, vcc, v101, %[Z], vcc\n v_add_co_u32 v102, vcc, v102, %[Y]\n v_addc_co_u32 v103, vcc, v103, %[Z], vcc\n v_add_co_u32 v104, vcc, v104, %[Y]\n v_addc_co_u32 v105, vcc, v105, %[Z], vcc\n v_add_co_u32 v106, vcc, v106, %[Y]\n v_addc_co_u32 v107, vcc, v107, %[Z], vcc\n"
+#define I_LSHL64 "v_lshlrev_b64 v[100:101], 3, v[100:101]\n v_lshlrev_b64 v[102:103], 3, v[102:103]\n v_lshlrev_b64 v[104:105], 3, v[104:105]\n v_lshlrev_b64 v[106:107], 3, v[106:107]\n v_lshlrev_b64 v[100:101], 3, v[100:101]\n v_lshlrev_b64 v[102:103], 3, v[102:103]\n v_lshlrev_b64 v[104:105], 3, v[104:105]\n v_lshlrev_b64 v[106:107], 3, v[106:107]\n"
+#define I_BPERM "ds_bpermute_b32 v100, v109, v100\n ds_bpermute_b32 v101, v109, v101\n ds_bpermute_b32 v102, v109, v102\n ds_bpermute_b32 v103, v109, v103\n ds_bpermute_b32 v104, v109, v104\n ds_bpermute_b32 v105, v109, v105\n ds_bpermute_b32 v106, v109, v106\n ds_bpermute_b32 v107, v109, v107\n s_waitcnt lgkmcnt(0)\n"
+#define I_EXEC  "s_and_saveexec_b64 s[20:21], s[26:27]\n v_add_u32 v100, v100, %[Y]\n s_mov_b64 exec, s[20:21]\n v_add_u32 v101, v101, %[Y]\n s_and_saveexec_b64 s[20:21], s[26:27]\n v_add_u32 v102, v102, %[Y]\n s_mov_b64 exec, s[20:21]\n v_add_u32 v103, v103, %[Y]\n"
+#define I_MIX44 "v_bfe_u32 v100, v100, 1, 31\n s_add_u32 s20, s20, 3\n v_bfe_u32 v101, v101, 1, 31\n s_add_u32 s21, s21, 3\n v_bfe_u32 v102, v102, 1, 31\n s_add_u32 s22, s22, 3\n v_bfe_u32 v103, v103, 1, 31\n s_add_u32 s23, s23, 3\n"
+#define I_MIXFS "v_bfe_u32 v100, v100, 1, 31\n v_add_u32 v104, v104, %[Y]\n v_bfe_u32 v101, v101, 1, 31\n v_add_u32 v105, v105, %[Y]\n v_bfe_u32 v102, v102, 1, 31\n v_add_u32 v106, v106, %[Y]\n v_bfe_u32 v103, v103, 1, 31\n v_add_u32 v107, v107, %[Y]\n"
 // independent: eight registers round robin; dependent: one register
 #define I_ADD  "v_add_u32 v100, v100, %[Y]\n v_add_u32 v101, v101, %[Y]\n v_add_u32 v102, v102, %[Y]\n v_add_u32 v103, v103, %[Y]\n v_add_u32 v104, v104, %[Y]\n v_add_u32 v105, v105, %[Y]\n v_add_u32 v106, v106, %[Y]\n v_add_u32 v107, v107, %[Y]\n"
 #define D_ADD  "v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n v_add_u32 v100, v100, %[Y]\n"
@@ -68,7 +86,7 @@ __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t iters, unsig
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
     asm volatile("v_mov_b32 v100, %[X]\n v_mov_b32 v101, %[X]\n v_mov_b32 v102, %[X]\n v_mov_b32 v103, %[X]\n v_mov_b32 v104, %[X]\n v_mov_b32 v105, %[X]\n v_mov_b32 v106, %[X]\n v_mov_b32 v107, %[X]\n v_mov_b32 v108, %[Y]\n v_lshlrev_b32 v109, 2, %[X]\n v_lshlrev_b32 v110, 3, %[X]\n" \
                  "s_mov_b32 s20, 0\n s_mov_b32 s21, 0\n s_mov_b32 s22, 0\n s_mov_b32 s23, 0\n s_mov_b32 s24, 0\n s_mov_b32 s25, 0\n s_mov_b32 s26, 0\n s_mov_b32 s27, 0\n" \
-                 "s_mov_b32 s28, %[N]\n" \
+                 "s_mov_b32 s28, %[N]\n s_mov_b32 s26, 0x0f0f0f0f\n s_mov_b32 s27, -1\n s_mov_b32 s22, 5\n s_mov_b32 s23, 0x00ff00ff\n" \
                  "1:\n" R8(BODY) \
                  "s_sub_u32 s28, s28, 1\n s_cmp_lg_u32 s28, 0\n s_cbranch_scc1 1b\n" \
                  "v_add_u32 %[A], v100, v101\n v_add_u32 %[A], %[A], v102\n v_add_u32 %[A], %[A], v103\n v_add_u32 %[A], %[A], v104\n v_add_u32 %[A], %[A], v105\n v_add_u32 %[A], %[A], v106\n v_add_u32 %[A], %[A], v107\n v_add_u32 %[A], %[A], s20\n v_add_u32 %[A], %[A], s21\n" \
@@ -86,6 +104,9 @@ KERNEL(k_mix31, I_MIX31) KERNEL(k_rdl, I_RDL)     KERNEL(k_ldsr, I_LDSR)
 KERNEL(k_and, I_AND) KERNEL(k_xor, I_XOR) KERNEL(k_sub, I_SUB) KERNEL(k_min, I_MIN) KERNEL(k_mov, I_MOV) KERNEL(k_shl, I_SHL) KERNEL(k_shr, I_SHR) KERNEL(k_shlv, I_SHLV)
 KERNEL(k_ffbh, I_FFBH) KERNEL(k_cndm, I_CNDM) KERNEL(k_add64, I_ADD64) KERNEL(k_addk, I_ADDK) KERNEL(k_add3, I_ADD3) KERNEL(k_ladd, I_LADD) KERNEL(k_andor, I_ANDOR)
 KERNEL(k_align, I_ALIGN) KERNEL(k_bfi, I_BFI) KERNEL(k_mad24, I_MAD24) KERNEL(k_mul24, I_MUL24) KERNEL(k_mullo, I_MULLO) KERNEL(k_sdwa, I_SDWA) KERNEL(k_qperm, I_QPERM)
+KERNEL(k_or, I_OR) KERNEL(k_max, I_MAX) KERNEL(k_adds, I_ADDS) KERNEL(k_ands, I_ANDS) KERNEL(k_bfes, I_BFES) KERNEL(k_cnds, I_CNDS) KERNEL(k_cndv4, I_CNDV4) KERNEL(k_cnd2, I_CND2)
+KERNEL(k_cndsm, I_CNDSM) KERNEL(k_cmp64, I_CMP64) KERNEL(k_rfl, I_RFL) KERNEL(k_addco, I_ADDCO) KERNEL(k_add64b, I_ADD64B) KERNEL(k_lshl64, I_LSHL64) KERNEL(k_bperm, I_BPERM) KERNEL(k_exec, I_EXEC)
+KERNEL(k_mix44, I_MIX44) KERNEL(k_mixfs, I_MIXFS)
 KERNEL(k_cmps, I_CMPS) KERNEL(k_bcnt, I_BCNT) KERNEL(k_mbcnt, I_MBCNT) KERNEL(k_sand64, I_SAND64) KERNEL(k_sbcnt, I_SBCNT) KERNEL(k_ldsw, I_LDSW) KERNEL(k_ldsr64, I_LDSR64)
 
 typedef void (*kern_t)(uint32_t*, uint32_t, unsigned long long*);
@@ -107,6 +128,12 @@ int main(int argc, char** argv) {
         {"v_add3_u32 (VOP3)", k_add3, 64}, {"v_lshl_add_u32 (VOP3)", k_ladd, 64}, {"v_and_or_b32 (VOP3)", k_andor, 64}, {"v_alignbit_b32 (VOP3)", k_align, 64}, {"v_bfi_b32 (VOP3)", k_bfi, 64},
         {"v_mad_u32_u24 (VOP3)", k_mad24, 64}, {"v_mul_u32_u24 (VOP2)", k_mul24, 64}, {"v_mul_lo_u32 (VOP3)", k_mullo, 64}, {"v_add_u32_sdwa", k_sdwa, 64},
         {"v_add_u32_dpp quad_perm", k_qperm, 64}, {"v_cmp_lt_u32 vcc (VOPC)", k_cmps, 64}, {"v_bcnt_u32_b32 (VOP3)", k_bcnt, 64}, {"v_mbcnt_lo_u32_b32 (VOP3)", k_mbcnt, 64},
+        {"v_or_b32 (VOP2)", k_or, 64}, {"v_max_u32 (VOP2)", k_max, 64}, {"v_add_u32 with an SGPR operand", k_adds, 64}, {"v_and_b32 with an SGPR operand", k_ands, 64},
+        {"v_bfe_u32 with an SGPR operand", k_bfes, 64}, {"v_cndmask_b32_e64, mask in an SGPR pair", k_cnds, 64}, {"v_cmp, 3 v_add, v_cndmask, 3 v_add", k_cndv4, 64},
+        {"v_cmp + 3 v_cndmask on its vcc", k_cnd2, 64}, {"s_mov_b64 vcc + v_cndmask pairs", k_cndsm, 64}, {"v_cmp_lt_u32_e64 -> SGPR pair", k_cmp64, 64},
+        {"v_readfirstlane_b32", k_rfl, 64}, {"v_add_co_u32 (carry out to vcc)", k_addco, 64}, {"v_add_co_u32 + v_addc_co_u32 (64-bit add)", k_add64b, 64},
+        {"v_lshlrev_b64", k_lshl64, 64}, {"8 ds_bpermute_b32 + s_waitcnt", k_bperm, 72}, {"s_and_saveexec / v_add / s_mov exec / v_add", k_exec, 64},
+        {"v_bfe_u32 / s_add_u32 alternating", k_mix44, 64}, {"v_bfe_u32 / v_add_u32 alternating", k_mixfs, 64},
         {"s_and_b64", k_sand64, 64}, {"s_bcnt1_i32_b64", k_sbcnt, 64}, {"8 ds_write_b32 + s_waitcnt lgkmcnt(0)", k_ldsw, 72}, {"8 ds_read_b64 + s_waitcnt lgkmcnt(0)", k_ldsr64, 72}};
     const uint32_t iters = 20000;
     printf("%d CUs; 64 instructions x %u iterations per wave; every CU holds W workgroups of 4 waves (one per SIMD)\n", cus, iters);

@@ -55,7 +55,8 @@ static void* lane_main(void* p) {
     lane_arg* la = (lane_arg*)p;
     threadIdx.x = la->lane; blockIdx.x = la->block;
     emu_lane_done[la->lane] = 0;
-    if (la->which == 0) cz_chain_kernel(la->a); else if (la->which == 2 || la->which == 11) czx::cz_execute_frames_kernel(la->a);
+    if (la->which == 0 || la->which == 12) cz_chain_kernel(la->a); else if (la->which == 2 || la->which == 11 || la->which == 13) czx::cz_execute_frames_kernel(la->a);
+    else if (la->which == 14) cz_wexec_kernel(la->a);
     else if (la->which == 6) cz_dict_setup_kernel(la->dict_raw, la->dict_len, la->dict_state, la->dict_res);
     else if (la->which == 7) cz_huf_kernel(la->a);
     else if (la->which == 9) cz_huf1_kernel(la->a);
@@ -160,20 +161,29 @@ int main(int argc, char** argv) {
        "done" and takes every literals section; default: it sees it done at once and cz_huf_kernel takes them all */
     const int huf1_all = getenv("EMU_HUF1") && atoi(getenv("EMU_HUF1")) > 0;
     a.chain_grid = (uint32_t)grid;
-    int order[10] = {4, 5, 0, 9, 7, 8, 10, 2, 11, 1};                  /* 2 / 11: cz_execute_frames_kernel beside / behind cz_wexec_kernel (10) */
+    /* EMU_SPLIT=1: the chain pre-pass as two launches (0: the large blocks, published one by one; 12: the others) and the early launches
+       of cz_execute_frames_kernel (13) and cz_wexec_kernel (14) ahead of the later ones, as cz_context_set_early_execute(1) arranges them
+       on the device.  EMU_SPLIT=2: cz_wexec_kernel's early launch runs BEFORE the large blocks' chains, so every large block's flag
+       stays 0 until the bound of its wait: the frame goes to cz_decode_frames_kernel. */
+    const int emu_split = getenv("EMU_SPLIT") ? atoi(getenv("EMU_SPLIT")) : 0;
+    uint32_t early_exec_counter = 0, early_wx_counter = 0;
+    int order[14] = {4, 5, 0, 9, 7, 8, 10, 2, 11, 1, -1, -1, -1, -1};   /* 2 / 11: cz_execute_frames_kernel beside / behind cz_wexec_kernel (10) */
+    if (emu_split == 1) { const int o[14] = {4, 5, 0, 12, 9, 7, 8, 13, 14, 10, 2, 1, -1, -1}; for (int i = 0; i < 14; i++) order[i] = o[i]; }
+    if (emu_split == 2) { const int o[14] = {4, 5, 12, 9, 7, 8, 14, 0, 13, 10, 2, 1, -1, -1}; for (int i = 0; i < 14; i++) order[i] = o[i]; }
     /* EMU_EXEC_FIRST=1: cz_execute_frames_kernel ahead of cz_wexec_kernel — on the device the two run side by side, and which of them
        meets a frame first depends on timing; the emulator runs them one after the other, in either order */
     if (getenv("EMU_EXEC_FIRST") && atoi(getenv("EMU_EXEC_FIRST")) > 0) { order[6] = 2; order[7] = 10; }
-    for (int pi = arena ? 0 : 9; pi < 10; pi++) {
+    for (int pi = 0; pi < 14; pi++) {
         const int which = order[pi];
-        if ((which == 2 || which == 11) && !with_exec) continue;
-        if (which == 10 && wx_waves <= 0) continue;
+        if (which < 0 || (!arena && which != 1)) continue;
+        if ((which == 2 || which == 11 || which == 13) && !with_exec) continue;
+        if ((which == 10 || which == 14) && wx_waves <= 0) continue;
         if (which == 11) continue;
         if ((which == 7 || which == 8 || which == 9) && !lit_bytes) continue;
-        const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : (which == 10 ? 64 * wx_waves : 64));
+        const int nthreads = which == 7 ? CZH_THREADS : (which == 8 ? 256 : (which == 10 || which == 14 ? 64 * wx_waves : 64));
         blockDim.x = (unsigned)nthreads;
 
-        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 || which == 9 || which == 10 ? 1 : grid);
+        const int nblocks = which == 4 || which == 5 ? (int)((n + 63) / 64) : (which == 7 || which == 8 || which == 9 || which == 10 || which == 14 ? 1 : grid);
         emu_nthreads = nthreads; gridDim.x = (unsigned)nblocks;
         pthread_barrier_init(&emu_barrier, nullptr, (unsigned)nthreads);
         for (int b = 0; b < nblocks; b++) {
@@ -182,6 +192,13 @@ int main(int argc, char** argv) {
                 la[l].a = a; la[l].lane = (unsigned)l; la[l].block = (unsigned)b; la[l].which = which;
                 if (which == 4 || which == 5) la[l].a.scan_pass = (uint32_t)(which - 4);
                 if (which == 9 && huf1_all) la[l].a.chain_grid = 0x7FFFFFFFu;
+                if (emu_split) {
+                    if (which == 0) la[l].a.chain_part = 1u;
+                    if (which == 12) la[l].a.chain_part = 2u;
+                    if (which == 13) { la[l].a.early = 1u; la[l].a.exec_counter = &early_exec_counter; }
+                    if (which == 14) { la[l].a.early = 1u; la[l].a.wx_counter = &early_wx_counter; }
+                    if (which == 10 || which == 2) la[l].a.early = 2u;
+                }
                 pthread_create(&th[l], nullptr, lane_main, &la[l]);
             }
             for (int l = 0; l < nthreads; l++) pthread_join(th[l], nullptr);

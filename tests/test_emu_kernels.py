@@ -233,6 +233,35 @@ def test_emu_frames_handed_back_by_huf_kernel_are_listed_once_beside_wexec_kerne
         assert int(err.split("EMU_EXEC: ")[1].split()[0]) <= len(frames) - 12, err     # and they are on the fall-back list (once: the emulator checks)
 
 
+def test_emu_split_chain_prepass_and_early_execute_launches():
+    """cz_context_set_early_execute(1) under ASan/UBSan: the chain pre-pass as two launches (the emulator build calls a block of 256
+    sequences large), the large blocks of the batch's large frames published one by one; the early launch of cz_execute_frames_kernel on
+    the frames without a large block, the early launch of cz_wexec_kernel on the large frames, each large block behind its chain's flag;
+    then the later launches, which find those frames claimed.  EMU_SPLIT=2 runs cz_wexec_kernel's early launch BEFORE the large blocks'
+    chains: every wait for a flag runs into its bound and the frames go to cz_decode_frames_kernel."""
+    frames, caps = [], []
+    for first in (8265, 1750):
+        b = synth.generate("mix", 1, first_index=first, nthreads=1)
+        frames.append(b.frame(0))
+        caps.append(int(b.regen[0]) + 8)
+    b = synth.generate("mix", 30, first_index=0, nthreads=2)
+    keep = [i for i in range(b.n) if b.regen[i] < 30000][:6]
+    frames += [b.frame(i) for i in keep]
+    caps += [int(b.regen[i]) + 8 for i in keep]
+    for _, z, orig in corpus_pairs(max_orig=1500)[:4]:
+        frames.append(z)
+        caps.append(len(orig) + 16)
+    for split, want_wx in (("1", 2), ("2", 0)):
+        os.environ["EMU_SPLIT"] = split
+        try:
+            _run_and_compare(frames, caps, chain_bytes=16 << 20, lit_bytes=8 << 20, exec_kernel=True, wexec_waves=16, verify=False, wexec_auto=True)
+        finally:
+            del os.environ["EMU_SPLIT"]
+        err = emu_runner.run.last_stderr
+        done_wx = int(err.split("frames listed, ")[1].split()[0])
+        assert done_wx == want_wx, (split, done_wx, err)
+
+
 def test_emu_d2_weight_log_10_unsupported():
     """DESIGN.md D2, device side: CZ_E_UNSUPPORTED for a Huffman-weight FSE accuracy log above 9."""
     import os

@@ -650,6 +650,42 @@ def test_frames_handed_back_by_huf_kernel_are_listed_once(cz):
         c.close()
 
 
+def test_split_chain_prepass_and_early_execute_launches(cz):
+    """cz_context_set_early_execute(1): the chain pre-pass as two launches of cz_chain_kernel (blocks of 4 096 sequences and more, which
+    are published block by block with an agent-scope release; all others) and the execute stage started behind the second — the early
+    launch of cz_execute_frames_kernel on the frames without a large block, the early launch of cz_wexec_kernel on the batch's large
+    frames, each large block behind its chain's flag — with every frame claimed by whoever gets to it first.  Same bytes and statuses
+    as the oracle on a corpus-like batch large enough for the large-frames arrangement, config 4a / 4b frames, the reference corpus
+    and damaged frames; several repeats (the arrangement depends on timing)."""
+    from cairo_zstd_amd import synth
+    c = cz.Context(0)
+    c.set_chain_arena(768 << 20, min_sequences=0)
+    c.set_literal_arena(384 << 20)
+    c.set_early_execute(True)
+    try:
+        frames, caps = [], []
+        for kind, n in (("mix", 2300), ("full_4a", 24), ("full_4b", 6)):
+            bb = synth.generate(kind, n, first_index=1234)
+            frames += [bb.frame(i) for i in range(n)]
+            caps += [int(r) + 16 for r in bb.regen]
+        for name, z, orig in corpus_pairs():
+            frames.append(z)
+            caps.append(len(orig) + 32)
+        for idx, (name, z, orig) in enumerate(corpus_pairs(max_orig=20000)):
+            for m in _mutations(z, idx)[:4]:
+                frames.append(m)
+                caps.append(len(orig) * 2 + 4096)
+        refs = [oracle.decode_frame(fr, cap=cap) for fr, cap in zip(frames, caps)]
+        for rep in range(3):
+            got = cz.decode_batch_host(frames, caps, c)
+            bad = [(i, cz.status.name(r["status"]), cz.status.name(st)) for i, ((st, ref, _), (r, out)) in enumerate(zip(refs, got)) if st != int(r["status"]) or (st == 0 and out != ref)]
+            assert not bad, (rep, bad[:10])
+            assert c.last_small_ms() > 0.0
+            assert c.last_fallback_count() <= len(frames)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("auto", [False, True])
 def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
     """cz_wexec_kernel (a workgroup of 16 waves per frame, the block in hand in an LDS window, chunks of 64 sequences composed by a
@@ -696,7 +732,8 @@ def test_wexec_kernel_side_by_side_matches_oracle(cz, auto):
             # all others on cz_execute_frames_kernel
             assert 12 <= finished < 140 and handed == 0, (listed, finished, handed)
         else:
-            assert listed > 100 and finished > 50 and handed > 0, (listed, finished, handed)
+            # (the damaged frames are handed on by whichever execute kernel gets to them first: small ones usually by the early launch of cz_execute_frames_kernel)
+            assert listed > 100 and finished > 50 and (handed > 0 or c.last_fallback_count() > 0), (listed, finished, handed, c.last_fallback_count())
     finally:
         c.close()
 
