@@ -29,7 +29,9 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task description)
                 chain_latency_floor = how long cz_chain_kernel's slots need for this batch at the
                 measured minimum step latency (a property of its slot count, not of zstd);
                 frac_dominant_kernel = the same bytes / the longest stage of the step (chain kernel or execute stage);
-                traffic = PMC bytes from profiles/r4 when that file was measured on
+                issue_bound_ms = the VALU instructions of the step's kernels (SQ counters, profiles/r5/sq_<workload>.json) at the
+                measured issue rate of a SIMD (profiles/r5/microbench_issue.txt) over all SIMDs; frac_of_issue_bound = that / the step;
+                traffic = PMC bytes from profiles/r5 when that file was measured on
                 these very kernel sources (kernel_source_hash), else null
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on all host cores over the whole
                 batch, on one thread over a bounded sample, and libzstd on one thread and on all
@@ -50,6 +52,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# What a SIMD of gfx950 issues, measured (profiles/r5/microbench_issue.txt, scripts/micro/issue.hip): with two or more waves one
+# integer VALU instruction of the kinds these kernels are made of (bit-field ops, funnel shifts, DPP, selects, SGPR operands) per
+# 4.2 clocks — the 2-clock rate holds for runs of plain VOP1 / VOP2 adds and logic ops on VGPRs only —, a lone wave one instruction
+# of any kind per 6.0; SALU 4.2 per SIMD, beside the VALU stream; clock in those loops 2.36 GHz.
+ISSUE = {"clk_per_valu": 4.2, "clk_per_valu_plain_runs": 2.25, "clk_per_instruction_lone_wave": 6.0, "clk_per_salu": 4.2, "clock_ghz": 2.36, "simds": 1024,
+         "source": "profiles/r5/microbench_issue.txt"}
 
 WORKLOADS = {
     "raw_rle": "config2: single-block frames, 50% Raw 131072 B random / 50% RLE 131072 B",
@@ -553,14 +561,33 @@ def main():
             line["roofline"]["chain_latency_floor"] = {"sequences_per_block": nseq, "chain_slots": slots, "rounds": rounds, "min_step_ns": step_ns,
                                                        "floor_ms": rounds * nseq * step_ns * 1e-6,
                                                        "source": "profiles/r2/microbench_chain_step.txt (variant 6: the dependent table chase alone)"}
+        # The instruction-issue bound of the step: every VALU instruction its kernels execute (SQ_INSTS_VALU of a counter pass, stamped with
+        # the kernel sources) at the rate a SIMD issues them, spread over all 1 024 SIMDs — what the step would take if nothing ever
+        # waited for memory, for another wave, or for a kernel boundary.  The entropy configs are bound by this, not by HBM bytes.
+        sqf = os.path.join(ROOT, "profiles", "r5", f"sq_{args.workload}.json")
+        if os.path.exists(sqf) and world == 1:
+            q = json.load(open(sqf))
+            if q.get("kernel_source_hash") == _kernel_source_hash() and q.get("frames") == F:
+                valu, salu = q["step_totals"].get("SQ_INSTS_VALU", 0.0), q["step_totals"].get("SQ_INSTS_SALU", 0.0)
+                rate = ISSUE["simds"] * ISSUE["clock_ghz"] * 1e9 / ISSUE["clk_per_valu"]
+                ib = valu / rate * 1e3
+                line["roofline"]["issue_bound_ms"] = ib
+                line["roofline"]["frac_of_issue_bound"] = ib / k_ms
+                line["roofline"]["issue_bound"] = {"valu_instructions_per_step": valu, "salu_instructions_per_step": salu, "valu_per_second_chip": rate,
+                                                   "per_kernel_valu": {k: v.get("SQ_INSTS_VALU", 0.0) for k, v in q["per_kernel"].items() if v.get("SQ_INSTS_VALU", 0.0) >= 1e6},
+                                                   **ISSUE, "counters": f"profiles/r5/sq_{args.workload}.json",
+                                                   "note": "cz_chain_kernel runs one wave per SIMD (a chain step is a dependent instruction stream): its own floor is chain_latency_floor, and at 6.0 clocks per instruction its 31.5 instructions per step are the 93 ns it measures"}
+            else:
+                line["roofline"]["issue_bound_ms"] = None
+                line["roofline"]["issue_bound_note"] = "profiles/r5 SQ counter file is from other kernel sources or another batch size: not quoted"
         # HBM traffic from the PMC counters is collected in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
         # this same command and committed under profiles/ together with the hash of the kernel sources it was made on
-        pmc = os.path.join(ROOT, "profiles", "r4", f"pmc_hbm_traffic_{args.workload}.json")
+        pmc = os.path.join(ROOT, "profiles", "r5", f"pmc_hbm_traffic_{args.workload}.json")
         if os.path.exists(pmc) and world == 1 and F == 10000:
             t = json.load(open(pmc))
             if t.get("kernel_source_hash") == _kernel_source_hash() and bool(t.get("chain_prepass")) == bool(chain_prepass) and bool(t.get("exec_kernel")) == bool(args.exec_kernel) and bool(t.get("wexec_kernel", True)) == bool(args.wexec_kernel):
                 line["roofline"]["traffic"] = t["fetch_bytes_uncorrected"] + t["write_bytes"]
-                alt = os.path.join(ROOT, "profiles", "r4", f"pmc_hbm_traffic_{args.workload}_alt.json")
+                alt = os.path.join(ROOT, "profiles", "r5", f"pmc_hbm_traffic_{args.workload}_alt.json")
                 if os.path.exists(alt):
                     ta = json.load(open(alt))
                     if ta.get("kernel_source_hash") == _kernel_source_hash():
@@ -568,9 +595,9 @@ def main():
                         line["roofline"]["traffic_note"] = ("a counter pass runs a step's kernels one after the other: cz_wexec_kernel, first in line, then executes every frame it is listed "
                                                             "(traffic: records + literals in, output out); traffic_without_wexec_kernel is the same step with cz_execute_frames_kernel alone "
                                                             "(match sources from HBM).  Side by side, as timed, each kernel does its share of the frames: see roofline.exec_stage")
-                line["roofline"]["traffic_source"] = f"profiles/r4/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
+                line["roofline"]["traffic_source"] = f"profiles/r5/pmc_hbm_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources {t['kernel_source_hash']}; FETCH_SIZE uncorrected), bytes per step, all kernels of the step"
             else:
-                line["roofline"]["traffic_source"] = "profiles/r4 PMC file is from other kernel sources or launch options: not quoted"
+                line["roofline"]["traffic_source"] = "profiles/r5 PMC file is from other kernel sources or launch options: not quoted"
         if copy_ceiling is not None:
             line["roofline"]["empirical_copy_GBps"] = copy_ceiling      # torch device-to-device copy on this box, read+write
             line["roofline"]["frac_of_empirical_copy"] = achieved / copy_ceiling

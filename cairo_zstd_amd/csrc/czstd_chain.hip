@@ -378,6 +378,81 @@ __device__ static inline void czc_group_asm(CzcLane& c, const CzcRole& ro, CZ_GL
     c.S -= 512u;
 }
 
+/* Round 5: the same 32 steps with the field picked by two 64-bit shifts instead of a compare, two selects, a funnel shift and a
+ * bit-field extract — 29.5 instructions per step instead of 31.5, and a lone wave pays ~2.9 ns for every one of them
+ * (profiles/r5/NOTES.md section 1; scripts/micro/chain_step.hip variants 1 / 10: 74.0 -> 67.2 ns).
+ *   per lane p = num_bits << 8 | extra bits (v102); summed over the quad (v105): byte 0 = the sequence's extra bits, byte 1 = its state
+ *   bits; sh (v109, low 6 bits) = extra bits + state bits of the lanes before this one = where this lane's field begins, counted
+ *   from the cursor.  The 64 stream bits below the cursor {v128 = low, v129 = high} are shifted left by sh, the high word joins
+ *   E >> 22 in {v130, v131} and that pair is shifted left by num_bits: v133 = (v << num_bits) | field = next state (+ 512, the marker
+ *   of v).  64-bit operands must sit in even-aligned register pairs on gfx950: hence the two moves.  v_alignbit takes the low five
+ *   bits of the cursor itself as its shift: no phase register.  A sequence of more than 32 extra bits leaves garbage in the state
+ *   (still inside the table: v << num_bits | num_bits bits) and in the cursor; c.slow tells, and the group is redone wide.
+ *   Inside the block the state lives in v133; the operand S is read once (first record) and written at the end. */
+#define CZC_ASM2_HEAD(WIN) \
+    CZC_ASM_LGKM_E \
+    "v_ffbh_u32 v100, %[E]\n" \
+    "v_bfe_u32 v101, %[E], 16, 5\n" \
+    "v_lshl_or_b32 v102, v100, 8, v101\n" \
+    "v_lshrrev_b32 v131, 22, %[E]\n" \
+    "v_and_b32_dpp v106, v100, %[M1] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n" \
+    "v_and_b32_dpp v107, v100, %[M2] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp v105, v102, v102 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp v105, v102, v105 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add3_u32 v109, v106, v107, v105\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_alignbit_b32 " WIN ", %[W2], v125, %[U]\n" \
+    "v_alignbit_b32 v128, v125, v124, %[U]\n" \
+    "v_mov_b32 v129, " WIN "\n" \
+    "v_lshlrev_b64 v[128:129], v109, v[128:129]\n" \
+    "v_mov_b32 v130, v129\n" \
+    "v_lshlrev_b64 v[132:133], v100, v[130:131]\n" \
+    "v_lshl_add_u32 v117, v133, 1, %[TB]\n" \
+    "ds_read_u16_d16_hi %[E], v117\n"
+#define CZC_ASM2_TAIL(STORE, NEXTH) \
+    STORE \
+    "v_lshl_add_u32 v118, v133, %[SH], %[NK]\n" \
+    "v_dot4c_i32_i8_e32 %[U], 0xffff, v105\n" \
+    "v_max_u32_sdwa %[SLOW], %[SLOW], v105 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"   /* most extra bits of any step so far; also the spacer: v118 -> DPP two instructions, v_dot4c -> reader three, 16-byte store -> write of its data one */ \
+    "v_add_u32_dpp " NEXTH ", v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_add_u32_dpp " NEXTH ", v118, " NEXTH " quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n" \
+    "v_bfe_u32 v114, %[U], 5, 7\n" \
+    "v_lshl_add_u32 v115, v114, 2, %[RB]\n" \
+    CZC_ASM_RING01 \
+    "ds_read_b32 %[W2], v115 offset:8\n"
+#define CZC_ASM2_EVEN(OFF) CZC_ASM2_HEAD("v120") CZC_ASM2_TAIL("", "v123")
+#define CZC_ASM2_ODD(OFF) CZC_ASM2_HEAD("v122") CZC_ASM2_TAIL(CZC_ASM_STORE(OFF), "v121")
+#define CZC_ASM2_PAIR(A) CZC_ASM2_EVEN(A) CZC_ASM2_ODD(A)
+__device__ static inline void czc_group_asm2(CzcLane& c, const CzcRole& ro, CZ_GLOBAL uint64_t* rec) {
+    static_assert(CZC_STEPS == 32, "the asm block is unrolled for 32 steps");
+    const uint32_t tb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint16_t*)ro.tb;
+    const uint32_t rb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)ro.ringm8;
+    const uint32_t tbm = tb32 - 1024u, nk = 0u - (512u << ro.sh);
+    c.S += 512u;
+    asm volatile(
+        "v_mov_b32 v124, %[W0]\n"
+        "v_mov_b32 v125, %[W1]\n"
+        "v_mov_b32 v133, %[S]\n"
+        /* state word of the first record */
+        "v_lshl_add_u32 v118, %[S], %[SH], %[NK]\n"
+        "s_nop 1\n"
+        "v_add_u32_dpp v121, v118, v118 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n"
+        "v_add_u32_dpp v121, v118, v121 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n"
+        CZC_ASM2_PAIR(0) CZC_ASM2_PAIR(16) CZC_ASM2_PAIR(32) CZC_ASM2_PAIR(48) CZC_ASM2_PAIR(64) CZC_ASM2_PAIR(80) CZC_ASM2_PAIR(96) CZC_ASM2_PAIR(112)
+        CZC_ASM2_PAIR(128) CZC_ASM2_PAIR(144) CZC_ASM2_PAIR(160) CZC_ASM2_PAIR(176) CZC_ASM2_PAIR(192) CZC_ASM2_PAIR(208) CZC_ASM2_PAIR(224) CZC_ASM2_PAIR(240)
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_and_b32 %[PH], 31, %[U]\n"
+        "v_mov_b32 %[W0], v124\n"
+        "v_mov_b32 %[W1], v125\n"
+        "v_mov_b32 %[S], v133\n"
+        : [E] "+v"(c.E), [S] "+v"(c.S), [U] "+v"(c.u), [PH] "+v"(c.ph), [W0] "+v"(c.w0), [W1] "+v"(c.w1), [W2] "+v"(c.w2), [SLOW] "+v"(c.slow)
+        : [TB] "v"(tbm), [RB] "v"(rb32), [M1] "v"(ro.m1 ? 0xFFu : 0u), [M2] "v"(ro.m2 ? 0xFFu : 0u), [SH] "v"(ro.sh), [NK] "v"(nk), [RP] "v"(rec)
+        : "memory",
+          "v100", "v101", "v102", "v105", "v106", "v107", "v109", "v114", "v115", "v117", "v118", "v120", "v121", "v122", "v123", "v124", "v125",
+          "v128", "v129", "v130", "v131", "v132", "v133");
+    c.S -= 512u;
+}
+
 /* The same group for blocks that hold sequences of more than 32 extra bits (up to 16 + 16 + 31): FOUR ring words are kept
  * (v[124:127] = words -3 .. 0 at the cursor), the 32 bits behind the extra bits are picked from three word pairs instead of
  * two, and the record of a wide sequence carries its bit position (low word) and the CZC_REC_WIDE flag instead of the
@@ -1103,7 +1178,11 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 if (!__ballot(chain_live && wide)) {
                     const CzcLane sv = c;
                     c.slow = 0;
+#ifdef CZC_EXP_OLD_STEP
                     czc_group_asm(c, ro, rp);
+#else
+                    czc_group_asm2(c, ro, rp);
+#endif
                     const int hit = chain_live && ql < 3 && c.slow > 32;
                     if (__ballot(hit)) { wide |= (int)czc_q0((uint32_t)hit); c = sv; }   /* redo this group wide; the slots that met a wide sequence stay wide for their block */
                 }

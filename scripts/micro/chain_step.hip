@@ -56,17 +56,17 @@
 #endif
 #if VARIANT >= 9
 /* round 5: the step with the field picked by two 64-bit shifts (no compare, no selects, no phase register) */
-#define N1 "s_waitcnt lgkmcnt(3)\n" "v_ffbh_u32 v100, %[E]\n" "v_bfe_u32 v101, %[E], 16, 5\n" "v_lshl_or_b32 v102, v100, 8, v101\n" "v_lshrrev_b32 v129, 22, %[E]\n"
+#define N1 "s_waitcnt lgkmcnt(3)\n" "v_ffbh_u32 v100, %[E]\n" "v_bfe_u32 v101, %[E], 16, 5\n" "v_lshl_or_b32 v102, v100, 8, v101\n" "v_lshrrev_b32 v131, 22, %[E]\n"
 #define N_DPP \
     "v_add_u32_dpp v105, v102, v102 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n" \
     "v_and_b32_dpp v106, v100, %[M1] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n" \
     "v_and_b32_dpp v107, v100, %[M2] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" \
     "v_add_u32_dpp v105, v102, v105 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf\n"
 #define N2 "v_add3_u32 v109, v106, v107, v105\n" "s_waitcnt lgkmcnt(0)\n" \
-    "v_alignbit_b32 v128, %[W2], %[W1], %[U]\n" "v_alignbit_b32 v127, %[W1], %[W0], %[U]\n" \
-    "v_lshlrev_b64 v[127:128], v109, v[127:128]\n" "v_lshlrev_b64 v[130:131], v100, v[128:129]\n" \
-    "v_mov_b32 %[S], v131\n" "v_lshl_add_u32 v117, v131, 1, %[TB]\n" "ds_read_u16_d16_hi %[E], v117\n"
-#define N_WIN "v_mov_b32 v120, v128\n"
+    "v_alignbit_b32 v120, %[W2], %[W1], %[U]\n" "v_alignbit_b32 v128, %[W1], %[W0], %[U]\n" "v_mov_b32 v129, v120\n" \
+    "v_lshlrev_b64 v[128:129], v109, v[128:129]\n" "v_mov_b32 v130, v129\n" "v_lshlrev_b64 v[132:133], v100, v[130:131]\n" \
+    "v_mov_b32 %[S], v133\n" "v_lshl_add_u32 v117, v133, 1, %[TB]\n" "ds_read_u16_d16_hi %[E], v117\n"
+#define N_WIN ""
 #define N_DOT "v_dot4c_i32_i8_e32 %[U], 0xffff, v105\n"
 #define N_MAX "v_max_u32_sdwa %[SLOW], %[SLOW], v105 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n"
 #define N_ADDR "v_bfe_u32 v114, %[U], 5, 7\n" "v_lshl_add_u32 v115, v114, 2, %[RB]\n"
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64, 1) k(uint32_t* out, uint64_t* sink, uint32
             : [TB] "v"(tb - 1024u), [RB] "v"(rb), [M1] "v"(r ? 0xFFu : 0u), [M2] "v"(r == 2 ? 0xFFu : 0u), [SH] "v"(r * 9u), [NK] "v"(0u - (512u << (r * 9u))),
               [K64] "v"(r == 0 ? 0x40000040u : 0x40u), [XM] "s"(0x1F0000u), [RP] "v"(rp)
             : "memory", "vcc", "v100", "v101", "v102", "v103", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
-              "v116", "v117", "v118", "v120", "v121", "v122", "v123", "v127", "v128", "v129", "v130", "v131");
+              "v116", "v117", "v118", "v120", "v121", "v122", "v123", "v127", "v128", "v129", "v130", "v131", "v132", "v133");
         S = (S & 1023u) | 512u; U |= 0x8000u;                          // keep addresses in range
     }
     out[threadIdx.x + blockIdx.x * 64] = E + S + U + PH + W0 + SLOW;
