@@ -932,6 +932,13 @@ __device__ static inline __attribute__((always_inline)) int czc_parse_tables(cz_
     return 0;
 }
 
+/* The workgroup of cz_chain_kernel is ONE wave, and the LDS executes a wave's accesses in order: between the phases that hand LDS
+ * contents from some lanes to others (stage -> parse -> build, ring top-up -> ring words) nothing has to be waited for, the compiler
+ * only must not move the accesses.  __syncthreads() also waits for every global access in flight (its fence is s_waitcnt vmcnt(0)):
+ * at a ring top-up — one per four groups on config 4a — that was the wave's record stores of the last microsecond, 8.6 % of the
+ * kernel's wave time (profiles/r5/NOTES.md).  cz_wave_sync: wavefront-scope fences and a wave barrier (the CPU emulator: a real
+ * barrier of the wave's 64 threads). */
+#define CZC_SYNC() cz_wave_sync()
 extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(cz_batch_args a) {
     __shared__ CzChainShared cs;
     __builtin_amdgcn_s_setprio(3);                                      /* the launch lasts as long as its longest chain: its waves issue ahead of cz_huf1_kernel's beside them */
@@ -991,9 +998,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             {
                 const uintptr_t base = (uintptr_t)blk + sbody;
                 const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)blk), Ek = Sk + czc_q0(bsize);
-                __syncthreads();                                        /* the slot's ring (same LDS) is no longer read */
+                CZC_SYNC();                                        /* the slot's ring (same LDS) is no longer read */
                 if (czc_q0((uint32_t)got) && has_slot) for (uint32_t cc = ql; cc < 16; cc += CZC_LPS) *(uint4*)&sl.stage[16 * cc] = czc_load16(bk + 16 * cc, Sk, Ek);
-                __syncthreads();
+                CZC_SYNC();
             }
             CZC_PROF_ACC(8); CZC_PROF_CNT(13);
             /* tables (sequence_section_decoder.cairo:405-647), serial per owner lane; a Repeat mode reads the description of
@@ -1023,9 +1030,9 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 {
                     const uintptr_t base = (uintptr_t)dblk + dsbody;
                     const uintptr_t bk = (uintptr_t)czc_q0_64((uint64_t)base), Sk = (uintptr_t)czc_q0_64((uint64_t)(uintptr_t)dblk), Ek = Sk + czc_q0(dbsize);
-                    __syncthreads();
+                    CZC_SYNC();
                     if (czc_q0((uint32_t)go) && has_slot) for (uint32_t cc = ql; cc < 16; cc += CZC_LPS) *(uint4*)&sl.stage[16 * cc] = czc_load16(bk + 16 * cc, Sk, Ek);
-                    __syncthreads();
+                    CZC_SYNC();
                 }
                 if (go) { uint32_t dummy; bad = czc_parse_tables(dblk, dbsize, dsbody, dmodes, 1u << t, sl.stage, 256u, sl.probs, &binfo, rles, &dummy); }
             }
@@ -1061,7 +1068,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
             /* build the tables of the refilled slots, each by the whole wave, slot after slot: LL and ML first (the slot's OF
                table, always rewritten for a new block, is their scratch), then OF (scratch: the description bytes, now read) */
             {
-                __syncthreads();                                        /* descriptions read */
+                CZC_SYNC();                                        /* descriptions read */
                 int tbad = 0;
                 for (unsigned long long need = __ballot(owner && got); need; need &= need - 1) {
                     const int ol = cz_unii(__ffsll((long long)need) - 1);
@@ -1083,14 +1090,14 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                     }
                     if (sbad && LANE == ol) tbad = 1;
                 }
-                __syncthreads();
+                CZC_SYNC();
                 if (got && tbad) { got = 0; o_have = 0; a.frame_first[o_frame] = 0; if (o_pub) CZ_ST_AGENT(&a.chain_arena[o_hdr + 3], (uint64_t)2); }
                 if (got) for (int t = 0; t < 3; t++) if (rles[t] >= 0) {    /* RLE: a one-state table (num_bits 0, base 0) at state 0 (:437-446) */
                     uint16_t* table = t == 0 ? sl.t_ll : (t == 1 ? sl.t_of : sl.t_ml);
                     table[0] = CZC_E16(0u, 0u, t == 1 ? (uint32_t)rles[t] : (cs.llml[(t == 2 ? 40u : 0u) + (uint32_t)rles[t]] >> 24));
                     if ((o_mapflags >> t) & 1u) ((cz_gptr)(a.chain_arena + o_hdr + 4))[t == 0 ? 0 : (t == 2 ? 512 : 1024)] = (uint8_t)rles[t];
                 }
-                __syncthreads();
+                CZC_SYNC();
             }
             CZC_PROF_ACC(11);
             /* the bit ring of the new blocks: the top 256 bytes of the stream; from here on every lane of a quad holds its slot's values */
@@ -1107,7 +1114,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 czc_prefetch(pre, 1, hi, S, E);
                 czc_commit(sl, 1, hi, loaded_lo, pre);
             }
-            __syncthreads();
+            CZC_SYNC();
             if (qgot) czc_prefetch(pre, 1, loaded_lo, S, E);               /* the next 256 bytes: in registers long before they are needed */
             /* initial states (owner), handed to the lanes of the quad */
             int32_t u0 = 0; uint32_t st_ll = 0, st_of = 0, st_ml = 0;
@@ -1155,10 +1162,10 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, 1) cz_chain_kernel(c
                 intptr_t new_lo = chain_live ? ((curb - (intptr_t)(CZC_RING - 4) + 15) & ~(intptr_t)15) : loaded_lo;
                 if (new_lo > loaded_lo) new_lo = loaded_lo;
                 if (new_lo < loaded_lo - 256) new_lo = loaded_lo - 256;      /* czc_commit moves at most 16 pieces */
-                __syncthreads();
+                CZC_SYNC();
                 czc_commit(sl, chain_live, loaded_lo, new_lo, pre);
                 loaded_lo = new_lo;
-                __syncthreads();
+                CZC_SYNC();
                 czc_prefetch(pre, chain_live, loaded_lo, S, E);
                 if (chain_live) czc_ring_words(c, ro);                    /* the words under the cursor may just have arrived */
                 CZC_PROF_ACC(2); CZC_PROF_CNT(5);
