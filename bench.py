@@ -606,6 +606,22 @@ def main():
             line["with_gather_to_rank0"] = gather_leg
         if others:
             line["other_workloads"] = others
+        if world == 1 and not args.no_other_workloads and chain_prepass:
+            # two batches in flight: two contexts decode alternately without waiting for each other, in a process
+            # of its own (it needs GPU_MAX_HW_QUEUES=8 before the runtime starts: six streams on four hardware queues run one after
+            # the other).  A separate figure; `value` stays the one-batch-at-a-time rate.
+            import subprocess
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pipelined.py"), args.workload, str(F), "2"], capture_output=True, timeout=300,
+                                    env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+                js = [l[5:] for l in pr.stdout.decode().splitlines() if l.startswith("JSON ")]
+                line["pipelined"] = json.loads(js[-1]) if js else {"error": pr.stderr.decode()[-300:]}
+                if js:
+                    line["pipelined"]["what"] = ("two contexts (arenas, streams and outputs of their own) decode the same batch alternately, enqueue only; ms per batch in the steady state. "
+                                                 "On config 4a the second batch's kernels find no room beside cz_chain_kernel (135 KB of LDS per CU): nothing overlaps; on the corpus-like mix, "
+                                                 "whose pre-pass leaves most of the chip idle, 8.4 -> 6.9 ms (profiles/r5/pipelined.txt)")
+            except Exception as e:                                       # noqa: BLE001 (a diagnostic leg: never fail the bench line)
+                line["pipelined"] = {"error": repr(e)[:300]}
         if cksum_leg:
             line["with_content_checksum_verified_on_device"] = cksum_leg
         if world == 1 and not args.no_cpu_baseline:

@@ -18,7 +18,7 @@ from . import status
 from ._lib import (RESULT_CHECKSUM_COMPUTED, RESULT_CHECKSUM_MATCH, RESULT_DTYPE, RESULT_FINISHED, RESULT_HAS_CHECKSUM,
                    BlockHeader, FrameHeader, build, lib)
 
-DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1, DEBUG_WX_POISON = 1, 2, 4     # cz_context_set_debug_flags
+DEBUG_CHAIN_CPP_STEP, DEBUG_NO_HUF1, DEBUG_WX_POISON, DEBUG_EXEC_FIRST = 1, 2, 4, 8     # cz_context_set_debug_flags
 from .status import CzError
 
 __all__ = ["Context", "FrameDecoder", "BlockDecodingStrategy", "decode_batch_host", "read_frame_header",

@@ -31,6 +31,13 @@
 #include "czstd_chain.hip"
 #include "czstd_pre.hip"
 #include "czstd_wexec.hip"
+#ifdef CZ_EXP_PAD   /* diagnostic: shifts the code objects behind it by CZ_EXP_PAD x 256 bytes (does the layout of the kernels in the code object matter?) */
+extern "C" __global__ void cz_pad_kernel(uint32_t* p) {
+#pragma unroll
+    for (int i = 0; i < CZ_EXP_PAD * 32; i++) asm volatile("s_nop 0\n s_nop 0");
+    if (p) p[0] = 1;
+}
+#endif
 /* the same kernel source once more, without its decoders: cz_execute_frames_kernel (czstd_kernels.hip, CZ_EXEC_ONLY) */
 #define CZ_EXEC_ONLY 1
 namespace czx {
@@ -52,6 +59,9 @@ namespace czx8 {
 #undef CZ_EXEC_ONLY
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
+#ifndef CZ_WX_SPARE_WGS
+#define CZ_WX_SPARE_WGS 0       /* workgroups of cz_wexec_kernel beyond those that stay */
+#endif
 
 /* ------------------------------------------------------------------ context */
 /* Dictionary (src/decoding/dictionary.cairo:11-18): the raw bytes and the carried-state image decode_dict makes of them, both
@@ -412,6 +422,7 @@ CZ_EXPORT int cz_context_last_wexec_counts(cz_context* c, size_t* listed, size_t
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     uint32_t h[4] = {0, 0, 0, 0};
     CZ_HIP(c, hipMemcpy(h, c->scan_ctl + 206, sizeof h, hipMemcpyDeviceToHost));
+    if (getenv("CZ_SIDE_COUNTS")) { uint32_t g[4] = {0, 0, 0, 0}; (void)hipMemcpy(g, c->scan_ctl + 213, sizeof g, hipMemcpyDeviceToHost); fprintf(stderr, "side counts: wexec workgroups counted in %u, (early %u), execute waves that left %u, that waited and stayed %u\n", g[0], g[1], g[2], g[3]); }
     if (listed) *listed = h[0];
     if (given_up) *given_up = h[1];
     if (finished) *finished = h[3];
@@ -626,7 +637,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 e.early = 1u;
                 e.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 12);
                 if (use_wx) {                                           /* (first: its workgroups need whole CUs) */
-                    e.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 8);
+                    e.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 8); e.wx_cus = 0;
                     CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_small, 0));
                     hipLaunchKernelGGL(cz_wexec_kernel, dim3(c->num_cu), dim3(WX_THREADS), WX_LDS_BYTES, c->stream2, e);
                     CZ_HIP(c, hipGetLastError());
@@ -646,18 +657,31 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                    sources from HBM: bound by the rate of random reads, which does not need every CU — on the others.  The first is
                    launched on this stream, the second on a stream of its own behind an event: so the first is dispatched first and
                    gets its CUs.  (If it does not, it finds every frame claimed when it starts: nothing is lost but the overlap.) */
-                int wgrid = c->wexec_cus > 0 ? c->wexec_cus : c->num_cu / 2;
-                if (wgrid > c->num_cu) wgrid = c->num_cu;
-                a.wx_leave = (uint32_t)(wgrid * c->wexec_leave_per_cu);
-                hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
-                CZ_HIP(c, hipGetLastError());
-                CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
-                c->timed_wx = true;
+                /* (args.wx_cus workgroups of cz_wexec_kernel stay; while they are not all in place, cz_execute_frames_kernel's waves keep off the
+                   even CUs — cz_cu_side —, so the split does not depend on which kernel the dispatcher places first) */
+                const int wcus = c->wexec_cus > 0 ? (c->wexec_cus > c->num_cu ? c->num_cu : c->wexec_cus) : c->num_cu / 2;
+                const int wgrid = wcus + CZ_WX_SPARE_WGS;
+                a.wx_cus = (uint32_t)wcus;
+                a.wx_leave = a.wx_cus * (uint32_t)c->wexec_leave_per_cu;
+                const bool exec_first = (c->debug_flags & CZ_DEBUG_EXEC_FIRST) != 0;   /* test knob: the other submission order */
+                if (!exec_first) {
+                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
+                    CZ_HIP(c, hipGetLastError());
+                    CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
+                }
                 CZ_HIP(c, hipStreamWaitEvent(sx, c->ev_lit, 0));
                 hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);
                 hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
                 CZ_HIP(c, hipEventRecord(split ? c->ev_x4 : c->ev_join, sx));
+                if (exec_first) {
+                    CZ_HIP(c, hipEventRecord(c->ev_fork, sx));          /* (free by now: an event behind the other kernel's SUBMISSION is the best a host can do to put this one second) */
+                    CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_lit, 0));
+                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
+                    CZ_HIP(c, hipGetLastError());
+                    CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
+                }
+                c->timed_wx = true;
                 CZ_HIP(c, hipStreamWaitEvent(c->stream, split ? c->ev_x4 : c->ev_join, 0));
             } else {
                 /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of its

@@ -78,6 +78,32 @@ __device__ static inline int cz_wx_big_only(const cz_batch_args& a) {
     const uint32_t nbig = a.scan_ctl[210];
     return a.wx_list != nullptr && a.wx_force != 2u && !cz_wx_side_by_side(a) && nbig != 0u && a.n >= CZ_WX_BIG_MIN_FRAMES && (uint64_t)nbig * CZ_WX_BIG_SHARE <= a.n && cz_exec_variant(a) == 4u;
 }
+/* Side by side (far-offset batches), cz_wexec_kernel takes half of the CUs and cz_execute_frames_kernel the others.  A workgroup of
+   cz_wexec_kernel fills a CU (152 KB of LDS, 16 x 128 registers), so it can only ever start on a CU that holds no wave of the other
+   kernel: round 4 got that by launching it first and the other kernel behind an event — which HIP does not promise (dispatch order
+   is undefined); submitted second it found every CU held by persistent waves and did nothing.  Now cz_wexec_kernel's workgroups
+   count themselves in (scan_ctl[213]; args.wx_cus of them stay, the launch has more), and a wave of cz_execute_frames_kernel that finds
+   itself on an EVEN CU (s_getreg HW_REG_HW_ID, cu_id bit 0) waits up to ~30 us for them to be all in place and leaves if they are not —
+   its launch has twice the waves the other half of the chip holds.  Dispatched first (the usual case), cz_wexec_kernel has its CUs before
+   the first wave of the other kernel asks, nobody leaves, and the placement is the dispatcher's, which measured 0.1 ms faster on
+   config 4a than any split by id (profiles/r5/NOTES.md); dispatched second, it finds the even CUs free.  On this part every XCD has
+   4 shader engines x 8 active CUs with ids 0..8, 128 even and 128 odd (scripts/micro/census.hip).  1: even, 0: odd; the CPU emulator
+   runs the kernels one after the other and has no CUs: 2. */
+__device__ static inline uint32_t cz_cu_side() {
+#if defined(CZ_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+    return 2u;
+#else
+#ifndef CZ_CU_SIDE_RULE
+#define CZ_CU_SIDE_RULE 0
+#endif
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31u << 11) | (0u << 6) | 4u);    /* HW_REG_HW_ID (4): cu_id [11:8], se_id [15:13] */
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3u << 11) | (0u << 6) | 20u);   /* HW_REG_XCC_ID (20): [3:0] */
+    const uint32_t cu = (hw >> 8) & 15u, se = (hw >> 13) & 7u;
+    (void)xcc; (void)se; (void)cu;
+    return CZ_CU_SIDE_RULE == 0 ? (cu & 1u) ^ 1u : CZ_CU_SIDE_RULE == 1 ? (xcc & 1u) ^ 1u : CZ_CU_SIDE_RULE == 2 ? (xcc < 4u ? 1u : 0u)
+         : CZ_CU_SIDE_RULE == 3 ? (se & 1u) ^ 1u : ((cu >> 1) & 1u) ^ 1u;
+#endif
+}
 /* Agent-scope hand-off between kernels that run at the same time (the large blocks' chains -> cz_wexec_kernel's early launch).
    Producer: its stores, s_waitcnt vmcnt(0), CZ_RELEASE_AGENT (writes the XCD's L2 back; the explicit wait after it is not
    optional: the compiler drops its own when the scoreboard looks empty), then the flag with CZ_ST_AGENT.  Consumer: polls the flag
@@ -2543,6 +2569,17 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
     if (!early && ::cz_exec_variant(a) != CZ_EXEC_WAVES) return;        /* the build with the other register budget runs this batch */
     const uint32_t total = a.n;
     const int wx_on = !early && ::cz_wx_side_by_side(a), wx_big = !early && ::cz_wx_big_only(a);
+    /* side by side: cz_wexec_kernel needs whole CUs.  A wave that finds itself on an even CU gives that kernel's workgroups a few
+       microseconds to count themselves in (scan_ctl[213] of args.wx_cus: dispatched first, as usual, they are there and nobody
+       leaves); if they are not, this kernel was placed first and holds every CU: the waves on the even ones leave (cz_cu_side) */
+#ifndef CZ_EXP_NO_SIDE
+    if (wx_on && ::cz_cu_side() == 1u) {
+        uint32_t polls = 0;
+        while (*(volatile uint32_t*)&a.scan_ctl[213] < a.wx_cus && polls < 8u) { __builtin_amdgcn_s_sleep(127); polls++; }
+        if (*(volatile uint32_t*)&a.scan_ctl[213] < a.wx_cus) { if (LANE == 0) atomicAdd(&a.scan_ctl[215], 1u); return; }
+        if (polls && LANE == 0) atomicAdd(&a.scan_ctl[216], 1u);
+    }
+#endif
     cz_init_llml();
     for (;;) {
         __syncthreads();

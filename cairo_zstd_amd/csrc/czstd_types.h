@@ -74,7 +74,8 @@ typedef struct cz_blk_desc {
                                   [206] frames listed for cz_wexec_kernel (wx_list), [207] of those, frames it did not finish,
                                   [208] listed frames claimed so far (by either execute kernel), [209] frames cz_wexec_kernel finished,
                                   [210] listed frames of CZ_WX_BIG_UNITS and more (the first CZ_WX_BIG_MAX of them carry CZ_PRE_WXBIG),
-                                  [211] frames marked CZ_PRE_EARLY, [212] work counter of the small-block launch of cz_chain_kernel (args.chain_part 2) */
+                                  [211] frames marked CZ_PRE_EARLY, [212] work counter of the small-block launch of cz_chain_kernel (args.chain_part 2),
+                                  [213] workgroups of cz_wexec_kernel that stayed (at most args.wx_cus), [214] the same for its early launch */
 /* The chain pre-pass runs as TWO launches of cz_chain_kernel (args.chain_part): part 1 the LARGE blocks — CZ_BIG_BLOCK_SEQS sequences and
    more: the head of the block list, which is sorted by size class — part 2 all others.  A batch is as long as its longest chain
    (sequences x ~95 ns), and on ragged batches that is ONE block: with the small blocks in a launch of their own, everything that
@@ -171,6 +172,9 @@ typedef struct cz_batch_args {
                                                  cz_wexec_kernel: the batch's large frames, each block behind its chain's flag); 2 = a later launch of a batch that had early ones
                                                  (every frame is claimed with an atomic before it is executed) */
     uint32_t wx_leave;                        /* cz_execute_frames_kernel leaves the last wx_leave listed frames to cz_wexec_kernel (a frame takes one wave of the former far longer than a workgroup of the latter) */
+    uint32_t wx_cus;                          /* workgroups of cz_wexec_kernel that stay (a launch may have more: any beyond this many leave at once); cz_execute_frames_kernel's waves
+                                                 on even CUs wait for that many to be in place (cz_cu_side).  (Kept at the END of the struct: the offsets of the fields above
+                                                 decide how the compiler spills the execute kernels' scalar registers, and 0.1 ms of config 4a with them: profiles/r5/NOTES.md) */
 } cz_batch_args;
 
 #endif

@@ -693,6 +693,16 @@ extern "C" __global__ void __launch_bounds__(WX_THREADS, 1) cz_wexec_kernel(cz_b
        claims it. */
     const int early = a.early == 1u;
     if (nlist == 0 || !((!early && cz_wx_side_by_side(a)) || big_only)) return;
+#ifndef CZ_EXP_NO_WXCOUNT
+    {   /* the launch has a workgroup for every CU and more; args.wx_cus of them stay (half of the chip: profiles/r4 wexec_sweep) */
+        /* (the slot goes through a word of WxCtl: a static __shared__ variable would shift the dynamic LDS — the window — off its alignment: 0.12 ms on config 4a) */
+        if (tid == 0) ctl.fidx = atomicAdd(&a.scan_ctl[early ? 214 : 213], 1u);
+        __syncthreads();
+        const uint32_t wx_slot = cz_uni(ctl.fidx);
+        __syncthreads();
+        if (a.wx_cus && wx_slot >= a.wx_cus) return;
+    }
+#endif
     unsigned long long wxp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CZ_PROFILE
     unsigned long long wxt_ = 0;

@@ -235,6 +235,8 @@ int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
 #define CZ_DEBUG_NO_HUF1 2u
 #define CZ_DEBUG_WX_POISON 4u       /* cz_wexec_kernel: chunk 2 of every block never publishes its look-back entry, so every wave behind it waits until the
                                        bound of its polling loop (WX_SPIN_LIMIT) and the frame is handed to cz_decode_frames_kernel: the test of that bound */
+#define CZ_DEBUG_EXEC_FIRST 8u      /* side by side: cz_execute_frames_kernel is submitted AHEAD of cz_wexec_kernel (normally behind it): the two keep to their halves
+                                       of the CUs by the hardware's CU id, so the frames split the same way in either order — the test of that */
 int cz_context_set_debug_flags(cz_context* ctx, uint32_t flags);
 /* Copies the first `bytes` of the chain arena (headers, state -> code maps and per-sequence records of the most recent batch
  * launch, as cz_chain_kernel left them) to host memory and returns the arena units in use; synchronises.  For tests. */

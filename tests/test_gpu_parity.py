@@ -650,6 +650,35 @@ def test_frames_handed_back_by_huf_kernel_are_listed_once(cz):
         c.close()
 
 
+def test_side_by_side_split_does_not_depend_on_submission_order(cz):
+    """Side by side, cz_wexec_kernel and cz_execute_frames_kernel each keep to one half of the CUs by the hardware's CU id (cz_cu_side):
+    whichever kernel the host submits first, cz_wexec_kernel gets its CUs and finishes a comparable share of a far-offset batch
+    (round 4: submitted second it found every CU held by the other kernel's persistent waves and finished next to nothing).  Outputs
+    against the oracle in both orders."""
+    from cairo_zstd_amd import synth
+    b = synth.generate("full_4a", 3000, first_index=5)
+    frames, caps = [b.frame(i) for i in range(b.n)], [int(r) for r in b.regen]
+    refs = [oracle.decode_frame(frames[i], cap=caps[i]) for i in range(0, b.n, 100)]
+    share = []
+    for flags in (0, cz.DEBUG_EXEC_FIRST):
+        c = cz.Context(0)
+        try:
+            c.set_chain_arena(1024 << 20, min_sequences=0)
+            c.set_literal_arena(128 << 20)
+            c.set_debug_flags(flags)
+            for rep in range(3):
+                got = cz.decode_batch_host(frames, caps, c)
+            assert all(int(r["status"]) == 0 for r, _ in got)
+            for k, i in enumerate(range(0, b.n, 100)):
+                assert got[i][1] == refs[k][1], (flags, i)
+            listed, finished, handed = c.last_wexec_counts()
+            assert listed == b.n and handed == 0, (flags, listed, finished, handed)
+            share.append(finished)
+        finally:
+            c.close()
+    assert min(share) > 0.15 * b.n and max(share) < 0.6 * b.n and abs(share[0] - share[1]) < 0.15 * b.n, share
+
+
 def test_split_chain_prepass_and_early_execute_launches(cz):
     """cz_context_set_early_execute(1): the chain pre-pass as two launches of cz_chain_kernel (blocks of 4 096 sequences and more, which
     are published block by block with an agent-scope release; all others) and the execute stage started behind the second — the early
