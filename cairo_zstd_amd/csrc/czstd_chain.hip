@@ -775,7 +775,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS) cz_scan_kernel(cz_ba
         uint64_t total, incl = czs_scan64(lbytes, &total), wbase = 0;
         if (LANE == 0 && total) wbase = atomicAdd(a.lit_top, (unsigned long long)total);
         wbase = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(wbase >> 32), 0) << 32) | (uint32_t)__shfl((int)(uint32_t)wbase, 0);
-        if (lbytes) { lat = wbase + (incl - lbytes); if (lat + lbytes > a.lit_capacity) { lat = 0; placed = 0; } }   /* lit_top starts at 64: offset 0 = "no node" */
+        if (lbytes) { lat = 64ull + wbase + (incl - lbytes); if (lat + lbytes > a.lit_capacity) { lat = 0; placed = 0; } }   /* nodes start at offset 64 (lit_top counts from 0, like every word of the control block, which ONE memset clears per launch): offset 0 = "no node" */
     }
     if (!placed) { at = 0; lat = 0; }
     uint32_t base[20]; { uint32_t run = 0; for (int c = 19; c >= 0; c--) { base[c] = run; run += a.scan_ctl[c]; } }   /* larger classes first */

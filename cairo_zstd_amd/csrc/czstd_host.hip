@@ -59,6 +59,7 @@ namespace czx8 {
 #undef CZ_EXEC_ONLY
 
 #define CZ_EXPORT extern "C" __attribute__((visibility("default")))
+#define CZ_CTL_BLOCK_BYTES (192 + CZ_SCAN_CTL_WORDS * 4)
 #ifndef CZ_WX_SPARE_WGS
 #define CZ_WX_SPARE_WGS 0       /* workgroups of cz_wexec_kernel beyond those that stay */
 #endif
@@ -138,7 +139,9 @@ CZ_EXPORT int cz_context_create(cz_context** out, int device, void* stream) {
     if (stream) c->stream = (hipStream_t)stream;
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->stream = nullptr; delete c; return CZ_E_HIP; } c->own_stream = true; }
     /* the per-workgroup literal scratch (266 KB each) is allocated by the first launch, for the workgroups it uses */
-    if (hipMalloc((void**)&c->work_counter, 64) != hipSuccess ||
+    /* every counter the kernels of a launch share — work_counter (64 bytes), chain_top (64), lit_top (64), scan_ctl — in ONE block, cleared by
+       one memset per launch (four separate ones were four tiny kernels and their boundaries in front of every step) */
+    if (hipMalloc((void**)&c->work_counter, CZ_CTL_BLOCK_BYTES) != hipSuccess ||
         hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_mid) != hipSuccess || hipEventCreate(&c->ev_mid2) != hipSuccess ||
         hipEventCreate(&c->ev_stop) != hipSuccess) {
         cz_context_destroy(c); return CZ_E_HIP;
@@ -175,7 +178,6 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->d_prof) (void)hipFree(c->d_prof);
     if (c->chain_arena) (void)hipFree(c->chain_arena);
     if (c->lit_arena) (void)hipFree(c->lit_arena);
-    if (c->lit_top) (void)hipFree(c->lit_top);
     if (c->lit_first) (void)hipFree(c->lit_first);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -186,10 +188,8 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->frame_pre) (void)hipFree(c->frame_pre);
     if (c->ev_lit) (void)hipEventDestroy(c->ev_lit);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->chain_top) (void)hipFree(c->chain_top);
     if (c->frame_first) (void)hipFree(c->frame_first);
     if (c->blk_desc) (void)hipFree(c->blk_desc);
-    if (c->scan_ctl) (void)hipFree(c->scan_ctl);
     if (c->frame_order) (void)hipFree(c->frame_order);
     if (c->scan_wave) (void)hipFree(c->scan_wave);
     if (c->fallback_list) (void)hipFree(c->fallback_list);
@@ -257,7 +257,7 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (c->chain_arena) { (void)hipFree(c->chain_arena); c->chain_arena = nullptr; c->chain_capacity = 0; }
     if (!bytes) return CZ_OK;
     if (bytes < 4096) bytes = 4096;                                     /* header indices 0..63 are reserved (sink of the chain step) */
-    if (!c->chain_top) { CZ_HIP(c, hipMalloc((void**)&c->chain_top, 64)); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
+    if (!c->chain_top) { c->chain_top = (unsigned long long*)((uint8_t*)c->work_counter + 64); c->chain_counter = (uint32_t*)((uint8_t*)c->chain_top + 16); }
     if (!c->exec_grid) {
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, czx::cz_execute_frames_kernel, CZ_WG_THREADS, CZ_EXEC_DYN_LDS) != hipSuccess || occ <= 0) occ = 4;
@@ -271,7 +271,7 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (c->blk_desc) { (void)hipFree(c->blk_desc); c->blk_desc = nullptr; }
     c->blk_capacity = (uint32_t)(c->chain_capacity / (4 + CZ_CHAIN_MAP_WORDS + 1) + 4096);
     CZ_HIP(c, hipMalloc((void**)&c->blk_desc, (size_t)c->blk_capacity * sizeof(cz_blk_desc)));
-    if (!c->scan_ctl) CZ_HIP(c, hipMalloc((void**)&c->scan_ctl, CZ_SCAN_CTL_WORDS * 4));
+    if (!c->scan_ctl) c->scan_ctl = (uint32_t*)((uint8_t*)c->work_counter + 192);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cz_chain_kernel, CZ_WG_THREADS, 0) != hipSuccess || occ <= 0) occ = 2;
     c->chain_grid = c->num_cu * occ;
@@ -295,7 +295,7 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
     c->seg_capacity = 0;
     if (!bytes) return CZ_OK;
     if (bytes < 4096) bytes = 4096;
-    if (!c->lit_top) { CZ_HIP(c, hipMalloc((void**)&c->lit_top, 64)); c->lit_counter = (uint32_t*)((uint8_t*)c->lit_top + 16); }
+    if (!c->lit_top) { c->lit_top = (unsigned long long*)((uint8_t*)c->work_counter + 128); c->lit_counter = (uint32_t*)((uint8_t*)c->lit_top + 16); }
     if (!c->stream2) {
         CZ_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         CZ_HIP(c, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
@@ -481,7 +481,7 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         CZ_HIP(c, hipMalloc((void**)&c->lit_scratch, (size_t)slots * CZ_WG_SCRATCH_BYTES)); c->lit_slots = slots;
         a.lit_scratch = c->lit_scratch;
     }
-    CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
+    CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, c->chain_arena && !proto.tasks ? CZ_CTL_BLOCK_BYTES : 64, c->stream));   /* the whole control block */
     CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
     if (c->chain_arena && !a.tasks) {
@@ -503,7 +503,6 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             CZ_HIP(c, hipMalloc((void**)&c->wx_list, n * 4));
             c->frame_first_cap = n;
         }
-        CZ_HIP(c, hipMemsetAsync(c->chain_top, 0, 64, c->stream));
         a.chain_arena = c->chain_arena; a.chain_capacity = c->chain_capacity; a.chain_top = c->chain_top;
         a.frame_first = c->frame_first; a.chain_counter = c->chain_counter; a.chain_min_nseq = c->chain_min_nseq;
         const bool lit_pass = c->lit_arena != nullptr;
@@ -515,8 +514,6 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 c->frame_pre = nullptr;
                 CZ_HIP(c, hipMalloc((void**)&c->frame_pre, n * 4));
             }
-            static const unsigned long long top0[4] = {64, 0, 0, 0};    /* offset 0 = "no node" */
-            CZ_HIP(c, hipMemcpyAsync(c->lit_top, top0, 32, hipMemcpyHostToDevice, c->stream));
             a.lit_arena = c->lit_arena; a.lit_capacity = c->lit_capacity; a.lit_top = c->lit_top; a.lit_first = c->lit_first;
             a.lit_segs = c->lit_segs; a.lit_seg_capacity = c->seg_capacity; a.copy_segs = c->copy_segs; a.copy_seg_capacity = c->seg_capacity; a.frame_pre = c->frame_pre;
         }
@@ -533,7 +530,6 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         if (use_wx) { a.wx_list = c->wx_list; a.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 20); }
         /* pass A0: the block list (cz_scan_kernel, one lane per frame, two passes: count, place) */
         a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
-        CZ_HIP(c, hipMemsetAsync(c->scan_ctl, 0, CZ_SCAN_CTL_WORDS * 4, c->stream));
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
         a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);

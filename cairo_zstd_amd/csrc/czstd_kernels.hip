@@ -2572,7 +2572,7 @@ extern "C" __global__ void __launch_bounds__(CZ_WG_THREADS, CZ_EXEC_WAVES) CZ_EX
     /* side by side: cz_wexec_kernel needs whole CUs.  A wave that finds itself on an even CU gives that kernel's workgroups a few
        microseconds to count themselves in (scan_ctl[213] of args.wx_cus: dispatched first, as usual, they are there and nobody
        leaves); if they are not, this kernel was placed first and holds every CU: the waves on the even ones leave (cz_cu_side) */
-#ifndef CZ_EXP_NO_SIDE
+#if !defined(CZ_EXP_NO_SIDE) && !defined(CZ_EMU)                       /* (the emulator runs the kernels one after the other: no CUs to share) */
     if (wx_on && ::cz_cu_side() == 1u) {
         uint32_t polls = 0;
         while (*(volatile uint32_t*)&a.scan_ctl[213] < a.wx_cus && polls < 8u) { __builtin_amdgcn_s_sleep(127); polls++; }

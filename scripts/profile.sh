@@ -6,7 +6,7 @@
 #   outputs suffixed _alt (e.g. PMC_EXTRA=--no-wexec-kernel: under a counter pass the kernels of a step run one after the other, so
 #   cz_wexec_kernel, first in line, takes every frame it is listed; the alt pass shows cz_execute_frames_kernel's traffic).
 set -o pipefail
-R=${1:-r4}; shift
+R=${1:-r5}; shift
 WLS=${@:-full_4a huf_literals mix}
 O=gpurun_out/$R; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
     for (int w = 0; w < EMU_MAX_WAVES; w++) pthread_barrier_init(&emu_wbar[w], nullptr, 64);
     uint32_t exec_counter = 0; a.exec_counter = &exec_counter; a.exec_variant_force = 4;   /* (the emulator has one build of cz_execute_frames_kernel) */
     /* EMU_LIT=<bytes>: the literal / copy half of the pre-pass (cz_huf_kernel, cz_tile_kernel) with a literal arena of that many bytes */
-    unsigned long long lit_top[4] = {64, 0, 0, 0}; std::vector<uint64_t> lit_first(n ? n : 1, 0); uint8_t* lit_arena = nullptr;
+    unsigned long long lit_top[4] = {0, 0, 0, 0}; std::vector<uint64_t> lit_first(n ? n : 1, 0); uint8_t* lit_arena = nullptr;
     const size_t lit_bytes = arena && getenv("EMU_LIT") ? (size_t)atoll(getenv("EMU_LIT")) : 0;
     std::vector<cz_lit_seg> lit_segs; std::vector<cz_copy_seg> copy_segs; std::vector<uint32_t> frame_pre(n ? n : 1, 0);
     if (lit_bytes) {
