@@ -161,6 +161,14 @@ class Context:
         """Two chain launches (large blocks / all others) with the early execute launches behind the second, or one (default)."""
         lib().cz_context_set_early_execute(self._h, 1 if on else 0)
 
+    def set_graph_replay(self, on: bool):
+        """on: a launch that repeats the one before it is captured as a hipGraph and replayed from then on; off (default): never."""
+        lib().cz_context_set_graph_replay(self._h, 1 if on else 0)
+
+    def last_launch_was_replay(self) -> bool:
+        """Whether the last batch launch was the replay of a captured graph."""
+        return bool(lib().cz_context_last_launch_was_replay(self._h))
+
     def last_small_ms(self) -> float:
         """When the small blocks' chains and all literals of the last launch were done, ms from its start (0: not a split launch)."""
         ms = C.c_float(0)

@@ -109,6 +109,10 @@ def lib() -> C.CDLL:
     L.cz_context_last_sequence_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.cz_context_set_early_execute.restype = C.c_int
     L.cz_context_set_early_execute.argtypes = [vp, C.c_int]
+    L.cz_context_set_graph_replay.restype = C.c_int
+    L.cz_context_set_graph_replay.argtypes = [vp, C.c_int]
+    L.cz_context_last_launch_was_replay.restype = C.c_int
+    L.cz_context_last_launch_was_replay.argtypes = [vp]
     L.cz_context_last_small_ms.restype = C.c_int
     L.cz_context_last_small_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.cz_context_last_fallback_count.restype = C.c_int

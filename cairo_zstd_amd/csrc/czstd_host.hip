@@ -93,7 +93,7 @@ struct cz_context {
     int exec_grid = 0, exec8_grid = 0;
     uint32_t* fallback_list = nullptr;                                  /* n entries, allocated with frame_first */
     int last_grid = 0;
-    int last_hip_error = 0;
+    int last_hip_error = 0, last_hip_line = 0;
     /* staging for cz_decode_batch_host */
     void* d_stage = nullptr; size_t d_stage_bytes = 0;
     void* h_pin = nullptr; size_t h_pin_bytes = 0;                      /* pinned host staging of cz_decode_batch_multi's share */
@@ -113,9 +113,20 @@ struct cz_context {
     cz_lit_seg* lit_segs = nullptr; cz_copy_seg* copy_segs = nullptr; uint32_t seg_capacity = 0;   /* lists of the literal / copy pre-pass (cz_scan_kernel) */
     uint32_t* frame_pre = nullptr;                                      /* n entries, allocated with lit_first */
     uint32_t verify_checksum = 0;
+    /* A launch that repeats the one before it — same arguments, same context settings — is captured as a hipGraph and replayed
+       (cz_launch): one submission instead of ~35 stream operations per batch. */
+    int graph_mode = 0;                    /* cz_context_set_graph_replay: 0 never (default), 1 from the second identical launch on */
+    uint64_t cfg_gen = 0;                  /* grows with every change of the context that a launch depends on */
+    hipStream_t gstream = nullptr;         /* the capture's origin stream (the caller's may be the NULL stream, which cannot capture) */
+    hipGraphExec_t g_exec = nullptr; cz_batch_args g_proto; size_t g_n = 0; uint64_t g_gen = 0;   /* the captured launch */
+    cz_batch_args g_seen_proto; size_t g_seen_n = 0; uint64_t g_seen_gen = 0; bool g_seen = false;   /* the last launch that went the ordinary way */
+    bool g_bad = false;                    /* capture failed once on this context: not tried again */
+    bool capturing = false, g_replayed = false;
+    bool g_timed_chain = false, g_timed_exec = false, g_timed_lit = false, g_timed_wx = false, g_timed_small = false; int g_grid = 0;
+    hipEvent_t ev_lit_dep = nullptr, ev_small_dep = nullptr;   /* inside a capture the timed events are external record nodes; waits go through these */
 };
 
-#define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; return CZ_E_HIP; } } while (0)
+#define CZ_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) { (ctx)->last_hip_error = (int)_e; (ctx)->last_hip_line = __LINE__; if (getenv("CZ_GRAPH_DEBUG")) fprintf(stderr, "CZ_HIP: error %d at line %d (capturing %d)\n", (int)_e, __LINE__, (int)(ctx)->capturing); return CZ_E_HIP; } } while (0)
 
 CZ_EXPORT int cz_abi_version(void) { return CZ_ABI_VERSION; }
 CZ_EXPORT void cz_context_destroy(cz_context* c);
@@ -199,6 +210,10 @@ CZ_EXPORT void cz_context_destroy(cz_context* c) {
     if (c->ev_e1) (void)hipEventDestroy(c->ev_e1);
     if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
     if (c->ev_x4) (void)hipEventDestroy(c->ev_x4);
+    if (c->g_exec) (void)hipGraphExecDestroy(c->g_exec);
+    if (c->gstream) (void)hipStreamDestroy(c->gstream);
+    if (c->ev_lit_dep) (void)hipEventDestroy(c->ev_lit_dep);
+    if (c->ev_small_dep) (void)hipEventDestroy(c->ev_small_dep);
     if (c->stream4) (void)hipStreamDestroy(c->stream4);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
@@ -252,6 +267,7 @@ CZ_EXPORT int cz_context_last_chain_ms(cz_context* c, float* ms) {
  * to in-kernel chains, so any size is safe. */
 CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
     if (!c) return CZ_E_INVALID_ARG;
+    c->cfg_gen++;
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     if (c->chain_arena) { (void)hipFree(c->chain_arena); c->chain_arena = nullptr; c->chain_capacity = 0; }
@@ -287,6 +303,7 @@ CZ_EXPORT int cz_context_set_chain_arena(cz_context* c, size_t bytes) {
  * are decoded entirely by cz_decode_frames_kernel. */
 CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
     if (!c) return CZ_E_INVALID_ARG;
+    c->cfg_gen++;
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
     if (c->lit_arena) { (void)hipFree(c->lit_arena); c->lit_arena = nullptr; c->lit_capacity = 0; }
@@ -321,9 +338,9 @@ CZ_EXPORT int cz_context_set_literal_arena(cz_context* c, size_t bytes) {
 }
 
 /* Frames the pre-pass finished run on cz_execute_frames_kernel (default, 1) or, like every other frame, on cz_decode_frames_kernel (0). */
-CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->exec_kernel = on != 0; c->exec_variant_force = on == 4 || on == 8 ? (uint32_t)on : 0u; return CZ_OK; }
+CZ_EXPORT int cz_context_set_exec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->exec_kernel = on != 0; c->exec_variant_force = on == 4 || on == 8 ? (uint32_t)on : 0u; return CZ_OK; }
 
-CZ_EXPORT int cz_context_set_debug_flags(cz_context* c, uint32_t flags) { if (!c) return CZ_E_INVALID_ARG; c->debug_flags = flags; return CZ_OK; }
+CZ_EXPORT int cz_context_set_debug_flags(cz_context* c, uint32_t flags) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->debug_flags = flags; return CZ_OK; }
 CZ_EXPORT int cz_context_debug_read_chain_arena(cz_context* c, void* dst, size_t bytes, uint64_t* units_in_use) {
     if (!c || (bytes && !dst)) return CZ_E_INVALID_ARG;
     if (units_in_use) *units_in_use = 0;
@@ -335,11 +352,11 @@ CZ_EXPORT int cz_context_debug_read_chain_arena(cz_context* c, void* dst, size_t
     if (units_in_use) { unsigned long long top = 0; CZ_HIP(c, hipMemcpy(&top, c->chain_top, 8, hipMemcpyDeviceToHost)); *units_in_use = 64ull + top; }
     return CZ_OK;
 }
-CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
+CZ_EXPORT int cz_context_set_verify_checksum(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->verify_checksum = on ? 1u : 0u; return CZ_OK; }
 
 /* Frames whose first sequences section has fewer sequences than this are not pre-passed (default 0: every frame that has
  * sequences is; with the block-parallel pre-pass that measured fastest on the corpus-like mix too). */
-CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->chain_min_nseq = n; return CZ_OK; }
+CZ_EXPORT int cz_context_set_chain_min_sequences(cz_context* c, uint32_t n) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->chain_min_nseq = n; return CZ_OK; }
 
 /* Diagnostics of the last batch launch (synchronises): how many of its n frames got chain records from the pre-pass,
  * and how many had their literals decoded by the huff0 kernels. */
@@ -375,7 +392,7 @@ CZ_EXPORT int cz_context_last_literals_tail_ms(cz_context* c, float* ms) {
 /* The chain pre-pass as two launches — large blocks / all others — with the early execute launches behind the second (1), or one
    launch and the execute stage behind all of it (0, the default: on the corpus-like mix the small blocks' launch takes as long as
    the large blocks' — table parse and build per block, not chain steps — so nothing is ready early; profiles/r5/NOTES.md). */
-CZ_EXPORT int cz_context_set_early_execute(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->early_execute = on != 0; return CZ_OK; }
+CZ_EXPORT int cz_context_set_early_execute(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->early_execute = on != 0; return CZ_OK; }
 /* When the small blocks' chains and every literal of the last launch were done, in ms from its start (0: not a split launch). */
 CZ_EXPORT int cz_context_last_small_ms(cz_context* c, float* ms) {
     if (!c || !ms) return CZ_E_INVALID_ARG;
@@ -387,14 +404,25 @@ CZ_EXPORT int cz_context_last_small_ms(cz_context* c, float* ms) {
     return CZ_OK;
 }
 /* Far-offset batches run cz_wexec_kernel side by side with cz_execute_frames_kernel (default, 1), or cz_execute_frames_kernel alone (0). */
-CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->wexec_kernel = on != 0; return CZ_OK; }
+CZ_EXPORT int cz_context_set_wexec_kernel(cz_context* c, int on) { if (!c) return CZ_E_INVALID_ARG; c->cfg_gen++; c->wexec_kernel = on != 0; return CZ_OK; }
 /* A/B knobs of the side-by-side execute stage: CUs cz_wexec_kernel runs on (0: half), frames per CU of it that cz_execute_frames_kernel
    leaves to it at the end of a batch (0: default), force = 1: side by side whatever the batch's offsets look like. */
 CZ_EXPORT int cz_context_set_wexec_tuning(cz_context* c, int cus, int leave_per_cu, int force) {
     if (!c || cus < 0 || leave_per_cu < 0) return CZ_E_INVALID_ARG;
+    c->cfg_gen++;
     c->wexec_cus = cus; if (leave_per_cu) c->wexec_leave_per_cu = leave_per_cu; c->wexec_force = force == 2 ? 2u : (force ? 1u : 0u);   /* 1: side by side whatever the offsets; 2: never the large frames of a near-offset batch alone (A/B) */
     return CZ_OK;
 }
+/* A batch launch that repeats the one before it (same pointers, sizes and context settings; the bytes may differ) is captured as a
+   hipGraph and replayed from then on: 1; default 0 = every launch is enqueued operation by operation. */
+CZ_EXPORT int cz_context_set_graph_replay(cz_context* c, int on) {
+    if (!c) return CZ_E_INVALID_ARG;
+    c->graph_mode = on != 0; c->g_seen = false; c->g_bad = false;
+    if (!on && c->g_exec) { CZ_HIP(c, hipSetDevice(c->device)); CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
+    return CZ_OK;
+}
+/* 1 when the most recent batch launch was the replay of a captured graph. */
+CZ_EXPORT int cz_context_last_launch_was_replay(const cz_context* c) { return c && c->g_replayed ? 1 : 0; }
 /* Diagnostics of the most recent batch launch (synchronises): what cz_chain_kernel summed from the blocks' code tables, in sequences
    x 4 — with near offset codes (2..13), with far ones (14 and up), with a literal run above 8 or a match above 16 bytes: what
    cz_wx_side_by_side and cz_exec_variant decide from. */
@@ -464,9 +492,24 @@ CZ_EXPORT int cz_context_last_exec_ms(cz_context* c, float* ms) {
 }
 
 /* ------------------------------------------------------------------ launch */
-static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
-    if (n == 0) return CZ_OK;
-    if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
+#define CZ_E_NOGRAPH (-32000)            /* internal: this launch needs something a stream capture cannot hold (an allocation) */
+/* Enqueues one batch launch on `s0` and the context's other streams.  With c->capturing, s0 is the origin stream of a capture:
+   nothing may allocate or synchronise (CZ_E_NOGRAPH), and the events the cz_context_last_*_ms calls read are recorded as external
+   event nodes, so that a replay of the graph stamps them again. */
+static int cz_enqueue(cz_context* c, const cz_batch_args& proto, size_t n, hipStream_t s0) {
+    const bool cap = c->capturing;
+    /* a timed event: inside a capture an event-record NODE behind the stream's last captured nodes, which then takes their place */
+    auto rec_t = [&](hipEvent_t ev, hipStream_t st) -> hipError_t {
+        if (!cap) return hipEventRecord(ev, st);
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone; unsigned long long id = 0; hipGraph_t g = nullptr; const hipGraphNode_t* deps = nullptr; size_t ndeps = 0;
+        hipError_t e = hipStreamGetCaptureInfo_v2(st, &status, &id, &g, &deps, &ndeps);
+        if (e != hipSuccess) return e;
+        if (status != hipStreamCaptureStatusActive || !g) return hipErrorStreamCaptureInvalidated;
+        hipGraphNode_t node = nullptr;
+        e = hipGraphAddEventRecordNode(&node, g, deps, ndeps, ev);
+        if (e != hipSuccess) return e;
+        return hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+    };
     cz_batch_args a = proto;
     a.n = (uint32_t)n; a.work_counter = c->work_counter; a.lit_scratch = c->lit_scratch; a.lit_scratch_stride = CZ_WG_SCRATCH_BYTES;
     a.prof = c->d_prof; a.verify_checksum = a.tasks ? 0 : c->verify_checksum; a.debug_flags = c->debug_flags;
@@ -476,18 +519,22 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (const char* e = getenv("CZ_GRID_PER_CU")) { const int g = atoi(e) * c->num_cu; if (g > 0 && g < grid) grid = g; }
 #endif
     if (c->lit_slots < grid) {                                          /* one literal scratch region per resident workgroup */
-        if (c->lit_scratch) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->lit_scratch); c->lit_scratch = nullptr; c->lit_slots = 0; }
+        if (cap) return CZ_E_NOGRAPH;
+        c->cfg_gen++;
+        if (c->lit_scratch) { CZ_HIP(c, hipStreamSynchronize(s0)); (void)hipFree(c->lit_scratch); c->lit_scratch = nullptr; c->lit_slots = 0; }
         const int slots = grid <= 16 ? 16 : c->grid_max;
         CZ_HIP(c, hipMalloc((void**)&c->lit_scratch, (size_t)slots * CZ_WG_SCRATCH_BYTES)); c->lit_slots = slots;
         a.lit_scratch = c->lit_scratch;
     }
-    CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, c->chain_arena && !proto.tasks ? CZ_CTL_BLOCK_BYTES : 64, c->stream));   /* the whole control block */
-    CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, c->chain_arena && !proto.tasks ? CZ_CTL_BLOCK_BYTES : 64, s0));   /* the whole control block */
+    if (!cap) CZ_HIP(c, hipEventRecord(c->ev_start, s0));   /* (a replayed graph: cz_launch records it in front of the graph) */
     a.chain_arena = nullptr; a.chain_capacity = 0; a.chain_top = nullptr; a.frame_first = nullptr; a.chain_counter = nullptr;
     if (c->chain_arena && !a.tasks) {
         /* the pre-pass: block list (cz_scan_kernel), then the FSE chains of all blocks (cz_chain_kernel) -> records in the arena */
         if (c->frame_first_cap < n) {
-            if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
+            if (cap) return CZ_E_NOGRAPH;
+            c->cfg_gen++;
+            if (c->frame_first) { CZ_HIP(c, hipStreamSynchronize(s0)); (void)hipFree(c->frame_first); c->frame_first = nullptr; c->frame_first_cap = 0; }
             CZ_HIP(c, hipMalloc((void**)&c->frame_first, n * 8));        /* (frame_first_cap is set once every list below is there: a failure in between leaves the context asking again) */
             if (c->frame_order) (void)hipFree(c->frame_order);
             c->frame_order = nullptr;
@@ -508,7 +555,9 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         const bool lit_pass = c->lit_arena != nullptr;
         if (lit_pass) {
             if (c->lit_first_cap < n) {
-                if (c->lit_first) { CZ_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->lit_first); c->lit_first = nullptr; c->lit_first_cap = 0; }
+                if (cap) return CZ_E_NOGRAPH;
+                c->cfg_gen++;
+                if (c->lit_first) { CZ_HIP(c, hipStreamSynchronize(s0)); (void)hipFree(c->lit_first); c->lit_first = nullptr; c->lit_first_cap = 0; }
                 CZ_HIP(c, hipMalloc((void**)&c->lit_first, n * 8)); c->lit_first_cap = n;
                 if (c->frame_pre) (void)hipFree(c->frame_pre);
                 c->frame_pre = nullptr;
@@ -521,6 +570,8 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         const bool use_exec = c->exec_kernel && lit_pass && !c->batch_dict;
         bool use_wx = use_exec && c->wexec_kernel;
         if (use_wx && !c->wexec_ready) {
+            if (cap) return CZ_E_NOGRAPH;
+            c->cfg_gen++;
             /* (a workgroup of cz_wexec_kernel asks for more LDS than the default limit: where the runtime will not grant it,
                cz_execute_frames_kernel does the whole batch, as with cz_context_set_wexec_kernel(ctx, 0)) */
             if (hipFuncSetAttribute((const void*)cz_wexec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WX_LDS_BYTES) != hipSuccess ||
@@ -532,8 +583,8 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
         a.blk_desc = c->blk_desc; a.blk_capacity = c->blk_capacity; a.scan_ctl = c->scan_ctl; a.frame_order = c->frame_order; a.scan_wave = c->scan_wave;
         if (use_exec) { a.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 24); a.fallback_count = (uint32_t*)((uint8_t*)c->chain_top + 28); a.fallback_list = c->fallback_list; }
         const int sgrid = (int)((n + CZ_WG_THREADS - 1) / CZ_WG_THREADS);
-        a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
-        a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        a.scan_pass = 0; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, s0, a);
+        a.scan_pass = 1; hipLaunchKernelGGL(cz_scan_kernel, dim3(sgrid), dim3(CZ_WG_THREADS), 0, s0, a);
         CZ_HIP(c, hipGetLastError());
         /* With the execute stage on, the chain pre-pass is TWO launches (czstd_types.h, CZ_BIG_BLOCK_SEQS): the large blocks on the
            context's stream — the batch lasts as long as its longest chain —, all others on a stream of their own, followed there by
@@ -547,6 +598,8 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
            cz_wexec_kernel's early launch; stream3 — cz_tile_kernel, then cz_execute_frames_kernel's early launch; stream4 — small
            chains, cz_huf_kernel, then cz_execute_frames_kernel's later launch. */
         if (split && !c->stream4) {
+            if (cap) return CZ_E_NOGRAPH;
+            c->cfg_gen++;
             if (hipStreamCreateWithFlags(&c->stream4, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev_small) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_w1, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_x4, hipEventDisableTiming) != hipSuccess) {
@@ -561,27 +614,27 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
            bytes), after all literals; its output is the same bytes again.  Read the kernel trace, not the event times. */
         const char* ovl = use_exec ? getenv("CZ_EXP_OVERLAP") : nullptr;
         if (ovl) {
-            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, c->stream, a);
-            CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            hipLaunchKernelGGL(cz_huf_kernel, dim3(c->huf_grid), dim3(CZH_THREADS), 0, s0, a);
+            CZ_HIP(c, hipEventRecord(c->ev_fork, s0));
             CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             cz_batch_args a2 = a; a2.exec_counter = c->work_counter;
             hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(atoi(ovl) * c->num_cu), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream2, a2);
             CZ_HIP(c, hipEventRecord(c->ev_join, c->stream2));
             a.chain_grid = (uint32_t)c->chain_grid;
-            hipLaunchKernelGGL(cz_chain_kernel, dim3(c->chain_grid), dim3(CZ_WG_THREADS), 0, c->stream, a);
-            CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, c->stream));
-            CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+            hipLaunchKernelGGL(cz_chain_kernel, dim3(c->chain_grid), dim3(CZ_WG_THREADS), 0, s0, a);
+            CZ_HIP(c, hipStreamWaitEvent(s0, c->ev_join, 0));
+            CZ_HIP(c, hipMemsetAsync(c->work_counter, 0, 4, s0));
+            CZ_HIP(c, hipEventRecord(c->ev_fork, s0));
         }
 #endif
-        if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        if (lit_pass) CZ_HIP(c, hipEventRecord(c->ev_fork, s0));
         const int cgrid = c->chain_grid;                                /* the waves take blocks off the list until it is empty */
         a.chain_grid = (uint32_t)(split ? 2 * cgrid : cgrid);           /* (cz_huf1_kernel stops when this many chain waves have counted themselves out) */
         a.chain_part = split ? 1u : 0u;
-        hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL(cz_chain_kernel, dim3(cgrid), dim3(CZ_WG_THREADS), 0, s0, a);
         CZ_HIP(c, hipGetLastError());
-        CZ_HIP(c, hipEventRecord(c->ev_mid, c->stream));
-        hipStream_t sl = c->stream;                                     /* the stream the rest of the pre-pass is enqueued on */
+        CZ_HIP(c, rec_t(c->ev_mid, s0));
+        hipStream_t sl = s0;                                     /* the stream the rest of the pre-pass is enqueued on */
         if (split) {
             sl = c->stream4;
             CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_fork, 0));
@@ -612,10 +665,12 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
             CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_join, 0));
             CZ_HIP(c, hipStreamWaitEvent(sl, c->ev_join3, 0));
             if (split) {
-                CZ_HIP(c, hipEventRecord(c->ev_small, sl));             /* the small blocks' chains and every literal: done */
-                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_small, 0));
+                CZ_HIP(c, rec_t(c->ev_small, sl));                      /* the small blocks' chains and every literal: done */
+                if (cap) CZ_HIP(c, hipEventRecord(c->ev_small_dep, sl));
+                CZ_HIP(c, hipStreamWaitEvent(s0, cap ? c->ev_small_dep : c->ev_small, 0));
             }
-            CZ_HIP(c, hipEventRecord(c->ev_lit, c->stream));            /* all of the pre-pass done */
+            CZ_HIP(c, rec_t(c->ev_lit, s0));                     /* all of the pre-pass done */
+            if (cap) CZ_HIP(c, hipEventRecord(c->ev_lit_dep, s0));
             c->timed_lit = true;
         } else c->timed_lit = false;
         c->timed_chain = true;
@@ -634,12 +689,12 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 e.exec_counter = (uint32_t*)((uint8_t*)c->chain_top + 12);
                 if (use_wx) {                                           /* (first: its workgroups need whole CUs) */
                     e.wx_counter = (uint32_t*)((uint8_t*)c->chain_top + 8); e.wx_cus = 0;
-                    CZ_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_small, 0));
+                    CZ_HIP(c, hipStreamWaitEvent(c->stream2, cap ? c->ev_small_dep : c->ev_small, 0));
                     hipLaunchKernelGGL(cz_wexec_kernel, dim3(c->num_cu), dim3(WX_THREADS), WX_LDS_BYTES, c->stream2, e);
                     CZ_HIP(c, hipGetLastError());
                     CZ_HIP(c, hipEventRecord(c->ev_w1, c->stream2));
                 }
-                CZ_HIP(c, hipStreamWaitEvent(c->stream3, c->ev_small, 0));
+                CZ_HIP(c, hipStreamWaitEvent(c->stream3, cap ? c->ev_small_dep : c->ev_small, 0));
                 hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream3, e);
                 CZ_HIP(c, hipGetLastError());
                 CZ_HIP(c, hipEventRecord(c->ev_e1, c->stream3));
@@ -661,46 +716,109 @@ static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
                 a.wx_leave = a.wx_cus * (uint32_t)c->wexec_leave_per_cu;
                 const bool exec_first = (c->debug_flags & CZ_DEBUG_EXEC_FIRST) != 0;   /* test knob: the other submission order */
                 if (!exec_first) {
-                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
+                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, s0, a);
                     CZ_HIP(c, hipGetLastError());
-                    CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
+                    CZ_HIP(c, rec_t(c->ev_wx, s0));
                 }
-                CZ_HIP(c, hipStreamWaitEvent(sx, c->ev_lit, 0));
+                CZ_HIP(c, hipStreamWaitEvent(sx, cap ? c->ev_lit_dep : c->ev_lit, 0));
                 hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);
                 hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, sx, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
                 CZ_HIP(c, hipEventRecord(split ? c->ev_x4 : c->ev_join, sx));
                 if (exec_first) {
                     CZ_HIP(c, hipEventRecord(c->ev_fork, sx));          /* (free by now: an event behind the other kernel's SUBMISSION is the best a host can do to put this one second) */
-                    CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_lit, 0));
-                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, c->stream, a);
+                    CZ_HIP(c, hipStreamWaitEvent(s0, cap ? c->ev_lit_dep : c->ev_lit, 0));
+                    hipLaunchKernelGGL(cz_wexec_kernel, dim3(wgrid), dim3(WX_THREADS), WX_LDS_BYTES, s0, a);
                     CZ_HIP(c, hipGetLastError());
-                    CZ_HIP(c, hipEventRecord(c->ev_wx, c->stream));
+                    CZ_HIP(c, rec_t(c->ev_wx, s0));
                 }
                 c->timed_wx = true;
-                CZ_HIP(c, hipStreamWaitEvent(c->stream, split ? c->ev_x4 : c->ev_join, 0));
+                CZ_HIP(c, hipStreamWaitEvent(s0, split ? c->ev_x4 : c->ev_join, 0));
             } else {
                 /* the frames the pre-pass finished: cz_execute_frames_kernel (no decoders: 3 KB of LDS per wave and registers of its
                    own); it lists every frame it cannot do for cz_decode_frames_kernel */
-                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);
-                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, c->stream, a);   /* (only one of the two builds does anything) */
+                hipLaunchKernelGGL(czx::cz_execute_frames_kernel, dim3(egrid), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, s0, a);
+                hipLaunchKernelGGL(czx8::cz_execute_frames8_kernel, dim3(egrid8), dim3(CZ_WG_THREADS), CZ_EXEC_DYN_LDS, s0, a);   /* (only one of the two builds does anything) */
                 CZ_HIP(c, hipGetLastError());
             }
             if (split) {                                                /* the early launches may outlast these */
-                CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_e1, 0));
-                if (use_wx) CZ_HIP(c, hipStreamWaitEvent(c->stream, c->ev_w1, 0));
+                CZ_HIP(c, hipStreamWaitEvent(s0, c->ev_e1, 0));
+                if (use_wx) CZ_HIP(c, hipStreamWaitEvent(s0, c->ev_w1, 0));
             }
-            CZ_HIP(c, hipEventRecord(c->ev_mid2, c->stream));
+            CZ_HIP(c, rec_t(c->ev_mid2, s0));
             c->timed_exec = true;
         }
     } else { c->timed_chain = false; c->timed_exec = false; c->timed_lit = false; c->timed_wx = false; c->timed_small = false; }
     /* (A launch of the record-consuming frames without the FSE tables in LDS was measured: the
        kernel is VGPR-limited to 16 waves per CU either way, so one launch serves all frames.) */
-    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_MAIN_DYN_LDS, c->stream, a);
+    hipLaunchKernelGGL(cz_decode_frames_kernel, dim3(grid), dim3(CZ_WG_THREADS), CZ_MAIN_DYN_LDS, s0, a);
     CZ_HIP(c, hipGetLastError());
-    CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));
+    if (!cap) CZ_HIP(c, hipEventRecord(c->ev_stop, s0));
     c->timed = true; c->last_grid = grid;
     return CZ_OK;
+}
+
+/* A replay of the captured launch: the same kernels, grids, arguments and dependencies, submitted as one graph.  The start and stop
+   events stay outside it, on the caller's stream, so cz_context_last_kernel_ms covers the whole graph. */
+static int cz_replay(cz_context* c) {
+    CZ_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    CZ_HIP(c, hipGraphLaunch(c->g_exec, c->stream));
+    CZ_HIP(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true; c->timed_chain = c->g_timed_chain; c->timed_exec = c->g_timed_exec; c->timed_lit = c->g_timed_lit; c->timed_wx = c->g_timed_wx;
+    c->timed_small = c->g_timed_small; c->last_grid = c->g_grid; c->g_replayed = true;
+    return CZ_OK;
+}
+/* Captures the launch on a stream of the context's own (cz_enqueue does exactly what it does otherwise) and replays it at once.
+   CZ_E_NOGRAPH: nothing was enqueued — the caller goes the ordinary way, and this context does not try again. */
+static int cz_capture(cz_context* c, const cz_batch_args& proto, size_t n) {
+    int where = 0, rc = 0; hipError_t e = hipSuccess, e2 = hipSuccess;
+    auto give_up = [&]() {
+        if (getenv("CZ_GRAPH_DEBUG")) fprintf(stderr, "cz_capture: gave up at %d (enqueue rc %d, hip error of the context %d at line %d, end capture %d, instantiate %d, last %d)\n", where, rc, c->last_hip_error, c->last_hip_line, (int)e, (int)e2, (int)hipGetLastError());
+        (void)hipGetLastError(); c->g_bad = true; return CZ_E_NOGRAPH; };
+    if (!c->gstream && hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { c->gstream = nullptr; return give_up(); }
+    if (!c->ev_lit_dep && hipEventCreateWithFlags(&c->ev_lit_dep, hipEventDisableTiming) != hipSuccess) { c->ev_lit_dep = nullptr; return give_up(); }
+    if (!c->ev_small_dep && hipEventCreateWithFlags(&c->ev_small_dep, hipEventDisableTiming) != hipSuccess) { c->ev_small_dep = nullptr; return give_up(); }
+    if (c->g_exec) { (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
+    where = 1;
+    if (hipStreamBeginCapture(c->gstream, hipStreamCaptureModeRelaxed) != hipSuccess) return give_up();
+    c->capturing = true;
+    rc = cz_enqueue(c, proto, n, c->gstream);
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(c->gstream, &g);
+    where = 2;
+    if (rc != CZ_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return give_up(); }
+    hipGraphExec_t ex = nullptr;
+    e2 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    where = 3;
+    if (e2 != hipSuccess || !ex) return give_up();
+    c->g_exec = ex; c->g_proto = proto; c->g_n = n; c->g_gen = c->cfg_gen;
+    c->g_timed_chain = c->timed_chain; c->g_timed_exec = c->timed_exec; c->g_timed_lit = c->timed_lit; c->g_timed_wx = c->timed_wx; c->g_timed_small = c->timed_small;
+    c->g_grid = c->last_grid;
+    return cz_replay(c);
+}
+/* One batch launch.  With cz_context_set_graph_replay(ctx, 1) the second launch in a row with the same arguments and context settings
+   is captured as a hipGraph; from then on such a launch is a replay.  What a launch enqueues depends on nothing
+   but its arguments and the context (no device read-back), so a replay is the same work by construction; the BYTES behind the
+   pointers may change between replays. */
+static int cz_launch(cz_context* c, const cz_batch_args& proto, size_t n) {
+    if (n == 0) return CZ_OK;
+    if (n > 0xFFFFFFFFull) return CZ_E_INVALID_ARG;
+    /* (not the early-execute arrangement: capturing its four streams ended in a host-side crash inside the ROCm 7.2 runtime) */
+    const bool eligible = c->graph_mode && !c->g_bad && !proto.tasks && c->chain_arena && !c->early_execute;
+    if (eligible) {
+        if (c->g_exec && c->g_n == n && c->g_gen == c->cfg_gen && !memcmp(&c->g_proto, &proto, sizeof proto)) return cz_replay(c);
+        if (c->g_seen && c->g_seen_n == n && c->g_seen_gen == c->cfg_gen && !memcmp(&c->g_seen_proto, &proto, sizeof proto)) {
+            const int rc = cz_capture(c, proto, n);
+            if (rc != CZ_E_NOGRAPH) return rc;
+        }
+    }
+    c->g_replayed = false;
+    const int rc = cz_enqueue(c, proto, n, c->stream);
+    c->g_seen = eligible && rc == CZ_OK;
+    if (c->g_seen) { c->g_seen_proto = proto; c->g_seen_n = n; c->g_seen_gen = c->cfg_gen; }
+    return rc;
 }
 
 /* What the arenas of a batch must hold, from the headers alone (cz_scan_kernel's counting pass over the batch as it sits on the
@@ -1152,6 +1270,7 @@ CZ_EXPORT int cz_context_set_dictionary(cz_context* c, const cz_dictionary* d) {
     if (!c || (d && d->ctx != c)) return CZ_E_INVALID_ARG;
     CZ_HIP(c, hipSetDevice(c->device));
     CZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->cfg_gen++;
     c->batch_dict = d;
     return CZ_OK;
 }

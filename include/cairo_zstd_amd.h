@@ -223,6 +223,16 @@ int cz_context_last_small_ms(cz_context* ctx, float* ms);
  * kernels handed to cz_decode_frames_kernel, each listed once whoever handed it back.  The list has no analogue in the reference:
  * it is the device-side form of "decode this frame by the reference's own order of steps" (src/frame_decoder.cairo:156-222). */
 int cz_context_last_fallback_count(cz_context* ctx, size_t* listed);
+/* A batch decode enqueues about 35 stream operations (kernels, events, joins).  When a launch repeats the one before it — the same
+ * pointers, sizes and context settings; the bytes behind the pointers may differ — it is captured as a hipGraph, and from then on
+ * such a launch is ONE graph submission (what a launch enqueues depends on its arguments and the context alone, never on the data).
+ * on = 1 turns that on; default 0: every launch is enqueued operation by operation (measured: 3 % of a Raw/RLE batch, 7 % of a
+ * batch of 2 000 frames, nothing on the entropy-coded configurations — profiles/r5/graph_replay_ab.txt).  Nothing in the reference
+ * corresponds to this: it is how the loop "decode the next batch into the same buffers" (src/frame_decoder.cairo:156-222 called
+ * frame after frame) can be submitted here. */
+int cz_context_set_graph_replay(cz_context* ctx, int on);
+/* 1 when the most recent batch launch was the replay of a captured graph. */
+int cz_context_last_launch_was_replay(const cz_context* ctx);
 /* The part of the most recent launch spent in cz_wexec_kernel (0 when it did not run). */
 int cz_context_last_wexec_ms(cz_context* ctx, float* ms);
 

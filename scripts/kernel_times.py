@@ -32,6 +32,8 @@ def child(kind, n):
         cz.lib().cz_context_set_exec_kernel(ctx._h, int(os.environ.get("CZ_EXEC", "1")))   # 0 off, 1 on, 4 / 8: that register budget whatever the batch looks like
         wxe = os.environ.get("CZ_WEXEC", "1").split(",")               # on[,cus[,leave_per_cu[,force]]]
         ctx.set_wexec_kernel(wxe[0] == "1", *(int(v) for v in wxe[1:3]), force=int(wxe[3]) if len(wxe) > 3 else 0)
+    if os.environ.get("CZ_GRAPH") is not None and hasattr(ctx, "set_graph_replay"):
+        ctx.set_graph_replay(os.environ["CZ_GRAPH"] == "1")
     if os.environ.get("CZ_EARLY") is not None and hasattr(ctx, "set_early_execute"):
         ctx.set_early_execute(os.environ["CZ_EARLY"] == "1")
     tot, ch, ex, lt, wx = [], [], [], [], []

@@ -548,6 +548,71 @@ def test_bench_configuration_all_frames(cz):
         c.close()
 
 
+def test_repeated_launch_is_replayed_as_a_graph(cz):
+    """A launch that repeats the one before it (same pointers, sizes, context settings) is captured as a hipGraph and replayed from
+    then on (cz_context_set_graph_replay(ctx, 1); off by default).  The replay must be the same work: outputs against the oracle before and
+    after the BYTES behind the same pointers are replaced by another batch (a graph holds pointers and grids, never data); a
+    change of the context's settings ends the replays until the new launch has repeated; with replay off nothing is captured;
+    the library's event times stay available in a replay (its events are event-record nodes of the graph)."""
+    import torch
+    from cairo_zstd_amd import synth
+    dev = torch.device("cuda:0")
+    for kind, n in (("mix", 500), ("full_4a", 260), ("raw_rle", 300)):
+        batches = [synth.generate(kind, n, first_index=fi) for fi in (5, 7001)]
+        in_bytes = max(len(b.base) for b in batches)
+        cap_each = np.maximum(batches[0].regen, batches[1].regen).astype(np.uint64) + 256
+        out_off = np.concatenate([[0], np.cumsum(cap_each)[:-1]]).astype(np.uint64)
+        total = int(cap_each.sum())
+        t_in = torch.zeros(in_bytes, dtype=torch.uint8, device=dev)
+        t_off, t_len = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+        t_ooff, t_ocap = torch.from_numpy(out_off.astype(np.int64)).to(dev), torch.from_numpy(cap_each.astype(np.int64)).to(dev)
+        t_out = torch.empty(total, dtype=torch.uint8, device=dev)
+        t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        refs = []
+        for b in batches:
+            ref, olen, ost = oracle.decode_batch(b.base, b.off, b.length, out_off, cap_each, total, nthreads=os.cpu_count() or 8)
+            assert (ost == 0).all() and (olen == b.regen).all()
+            refs.append(ref)
+
+        def load(b):
+            t_in[:len(b.base)].copy_(torch.from_numpy(b.base).to(dev))
+            t_off.copy_(torch.from_numpy(b.off.astype(np.int64)).to(dev))
+            t_len.copy_(torch.from_numpy(b.length.astype(np.int64)).to(dev))
+
+        def run(c, b, ref):
+            t_out.fill_(0xA5)
+            c.decode_batch_device(t_in.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, t_out.data_ptr(), t_ooff.data_ptr(), t_ocap.data_ptr(), t_res.data_ptr())
+            torch.cuda.synchronize()
+            res, out = t_res.cpu().numpy().view(cz.RESULT_DTYPE), t_out.cpu().numpy()
+            assert (res["status"] == 0).all() and (res["bytes_produced"] == b.regen).all(), kind
+            for i in range(n):
+                lo, hi = int(out_off[i]), int(out_off[i] + b.regen[i])
+                assert oracle.xxh64(out[lo:hi]) == oracle.xxh64(ref[lo:hi]), (kind, i)
+            return c.last_launch_was_replay()
+
+        c = cz.Context(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            c.set_chain_arena(int(max(b.length.sum() for b in batches)) * 6 + (64 << 20))
+            c.set_literal_arena(int(max(b.regen.sum() for b in batches)) + (16 << 20))
+            load(batches[0])
+            assert [run(c, batches[0], refs[0]) for _ in range(2)] == [False, False], kind   # (off by default)
+            c.set_graph_replay(True)
+            assert [run(c, batches[0], refs[0]) for _ in range(4)] == [False, True, True, True], kind
+            ms, chain = c.last_kernel_ms(), c.last_chain_ms()
+            assert 0.0 < chain <= ms, (kind, ms, chain)                 # (stamped by the replay itself)
+            load(batches[1])                                            # other frames behind the same pointers
+            assert [run(c, batches[1], refs[1]) for _ in range(2)] == [True, True], kind
+            c.set_verify_checksum(True)                                 # the context changed: an ordinary launch, then a new graph
+            assert [run(c, batches[1], refs[1]) for _ in range(3)] == [False, True, True], kind
+            c.set_graph_replay(False)
+            assert [run(c, batches[1], refs[1]) for _ in range(3)] == [False, False, False], kind
+            c.set_graph_replay(True)
+            load(batches[0])
+            assert [run(c, batches[0], refs[0]) for _ in range(3)] == [False, True, True], kind
+        finally:
+            c.close()
+
+
 def test_execute_frames_kernel_matches_oracle(cz):
     """cz_execute_frames_kernel (the decode kernel's source without its decoders, for the frames the pre-pass finished) followed
     by cz_decode_frames_kernel on the frames it hands over: same results as the oracle on both kinds."""
