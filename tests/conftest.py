@@ -13,6 +13,29 @@ REFERENCE_CORPUS = "/root/reference/data/decode_corpus"  # only present in the b
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "xdist_group(name): tests of one group stay on one worker (pytest-xdist)")
+    _spread_cpu_tests(config)
+
+
+def _spread_cpu_tests(config):
+    """On a box WITHOUT a GPU the suite is dominated by the emulator tests (tests/emu: the kernel source with lanes as threads under
+    ASan — each run is one mostly serial program), so the tests are spread over a few worker processes when pytest-xdist is there
+    and the command line did not ask for anything itself.  Never on a GPU box: GPU tests run in ONE process.  CZ_TESTS_SERIAL=1 turns
+    it off."""
+    if os.path.exists("/dev/kfd") or hasattr(config, "workerinput") or os.environ.get("CZ_TESTS_SERIAL") == "1":
+        return
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) or getattr(config.option, "dist", "no") != "no":
+        return
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return
+    workers = min(4, os.cpu_count() or 1)
+    if workers < 2:
+        return
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "emu_decode"], stdout=subprocess.DEVNULL)   # once, before the workers ask for it
+    config.option.numprocesses = workers
+    config.option.dist = "loadgroup"
+    config.option.tx = ["popen"] * workers
 
 
 def corpus_pairs(max_orig: int | None = None):

@@ -14,6 +14,8 @@ import torch.multiprocessing as mp
 
 import oracle
 from cairo_zstd_amd import dist as czdist
+
+pytestmark = pytest.mark.xdist_group("gloo")        # (one worker: the rendezvous tests do not share a box's ports and cores with each other)
 from cairo_zstd_amd import synth
 
 F = 24
