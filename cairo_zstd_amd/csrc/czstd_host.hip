@@ -778,7 +778,7 @@ static int cz_capture(cz_context* c, const cz_batch_args& proto, size_t n) {
     if (!c->gstream && hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess) { c->gstream = nullptr; return give_up(); }
     if (!c->ev_lit_dep && hipEventCreateWithFlags(&c->ev_lit_dep, hipEventDisableTiming) != hipSuccess) { c->ev_lit_dep = nullptr; return give_up(); }
     if (!c->ev_small_dep && hipEventCreateWithFlags(&c->ev_small_dep, hipEventDisableTiming) != hipSuccess) { c->ev_small_dep = nullptr; return give_up(); }
-    if (c->g_exec) { (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }
+    if (c->g_exec) { if (hipStreamSynchronize(c->stream) != hipSuccess) return give_up(); (void)hipGraphExecDestroy(c->g_exec); c->g_exec = nullptr; }   /* (its last replay may still be running) */
     where = 1;
     if (hipStreamBeginCapture(c->gstream, hipStreamCaptureModeRelaxed) != hipSuccess) return give_up();
     c->capturing = true;
