@@ -2,7 +2,8 @@
 """Diagnostic: the same batch decoded over and over through the pre-pass pipeline (three streams, seven kernels), every run into a
 freshly poisoned buffer and compared on the device with the first run (which is compared with the oracle) — looks for anything
 that depends on timing between the kernels.   python scripts/soak.py [repeats=40] [workloads]
-CZ_WEXEC=force: every listed frame on cz_wexec_kernel whatever the batch's offset codes say; CZ_WEXEC=0: never."""
+CZ_WEXEC=force: every listed frame on cz_wexec_kernel whatever the batch's offset codes say; CZ_WEXEC=0: never.
+CZ_GRAPH=1: the repeated launch is captured as a hipGraph and replayed (cz_context_set_graph_replay)."""
 import os
 import sys
 
@@ -35,16 +36,21 @@ for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw
     ctx.set_literal_arena(int(b.regen.sum()) + (16 << 20))
     wx = os.environ.get("CZ_WEXEC", "1")
     ctx.set_wexec_kernel(wx != "0", force=wx == "force")
+    if os.environ.get("CZ_GRAPH") == "1":
+        ctx.set_graph_replay(True)
     ref_out = ref_res = None
-    bad = 0
+    bad = replays = 0
+    t_out = torch.empty(total + 256, dtype=torch.uint8, device=dev)      # (the same buffers every run: a launch that repeats can be replayed as a graph)
+    t_res = torch.empty(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     for it in range(reps + 1):
-        t_out = torch.full((total + 256,), 0xA5, dtype=torch.uint8, device=dev)
-        t_res = torch.zeros(n * cz.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        t_out.fill_(0xA5)
+        t_res.zero_()
         torch.cuda.synchronize()                                        # torch's default stream has handle 0: the context then runs on a stream of its own, not ordered with the fills above
         ctx.decode_batch_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, t_out.data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t_res.data_ptr())
         torch.cuda.synchronize()
+        replays += int(ctx.last_launch_was_replay())
         if it == 0:
-            ref_out, ref_res = t_out, t_res
+            ref_out, ref_res = t_out.clone(), t_res.clone()
             res = t_res.cpu().numpy().view(cz.RESULT_DTYPE)
             o = t_out.cpu().numpy()
             _, olen, ost = oracle.decode_batch(b.base, b.off, b.length, out_off, out_cap, int(total) + 256, nthreads=32)
@@ -67,7 +73,7 @@ for kind, n in (("full_4a", 5000), ("mix", 12500), ("huf_literals", 3000), ("raw
                 got = t_res.cpu().numpy().view(cz.RESULT_DTYPE)[fr]; want = ref_res.cpu().numpy().view(cz.RESULT_DTYPE)[fr]
                 msg += f"\n      got  {got}\n      want {want}"
             print(msg, flush=True)
-    print(f"{kind:14s} {reps} repeats, {bad} differing; cz_wexec_kernel listed / finished / handed on {ctx.last_wexec_counts()}", flush=True)
+    print(f"{kind:14s} {reps} repeats, {bad} differing; cz_wexec_kernel listed / finished / handed on {ctx.last_wexec_counts()}; launches replayed as a graph: {replays}", flush=True)
     bad_total += bad
     ctx.close()
 print("TOTAL DIFFERING", bad_total)
